@@ -1,0 +1,82 @@
+"""ctypes binding of libqtcnn_hip.so (the C ABI declared in include/qtcnn.h).
+
+There is no CPU or PyTorch fallback: if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C <pkg>/csrc`)
+every product entry point raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the process-wide HIP runtime first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqtcnn_hip.so")
+
+QT_F32, QT_BF16 = 0, 1
+QT_CONV_FWD, QT_CONV_DGRAD = 0, 1
+
+
+class QtError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", ctypes.c_int), ("mode", ctypes.c_int), ("batch", ctypes.c_int),
+        ("in_h", ctypes.c_int), ("in_w", ctypes.c_int),
+        ("out_h", ctypes.c_int), ("out_w", ctypes.c_int),
+        ("k_per_tap", ctypes.c_int), ("n_out", ctypes.c_int),
+        ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+        ("src_img_stride", ctypes.c_longlong),
+        ("src_row_stride", ctypes.c_int), ("src_pix_stride", ctypes.c_int),
+        ("quad", ctypes.c_int), ("relu", ctypes.c_int),
+    ]
+
+
+class ConvIO(ctypes.Structure):
+    _fields_ = [
+        ("src", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+        ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p), ("relu_mask", ctypes.c_void_p),
+        ("stats_partial", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises QtError (never falls back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QtError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the product path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.qt_last_error.restype = ctypes.c_char_p
+        _lib.qt_version.restype = ctypes.c_int
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().qt_last_error().decode(errors="replace")
+        raise QtError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def qt_dtype(torch_dtype):
+    if torch_dtype == torch.float32:
+        return QT_F32
+    if torch_dtype == torch.bfloat16:
+        return QT_BF16
+    raise QtError(f"unsupported activation dtype {torch_dtype}")

@@ -1,0 +1,110 @@
+// Shared device/host definitions for the QuadtreeCNN HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qtcnn.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define QT_WAVE 64
+#define QT_LDS_AS __attribute__((address_space(3)))
+
+// thread-local last-error text (qt_last_error)
+void qt_set_error(const char* fmt, ...);
+
+#define QT_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      qt_set_error(__VA_ARGS__);           \
+      return QT_ERR_INVALID_ARG;           \
+    }                                      \
+  } while (0)
+
+#define QT_CHECK_LAUNCH()                                              \
+  do {                                                                 \
+    hipError_t e_ = hipGetLastError();                                 \
+    if (e_ != hipSuccess) {                                            \
+      qt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,     \
+                   hipGetErrorString(e_));                             \
+      return QT_ERR_LAUNCH;                                            \
+    }                                                                  \
+  } while (0)
+
+template <typename T> struct QtElem;
+template <> struct QtElem<float> { static constexpr int kDtype = QT_F32; };
+template <> struct QtElem<bf16_t> { static constexpr int kDtype = QT_BF16; };
+
+// ---- 16-byte vector <-> 4 or 8 elements -----------------------------------
+__device__ __forceinline__ float qt_bf16_bits_to_f32(uint32_t bits16) {
+  return __uint_as_float(bits16 << 16);
+}
+
+// load N consecutive T as float (N*sizeof(T) must be 16 or 32 bytes aligned accordingly)
+template <typename T> struct QtVec8;  // 8 consecutive elements <-> float[8]
+template <> struct QtVec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct QtVec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = o;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float qt_to_f32(T v);
+template <> __device__ __forceinline__ float qt_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float qt_to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+// ---- MFMA: one 16-byte K-chunk per lane for both operands ---------------------
+// D[row][col] += sum_k A[row][k] * B[col][k]; lane l supplies row/col (l&15) and
+// the K-chunk (l>>4).  bf16: 8 k per chunk -> one 16x16x32 MFMA.  f32: 4 k per
+// chunk -> four 16x16x4 MFMAs (k-order inside the step is a permutation shared
+// by A and B, which a dot product does not see).
+template <typename T> struct QtMma;
+template <> struct QtMma<bf16_t> {
+  static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+        __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct QtMma<float> {
+  static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+// XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): blocks
+// that end up with consecutive logical ids share an XCD (and its L2).
+__device__ __forceinline__ int qt_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+static inline int qt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

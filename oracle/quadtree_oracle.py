@@ -1,0 +1,168 @@
+"""CPU oracle for the QuadtreeCNN hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A functional PyTorch-CPU fp32 restatement of the reference graph, driven by a
+flat `state_dict` (the reference's own key layout).  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this file; the product package never does and fails loudly when its HIP
+library is missing.
+
+Pinned by: tests/golden/*.npz, produced by tests/golden/make_golden.py which
+imports the reference's own `models.py` files by path and runs them on CPU
+(tests/test_oracle_golden.py checks this restatement against those vectors).
+The arithmetic itself lives in torch.nn / ATen and in torchvision's ResNet-18
+topology (both unpinned by the reference: no requirements file, no tests) --
+so parity is pinned to torch 2.10.0 CPU fp32 kernels, not by the reference.
+
+What each function follows:
+  resnet18 stem/stages  torchvision ResNet-18; reached by the
+                        reference at Quadtree_from scratch/models.py:221-230,
+                        resnet/models.py:76-88
+  quadrant split        Quadtree_from scratch/models.py:277-282, resnet/models.py:151-156
+  quadrant head         Quadtree_from scratch/models.py:234-238,284-287
+  global branch         Quadtree_from scratch/models.py:240-243,289; resnet/models.py:148-149
+  concat order          Quadtree_from scratch/models.py:291-294,300
+  numerical MLP         Quadtree_from scratch/models.py:255-260,297
+  classifier            Quadtree_from scratch/models.py:266-271,303; resnet/models.py:115-129
+  StandardResNetCNN     resnet/models.py:7-65
+"""
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _bn(sd, prefix, x, train):
+    return F.batch_norm(
+        x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+        sd[prefix + ".weight"], sd[prefix + ".bias"],
+        training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
+
+
+def _basic_block(sd, prefix, x, stride, train):
+    out = F.conv2d(x, sd[prefix + ".conv1.weight"], None, stride, 1)
+    out = F.relu(_bn(sd, prefix + ".bn1", out, train))
+    out = F.conv2d(out, sd[prefix + ".conv2.weight"], None, 1, 1)
+    out = _bn(sd, prefix + ".bn2", out, train)
+    if (prefix + ".downsample.0.weight") in sd:
+        idn = F.conv2d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0)
+        idn = _bn(sd, prefix + ".downsample.1", idn, train)
+    else:
+        idn = x
+    return F.relu(out + idn)
+
+
+def _layer(sd, name, x, stride, train):
+    x = _basic_block(sd, f"base_cnn.{name}.0", x, stride, train)
+    return _basic_block(sd, f"base_cnn.{name}.1", x, 1, train)
+
+
+def features_to_layer3(sd, image, train=False, taps=None):
+    """conv1-bn1-relu-maxpool-layer1-layer2-layer3: [B,3,224,224] -> [B,256,14,14]."""
+    x = F.conv2d(image, sd["base_cnn.conv1.weight"], None, 2, 3)
+    x = F.relu(_bn(sd, "base_cnn.bn1", x, train))
+    x = F.max_pool2d(x, 3, 2, 1)
+    if taps is not None:
+        taps["stem"] = x
+    x = _layer(sd, "layer1", x, 1, train)
+    if taps is not None:
+        taps["layer1"] = x
+    x = _layer(sd, "layer2", x, 2, train)
+    if taps is not None:
+        taps["layer2"] = x
+    x = _layer(sd, "layer3", x, 2, train)
+    if taps is not None:
+        taps["layer3"] = x
+    return x
+
+
+def _dropout(x, p, train, masks, name):
+    """Dropout with an optional injected keep-mask (values in {0,1}); the torch
+    RNG stream of the reference cannot be reproduced on another device, so
+    train-mode parity is checked with p=0 or an injected mask."""
+    if not train or p == 0.0:
+        return x
+    if masks is not None and name in masks:
+        return x * masks[name] / (1.0 - p)
+    return F.dropout(x, p, True)
+
+
+def quadrant_head(sd, q):
+    y = F.conv2d(q, sd["quadrant_processor.0.weight"], sd["quadrant_processor.0.bias"], 1, 1)
+    return F.max_pool2d(F.relu(y), 2, 2).flatten(1)
+
+
+def quadtree_forward(sd, image, numerical, mode="fusion", train=False,
+                     dropout_p=0.5, masks=None, taps=None):
+    """logits[B,C] of QuadtreeCNN.  mode per resnet/models.py:115-122."""
+    if mode not in ("fusion", "image_only", "numerical_only"):
+        raise ValueError(f"Invalid mode: {mode}")
+    feats = []
+    if mode in ("fusion", "image_only"):
+        base = features_to_layer3(sd, image, train, taps)
+        g = _layer(sd, "layer4", base, 2, train)
+        if taps is not None:
+            taps["layer4"] = g
+        g = F.adaptive_avg_pool2d(g, (1, 1)).flatten(1)
+        h, w = base.shape[2] // 2, base.shape[3] // 2
+        quads = [base[:, :, :h, :w], base[:, :, :h, w:], base[:, :, h:, :w], base[:, :, h:, w:]]
+        img = torch.cat([g] + [quadrant_head(sd, q) for q in quads], dim=1)
+        if taps is not None:
+            taps["image_features"] = img
+        feats.append(img)
+    if mode in ("fusion", "numerical_only"):
+        z = F.relu(F.linear(numerical, sd["numerical_mlp.0.weight"], sd["numerical_mlp.0.bias"]))
+        z = _dropout(z, dropout_p, train, masks, "numerical_mlp")
+        z = F.linear(z, sd["numerical_mlp.3.weight"], sd["numerical_mlp.3.bias"])
+        if taps is not None:
+            taps["numerical_features"] = z
+        feats.append(z)
+    fused = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
+    hdn = F.relu(F.linear(fused, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    if taps is not None:
+        taps["hidden"] = hdn
+    hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
+    return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
+def standard_resnet_forward(sd, image, train=False, dropout_p=0.5, masks=None, taps=None):
+    """logits[B,C] of StandardResNetCNN (numerical input ignored, resnet/models.py:56)."""
+    base = features_to_layer3(sd, image, train, taps)
+    g = _layer(sd, "layer4", base, 2, train)
+    if taps is not None:
+        taps["layer4"] = g
+    g = F.adaptive_avg_pool2d(g, (1, 1)).flatten(1)
+    hdn = F.relu(F.linear(g, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
+    return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
+def unique_params(sd, keys):
+    """Leaf copies (requires_grad) for `keys`; other entries cloned plain.
+    Aliased reference keys (features_extractor.*, global_processor.*) are not
+    needed by the functional form and are dropped."""
+    out = {}
+    for k, v in sd.items():
+        if not (k.startswith("base_cnn.") or k.startswith("quadrant_processor.")
+                or k.startswith("numerical_mlp.") or k.startswith("classifier.")):
+            continue
+        t = v.detach().clone()
+        if k in keys and t.is_floating_point():
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def trainable_keys(sd, frozen_backbone):
+    keys = []
+    for k, v in sd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf in ("running_mean", "running_var", "num_batches_tracked"):
+            continue
+        if k.startswith("base_cnn."):
+            if frozen_backbone or k.startswith("base_cnn.fc."):
+                continue
+            keys.append(k)
+        elif k.split(".")[0] in ("quadrant_processor", "numerical_mlp", "classifier"):
+            keys.append(k)
+    return keys

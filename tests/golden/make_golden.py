@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE on CPU (build container only).
+
+Imports the reference's own model files by path
+  /root/reference/Quadtree_from scratch/models.py
+  /root/reference/resnet/models.py
+with oracle/torchvision_standin first on sys.path (torchvision is absent here;
+the stand-in restates the ResNet-18 topology and never fetches weights), fills
+every tensor with the deterministic rule of <pkg>/synth.py, runs eval forwards
+and dropout-free train-mode forward+backward passes on seeded inputs and writes
+small .npz fixtures next to this file.  Only data is written: logits, per-stage
+checksums / strided samples, gradient checksums and the small gradients in
+full.  The 100 MB of weights and the inputs are regenerated from the rule on
+both sides and are not stored.
+
+Usage (from the repo root):  python tests/golden/make_golden.py
+"""
+import importlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+PKG = "multimodal-hierarchical-cnn-for-sun-salutation-pose-classification_amd"
+
+sys.path.insert(0, os.path.join(ROOT, "oracle", "torchvision_standin"))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module(PKG + ".synth")
+
+
+def load_ref(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def summary(t, nsample=256):
+    f = t.detach().double().flatten()
+    stride = max(1, f.numel() // nsample)
+    return {
+        "shape": np.array(t.shape, dtype=np.int64),
+        "sum": np.float64(f.sum().item()),
+        "abssum": np.float64(f.abs().sum().item()),
+        "sample": f[::stride][:nsample].numpy().astype(np.float32),
+    }
+
+
+def put(out, prefix, t, full_below=4097):
+    s = summary(t)
+    for k, v in s.items():
+        out[f"{prefix}/{k}"] = v
+    if t.numel() < full_below:
+        out[f"{prefix}/full"] = t.detach().float().numpy()
+
+
+def set_dropout_p(model, p):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = p
+
+
+def hook_taps(model, taps):
+    hs = []
+
+    def mk(name):
+        def fn(_m, _i, o):
+            taps[name] = o.detach()
+        return fn
+    b = model.base_cnn
+    hs.append(b.maxpool.register_forward_hook(mk("stem")))
+    for n in ("layer1", "layer2", "layer3", "layer4"):
+        hs.append(getattr(b, n).register_forward_hook(mk(n)))
+    if hasattr(model, "numerical_mlp"):
+        hs.append(model.numerical_mlp.register_forward_hook(mk("numerical_features")))
+    hs.append(model.classifier[1].register_forward_hook(mk("hidden")))
+    return hs
+
+
+def eval_case(model, images, feats, out, prefix, with_taps=True):
+    model.eval()
+    taps = {}
+    hs = hook_taps(model, taps) if with_taps else []
+    with torch.no_grad():
+        logits = model(images, feats)
+    for h in hs:
+        h.remove()
+    out[f"{prefix}/logits"] = logits.numpy()
+    for k, v in taps.items():
+        put(out, f"{prefix}/tap/{k}", v, full_below=0)
+
+
+def train_case(model, images, feats, labels, out, prefix):
+    model.train()
+    set_dropout_p(model, 0.0)
+    for p in model.parameters():
+        p.grad = None
+    logits = model(images, feats)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out[f"{prefix}/logits"] = logits.detach().numpy()
+    out[f"{prefix}/loss"] = np.float64(loss.item())
+    names = []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(name)
+        put(out, f"{prefix}/grad/{name}", p.grad)
+    out[f"{prefix}/grad_names"] = np.array(names)
+    for name, b in model.named_buffers():
+        if name.startswith("base_cnn.") and name.endswith(("running_mean", "running_var")):
+            put(out, f"{prefix}/buf/{name}", b, full_below=0)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    qs = load_ref(os.path.join(REF, "Quadtree_from scratch", "models.py"), "ref_qs_models")
+    rn = load_ref(os.path.join(REF, "resnet", "models.py"), "ref_rn_models")
+    C = 12
+
+    # ---- eval forwards, B=2 ------------------------------------------------
+    B = 2
+    images = synth.synth_images(B, salt=0)
+    feats = synth.synth_pose_features(B, salt=0, realistic=True)
+    out = {}
+    m = qs.QuadtreeCNN(num_classes=C)
+    m.load_state_dict(synth.synth_state_dict(m))
+    out["meta/state_dict_keys_quadtree"] = np.array(list(m.state_dict().keys()))
+    out["meta/param_names_quadtree"] = np.array([n for n, _ in m.named_parameters()])
+    eval_case(m, images, feats, out, "qs_quadtree_eval")
+    for mode in ("fusion", "image_only", "numerical_only"):
+        m = rn.QuadtreeCNN(num_classes=C, mode=mode)
+        m.load_state_dict(synth.synth_state_dict(m))
+        eval_case(m, images, feats, out, f"rn_{mode}_eval", with_taps=False)
+        out[f"meta/trainable_{mode}"] = np.int64(
+            sum(p.numel() for p in m.parameters() if p.requires_grad))
+    m = rn.StandardResNetCNN(num_classes=C)
+    m.load_state_dict(synth.synth_state_dict(m))
+    out["meta/state_dict_keys_standard"] = np.array(list(m.state_dict().keys()))
+    eval_case(m, images, None, out, "rn_standard_eval", with_taps=False)
+    np.savez_compressed(os.path.join(HERE, "eval_b2.npz"), **out)
+    print("eval_b2.npz:", len(out), "arrays")
+
+    # ---- train-mode forward+backward, B=4, dropout p=0 ----------------------
+    B = 4
+    images = synth.synth_images(B, salt=1)
+    feats = synth.synth_pose_features(B, salt=1, realistic=True)
+    labels = synth.synth_labels(B, C, salt=1)
+    out = {}
+    m = qs.QuadtreeCNN(num_classes=C)
+    m.load_state_dict(synth.synth_state_dict(m))
+    train_case(m, images, feats, labels, out, "qs_quadtree_train")
+    m = rn.QuadtreeCNN(num_classes=C, mode="fusion")
+    m.load_state_dict(synth.synth_state_dict(m))
+    train_case(m, images, feats, labels, out, "rn_fusion_train")
+    m = rn.StandardResNetCNN(num_classes=C)
+    m.load_state_dict(synth.synth_state_dict(m))
+    train_case(m, images, None, labels, out, "rn_standard_train")
+    np.savez_compressed(os.path.join(HERE, "train_b4.npz"), **out)
+    print("train_b4.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+"""GPU parity of the implicit-GEMM conv kernel (through the C ABI) against torch CPU fp32.
+
+Tolerances: f32 build 2e-5 of max|ref| (exact-f32 MFMA, different summation
+order); bf16 build 1.5e-2 (inputs are pre-rounded to bf16 on both sides, so the
+difference is the bf16 rounding of the output only).
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def run_conv(L, dt, x_nhwc, w_krsc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw, stride, pad,
+             mode, quad=0, relu=0, scale=None, shift=None, residual=None, relu_mask=None,
+             want_stats=False, strides=None, m_rows=None):
+    dev = x_nhwc.device
+    d = L.ConvDesc()
+    d.dtype = L.qt_dtype(dt)
+    d.mode = mode
+    d.batch = B
+    d.in_h, d.in_w = in_hw
+    d.out_h, d.out_w = out_hw
+    d.k_per_tap, d.n_out = k_per_tap, n_out
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    if strides is None:
+        c = x_nhwc.shape[-1]
+        strides = (x_nhwc.shape[1] * x_nhwc.shape[2] * c, x_nhwc.shape[2] * c, c)
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = strides
+    d.quad, d.relu = quad, relu
+    if m_rows is None:
+        m_rows = B * (4 if (quad and mode == L.QT_CONV_FWD) else 1) * out_hw[0] * out_hw[1]
+    y = torch.empty(m_rows, n_out, dtype=dt, device=dev)
+    stats = None
+    if want_stats:
+        rows = L.lib().qt_conv2d_stats_rows(ctypes.byref(d))
+        stats = torch.zeros(rows, 2, n_out, dtype=torch.float32, device=dev)
+    io = L.ConvIO(L.ptr(x_nhwc), L.ptr(w_krsc), L.ptr(y), L.ptr(scale), L.ptr(shift),
+                  L.ptr(residual), L.ptr(relu_mask), L.ptr(stats))
+    L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()), "qt_conv2d_igemm")
+    torch.cuda.synchronize()
+    return y, stats
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, Cout, H, k, stride, pad
+    (2, 64, 64, 56, 3, 1, 1),
+    (3, 64, 128, 56, 3, 2, 1),
+    (2, 64, 128, 56, 1, 2, 0),
+    (1, 256, 512, 14, 3, 2, 1),
+    (1, 512, 512, 7, 3, 1, 1),   # M = 49: ragged tile
+])
+def test_conv_fwd_epilogue(dt, cfg):
+    dev = _dev()
+    L = pkg("_lib")
+    B, Cin, Cout, H, k, s, p = cfg
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5).to(dt).float()
+    Ho = (H + 2 * p - k) // s + 1
+    res = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    raw = F.conv2d(x, w, None, s, p)
+    ref = F.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+
+    xd = nhwc(x).to(dev, dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev, dt)
+    # raw + stats
+    y, stats = run_conv(L, dt, xd, wd, B, (H, H), (Ho, Ho), Cin, Cout, k, k, s, p, L.QT_CONV_FWD,
+                        want_stats=True)
+    got = y.float().cpu().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
+    assert rel_err(got, raw) <= TOL[dt]
+    ssum = stats.sum(0).cpu()
+    assert rel_err(ssum[0], raw.sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    assert rel_err(ssum[1], (raw * raw).sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    # fused epilogue
+    y, _ = run_conv(L, dt, xd, wd, B, (H, H), (Ho, Ho), Cin, Cout, k, k, s, p, L.QT_CONV_FWD,
+                    relu=1, scale=scale.to(dev), shift=shift.to(dev),
+                    residual=nhwc(res).to(dev, dt).view(-1, Cout))
+    got = y.float().cpu().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 56, 3, 1, 1),
+    (2, 64, 128, 56, 3, 2, 1),
+    (2, 64, 128, 56, 1, 2, 0),
+    (1, 256, 512, 14, 3, 2, 1),
+])
+def test_conv_dgrad(dt, cfg):
+    dev = _dev()
+    L = pkg("_lib")
+    B, Cin, Cout, H, k, s, p = cfg
+    g = torch.Generator().manual_seed(2)
+    Ho = (H + 2 * p - k) // s + 1
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cout * k * k)) ** 0.5).to(dt).float()
+    dy = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    other = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    act = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    dx = torch.nn.grad.conv2d_input((B, Cin, H, H), w, dy, s, p)
+    ref = (dx + other) * (act > 0)
+
+    dyd = nhwc(dy).to(dev, dt)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dev, dt)  # [Cin][kh][kw][Cout]
+    y, _ = run_conv(L, dt, dyd, wt, B, (Ho, Ho), (H, H), Cout, Cin, k, k, s, p, L.QT_CONV_DGRAD,
+                    residual=nhwc(other).to(dev, dt).view(-1, Cin),
+                    relu_mask=nhwc(act).to(dev, dt).view(-1, Cin))
+    got = y.float().cpu().view(B, H, H, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_quadrant_conv_fwd_and_dgrad(dt):
+    """Quadrant split with zero halo at the seam
+    (/root/reference/Quadtree_from scratch/models.py:277-287)."""
+    dev = _dev()
+    L = pkg("_lib")
+    B, C, N = 3, 256, 128
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(B, C, 14, 14, generator=g).to(dt).float()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5).to(dt).float()
+    bias = torch.randn(N, generator=g) * 0.1
+    quads = [base[:, :, :7, :7], base[:, :, :7, 7:], base[:, :, 7:, :7], base[:, :, 7:, 7:]]
+    ref = torch.stack([F.relu(F.conv2d(q, w, bias, 1, 1)) for q in quads], 1)  # [B,4,N,7,7]
+    xd = nhwc(base).to(dev, dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev, dt)
+    y, _ = run_conv(L, dt, xd, wd, B, (7, 7), (7, 7), C, N, 3, 3, 1, 1, L.QT_CONV_FWD, quad=1, relu=1,
+                    shift=bias.to(dev), strides=(14 * 14 * C, 14 * C, C))
+    got = y.float().cpu().view(B, 4, 7, 7, N).permute(0, 1, 4, 2, 3)
+    assert rel_err(got, ref) <= TOL[dt]
+
+    # dgrad: per-quadrant gradient images -> un-split map
+    dyq = torch.randn(B, 4, N, 7, 7, generator=g).to(dt).float()
+    dbase = torch.zeros(B, C, 14, 14)
+    sl = [(slice(0, 7), slice(0, 7)), (slice(0, 7), slice(7, 14)), (slice(7, 14), slice(0, 7)), (slice(7, 14), slice(7, 14))]
+    for q in range(4):
+        dbase[:, :, sl[q][0], sl[q][1]] = torch.nn.grad.conv2d_input((B, C, 7, 7), w, dyq[:, q], 1, 1)
+    dyd = dyq.permute(0, 1, 3, 4, 2).contiguous().to(dev, dt)  # [B,4,7,7,N]
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dev, dt)
+    y, _ = run_conv(L, dt, dyd, wt, B, (7, 7), (14, 14), N, C, 3, 3, 1, 1, L.QT_CONV_DGRAD, quad=1,
+                    strides=(49 * N, 7 * N, N))
+    got = y.float().cpu().view(B, 14, 14, C).permute(0, 3, 1, 2)
+    assert rel_err(got, dbase) <= TOL[dt]
+
+
+def test_conv_rejects_bad_args():
+    _dev()
+    L = pkg("_lib")
+    d = L.ConvDesc()
+    d.dtype = 7
+    io = L.ConvIO()
+    st = L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), None)
+    assert st == -1 and b"dtype" in L.lib().qt_last_error()
