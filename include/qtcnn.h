@@ -84,6 +84,13 @@ typedef struct qt_conv_io {
 int qt_conv2d_stats_rows(const qt_conv_desc* desc);
 int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream);
 
+/* Weight gradient of the convolution described by `desc` (mode QT_CONV_FWD):
+ *   dw[n][tap][k] += sum_pixels dy[pixel][n] * x[pixel moved by tap][k]     (f32)
+ * replaces the conv/linear backward-weight ATen calls under loss.backward()
+ * (Quadtree_from scratch/Quadtree_train.py:65).  `dw` must be zeroed (or hold the
+ * running sum) by the caller: partial tiles are added with f32 atomics. */
+int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,326 @@
+// Weight-gradient of a convolution / linear layer on MFMA for gfx950.
+//
+// Replaces the conv2d / linear backward-weight ATen calls that loss.backward()
+// makes (/root/reference/Quadtree_from scratch/Quadtree_train.py:65) for the
+// layers built at Quadtree_from scratch/models.py:222-243,234-238,266-271.
+//
+//   dW[n][tap][c] += sum_pix dY[pix][n] * X[pix moved by tap][c]
+//
+// The contraction runs over PIXELS, which is the strided axis of both NHWC
+// operands.  Tiles are staged [pixel][channel] (channel contiguous, coalesced
+// 16-byte loads, zero fill of the halo in the register stage) and the
+// pixel-major MFMA fragments are produced by the hardware transposing LDS read
+// ds_read_b64_tr_b16 (bf16) or by plain ds_read_b32 (f32: one k per lane).  The
+// LDS image is XOR-swizzled per 32-byte block so both kinds of read are bank
+// conflict free.  The pixel axis is split over workgroups; partial tiles are
+// accumulated with global_atomic_add_f32 into the zero-initialised f32 gradient.
+#include "qt_common.h"
+
+namespace {
+
+struct FastDiv {
+  unsigned mul, shr;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
+  return (__umulhi(n, f.mul) + n) >> f.shr;  // exact for n < 2^31
+}
+
+struct WgradArgs {
+  const void* dy;   // [M][N]
+  const void* x;    // source activations
+  float* dw;        // [N][ntaps][KC] f32, accumulated into
+  long long x_img_stride;
+  int x_row_stride, x_pix_stride;
+  int M, N, KC;
+  int OH, OW, IH, IW;
+  int ntaps, KW, stride, pad;
+  int quad;
+  int tilesN, tilesC, ksplit, pix_per_split;
+  int tap_stride;   // STEM: element distance between virtual taps (rows of the padded image)
+  FastDiv div_ohw, div_ow;
+};
+
+constexpr int KP = 64;  // pixels per K-step
+
+template <typename T, int BMW, int BNW, bool STEM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
+  constexpr int RBA = BMW * ES;                // dY tile row bytes
+  constexpr int NBA = RBA / 32;                // 32-byte blocks per dY row
+  constexpr int BNWP = STEM ? 256 : BNW;       // padded X tile width (elements)
+  constexpr int RBB = BNWP * ES;
+  constexpr int NBB = RBB / 32;
+  constexpr int CPA = RBA / 16, CPB = (BNW * ES) / 16;  // 16-byte chunks per row actually loaded
+  constexpr int LA = (KP * CPA) / 256;         // dY chunks per thread per step
+  constexpr int LB = (KP * CPB + 255) / 256;   // X chunks per thread per step
+  constexpr int STAGE = KP * (RBA + RBB);
+  constexpr int TMW = BMW / 32, TNW = BNW / 32;
+  static_assert(NBA == 4 || NBA == 8 || NBA == 16, "dY row must be 128/256/512 bytes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const T* __restrict__ dy = static_cast<const T*>(p.dy);
+  const T* __restrict__ x = static_cast<const T*>(p.x);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  int bid = blockIdx.x;
+  const int split = bid % p.ksplit; bid /= p.ksplit;
+  const int tc = bid % p.tilesC; bid /= p.tilesC;
+  const int tn = bid % p.tilesN; bid /= p.tilesN;
+  const int tap = bid;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int n0 = tn * BMW, c0 = tc * BNW;
+  const int pbeg = split * p.pix_per_split;
+  const int pend = min(p.M, pbeg + p.pix_per_split);
+  const int nsteps = (pend - pbeg + KP - 1) / KP;
+
+  auto key = [](int row, int nblk) { return nblk >= 8 ? (row & 7) : ((row >> 1) & 3); };
+
+  uint4 ra[LA], rb[LB];
+  auto load_stage = [&](int ks) {
+    const int pb = pbeg + ks * KP;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int id = tid + 256 * i;
+      const int r = id / CPA, c = id - r * CPA;
+      const int m = pb + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < pend && n0 + c * EPC < p.N) v = *reinterpret_cast<const uint4*>(dy + (long long)m * p.N + n0 + c * EPC);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int id = tid + 256 * i;
+      const int r = id / CPB, c = id - r * CPB;
+      const int m = pb + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < KP && m < pend) {
+        unsigned img = fdiv((unsigned)m, p.div_ohw);
+        unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
+        unsigned oh = fdiv(rem, p.div_ow);
+        unsigned ow = rem - oh * (unsigned)p.OW;
+        long long base;
+        if (p.quad) {
+          const int n = img >> 2, q = img & 3;
+          base = (long long)n * p.x_img_stride + (long long)(q >> 1) * p.IH * p.x_row_stride +
+                 (long long)(q & 1) * p.IW * p.x_pix_stride;
+        } else {
+          base = (long long)img * p.x_img_stride;
+        }
+        const int ih = (int)oh * p.stride - p.pad + kh;
+        const int iw = (int)ow * p.stride - p.pad + kw;
+        if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+          long long off = base + (long long)ih * p.x_row_stride + (long long)iw * p.x_pix_stride;
+          if (STEM) {
+            const int v0 = c * EPC;  // virtual channel: (tap row, element)
+            off += (long long)(v0 / p.KC) * p.tap_stride + (v0 % p.KC);
+            v = *reinterpret_cast<const uint4*>(x + off);
+          } else if (c0 + c * EPC < p.KC) {
+            v = *reinterpret_cast<const uint4*>(x + off + c0 + c * EPC);
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = sa + KP * RBA;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int id = tid + 256 * i;
+      const int r = id / CPA, c = id - r * CPA;
+      *reinterpret_cast<uint4*>(sa + r * RBA + ((((c >> 1) ^ key(r, NBA)) << 5) | ((c & 1) << 4))) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int id = tid + 256 * i;
+      const int r = id / CPB, c = id - r * CPB;
+      if (r < KP)
+        *reinterpret_cast<uint4*>(sb + r * RBB + ((((c >> 1) ^ key(r, NBB)) << 5) | ((c & 1) << 4))) = rb[i];
+    }
+  };
+
+  f32x4 acc[TMW][TNW];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, lg = lane >> 4;
+
+  if (nsteps > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nsteps; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nsteps) load_stage(ks + 1);
+    const unsigned char* sa = smem + buf * STAGE;
+    const unsigned char* sb = sa + KP * RBA;
+    if constexpr (sizeof(T) == 2) {
+      // bf16: two transposing reads give the 8 k (pixels) of one lane:
+      //   j=0..3 -> pixel kb+4g+j, j=4..7 -> pixel kb+16+4g+j-4
+      const int q = li >> 2, pp = li & 3;
+#pragma unroll
+      for (int kb = 0; kb < KP; kb += 32) {
+        uint4 fa[TMW], fb[TNW];
+        const int r1 = kb + 4 * lg + q, r2 = r1 + 16;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+          const int blk = (wm * (BMW / 2) + i * 16) >> 4;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (QT_LDS_AS s16x4*)(sa + r1 * RBA + ((blk ^ key(r1, NBA)) << 5) + pp * 8));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (QT_LDS_AS s16x4*)(sa + r2 * RBA + ((blk ^ key(r2, NBA)) << 5) + pp * 8));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          const int blk = (wn * (BNW / 2) + j * 16) >> 4;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (QT_LDS_AS s16x4*)(sb + r1 * RBB + ((blk ^ key(r1, NBB)) << 5) + pp * 8));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (QT_LDS_AS s16x4*)(sb + r2 * RBB + ((blk ^ key(r2, NBB)) << 5) + pp * 8));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+          for (int j = 0; j < TNW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // f32: lane supplies (channel li, pixel kb+lg) directly
+#pragma unroll 4
+      for (int kb = 0; kb < KP; kb += 4) {
+        const int r = kb + lg;
+        float fa[TMW], fb[TNW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+          const int ch = wm * (BMW / 2) + i * 16 + li;
+          fa[i] = *reinterpret_cast<const float*>(sa + r * RBA + ((((ch >> 3) ^ key(r, NBA)) << 5) | ((ch & 7) << 2)));
+        }
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          const int ch = wn * (BNW / 2) + j * 16 + li;
+          fb[j] = *reinterpret_cast<const float*>(sb + r * RBB + ((((ch >> 3) ^ key(r, NBB)) << 5) | ((ch & 7) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+          for (int j = 0; j < TNW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ks + 1 < nsteps) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- accumulate: lane holds rows n = 4*lg + r, column c = li of each tile ----
+  if (nsteps > 0) {
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+        const int cc = wn * (BNW / 2) + j * 16 + li;
+        int tap_o, c_o;
+        if (STEM) {
+          tap_o = cc / p.KC;
+          c_o = cc - tap_o * p.KC;
+        } else {
+          tap_o = tap;
+          c_o = c0 + cc;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wm * (BMW / 2) + i * 16 + lg * 4 + r;
+          if (n < p.N && c_o < p.KC && tap_o < p.ntaps)
+            atomicAdd(p.dw + ((long long)n * p.ntaps + tap_o) * p.KC + c_o, acc[i][j][r]);
+        }
+      }
+  }
+}
+
+template <typename T, int BMW, int BNW, bool STEM>
+int launch(WgradArgs a, hipStream_t stream) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BNWP = STEM ? 256 : BNW;
+  constexpr int LDS = 2 * KP * (BMW * ES + BNWP * ES);
+  auto kern = conv_wgrad_kernel<T, BMW, BNW, STEM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return QT_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  a.tilesN = qt_cdiv(a.N, BMW);
+  a.tilesC = STEM ? 1 : qt_cdiv(a.KC, BNW);
+  const int gtaps = STEM ? 1 : a.ntaps;
+  const int base_blocks = a.tilesN * a.tilesC * gtaps;
+  int ksplit = qt_cdiv(1536, base_blocks);
+  const int max_split = qt_cdiv(a.M, KP * 4);
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  int pps = qt_cdiv(a.M, ksplit);
+  pps = qt_cdiv(pps, KP) * KP;
+  a.ksplit = qt_cdiv(a.M, pps);
+  a.pix_per_split = pps;
+  hipLaunchKernelGGL(kern, dim3(base_blocks * a.ksplit), dim3(256), LDS, stream, a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+}  // namespace
+
+extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+  QT_CHECK_ARG(d && dy && x && dw, "qt_conv2d_wgrad: null argument");
+  QT_CHECK_ARG(d->dtype == QT_F32 || d->dtype == QT_BF16, "qt_conv2d_wgrad: bad dtype %d", d->dtype);
+  QT_CHECK_ARG(d->mode == QT_CONV_FWD, "qt_conv2d_wgrad: describe the FORWARD convolution (mode QT_CONV_FWD)");
+  QT_CHECK_ARG(d->n_out > 0 && d->n_out % 8 == 0 && d->k_per_tap > 0 && d->k_per_tap % 8 == 0,
+               "qt_conv2d_wgrad: channel counts must be multiples of 8 (n_out=%d k_per_tap=%d)", d->n_out, d->k_per_tap);
+  QT_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dw % 4) == 0,
+               "qt_conv2d_wgrad: misaligned pointer");
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.dw = dw;
+  a.x_img_stride = d->src_img_stride; a.x_row_stride = d->src_row_stride; a.x_pix_stride = d->src_pix_stride;
+  const long long M = (long long)d->batch * (d->quad ? 4 : 1) * d->out_h * d->out_w;
+  QT_CHECK_ARG(M > 0 && M < (1ll << 31), "qt_conv2d_wgrad: bad pixel count");
+  a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap;
+  a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
+  a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad; a.quad = d->quad;
+  a.tap_stride = d->src_row_stride;
+  a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
+  a.div_ow = make_fastdiv((unsigned)d->out_w);
+  a.tilesN = a.tilesC = a.ksplit = a.pix_per_split = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
+  const bool stem = d->k_per_tap == 32 && d->kw == 1 && d->kh == 7 && d->n_out == 64;
+  if (d->dtype == QT_BF16) {
+    if (stem) return launch<bf16_t, 64, 224, true>(a, s);
+    const bool n64 = d->n_out <= 64, c64 = d->k_per_tap <= 64;
+    if (n64 && c64) return launch<bf16_t, 64, 64, false>(a, s);
+    if (n64) return launch<bf16_t, 64, 128, false>(a, s);
+    if (c64) return launch<bf16_t, 128, 64, false>(a, s);
+    return launch<bf16_t, 128, 128, false>(a, s);
+  }
+  if (stem) return launch<float, 64, 224, true>(a, s);
+  return launch<float, 64, 64, false>(a, s);
+}

@@ -170,3 +170,67 @@ def test_conv_rejects_bad_args():
     io = L.ConvIO()
     st = L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), None)
     assert st == -1 and b"dtype" in L.lib().qt_last_error()
+
+
+def run_wgrad(L, dt, dy_nhwc, x_nhwc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw, stride, pad, quad=0, strides=None):
+    dev = x_nhwc.device
+    d = L.ConvDesc()
+    d.dtype = L.qt_dtype(dt)
+    d.mode = L.QT_CONV_FWD
+    d.batch = B
+    d.in_h, d.in_w = in_hw
+    d.out_h, d.out_w = out_hw
+    d.k_per_tap, d.n_out = k_per_tap, n_out
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    if strides is None:
+        c = x_nhwc.shape[-1]
+        strides = (x_nhwc.shape[1] * x_nhwc.shape[2] * c, x_nhwc.shape[2] * c, c)
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = strides
+    d.quad = quad
+    dw = torch.zeros(n_out, kh * kw, k_per_tap, dtype=torch.float32, device=dev)
+    L.check(L.lib().qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dy_nhwc), L.ptr(x_nhwc), L.ptr(dw), L.stream_ptr()),
+            "qt_conv2d_wgrad")
+    torch.cuda.synchronize()
+    return dw
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 56, 3, 1, 1),
+    (3, 64, 128, 56, 3, 2, 1),
+    (2, 64, 128, 56, 1, 2, 0),
+    (2, 128, 128, 28, 3, 1, 1),
+    (1, 256, 512, 14, 3, 2, 1),
+    (5, 512, 512, 7, 3, 1, 1),
+    (37, 5376, 2688, 1, 1, 1, 0),   # classifier.0 as a 1x1 conv on 1x1 images, ragged batch
+])
+def test_conv_wgrad(dt, cfg):
+    dev = _dev()
+    L = pkg("_lib")
+    B, Cin, Cout, H, k, s, p = cfg
+    g = torch.Generator().manual_seed(4)
+    Ho = (H + 2 * p - k) // s + 1
+    x = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    dy = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, s, p)
+    dw = run_wgrad(L, dt, nhwc(dy).to(dev, dt), nhwc(x).to(dev, dt), B, (H, H), (Ho, Ho), Cin, Cout, k, k, s, p)
+    got = dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= 3e-5  # f32 accumulation of exactly representable products
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_quadrant_wgrad(dt):
+    dev = _dev()
+    L = pkg("_lib")
+    B, C, N = 3, 256, 128
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(B, C, 14, 14, generator=g).to(dt).float()
+    dyq = torch.randn(B, 4, N, 7, 7, generator=g).to(dt).float()
+    quads = [base[:, :, :7, :7], base[:, :, :7, 7:], base[:, :, 7:, :7], base[:, :, 7:, 7:]]
+    ref = sum(torch.nn.grad.conv2d_weight(quads[q].contiguous(), (N, C, 3, 3), dyq[:, q].contiguous(), 1, 1)
+              for q in range(4))
+    dyd = dyq.permute(0, 1, 3, 4, 2).contiguous().to(dev, dt)
+    dw = run_wgrad(L, dt, dyd, nhwc(base).to(dev, dt), B, (7, 7), (7, 7), C, N, 3, 3, 1, 1, quad=1,
+                   strides=(14 * 14 * C, 14 * C, C))
+    got = dw.cpu().view(N, 3, 3, C).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= 3e-5
