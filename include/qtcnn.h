@@ -91,6 +91,153 @@ int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream
  * running sum) by the caller: partial tiles are added with f32 atomics. */
 int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Layout packing (HBM-bound).
+ * ------------------------------------------------------------------------ */
+/* Packed stem input: [B][QT_STEM_PAD_H][QT_STEM_PAD_W][4] (3 zero rows/cols before,
+ * 3 rows / 5 cols after, channel 3 zero) so that the 7x7/2 stem conv
+ * (torchvision conv1, reached at Quadtree_from scratch/models.py:223) becomes 7
+ * row taps of 32 contiguous elements: desc {kh=7,kw=1,stride=2,pad=0,k_per_tap=32,
+ * src_pix_stride=4}.  Input contract: image [B,3,224,224] f32 NCHW
+ * (Quadtree_from scratch/dataloader.py:72-91). */
+#define QT_STEM_PAD_H 230
+#define QT_STEM_PAD_W 232
+int qt_pack_stem_input(int dtype, const float* image_nchw, void* dst, int batch, void* stream);
+/* OIHW f32 master weights (reference state_dict layout) -> [O][kh][kw][I] (w_fwd)
+ * and/or [I][kh][kw][O] (w_dgrad); either may be NULL.  Linear layers: kh=kw=1. */
+int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int O, int I, int kh, int kw,
+                        void* stream);
+/* [64][3][7][7] -> [64][taps][8][4] for the packed stem; taps = 7, or 8 (8th row zero)
+ * when a 32-element tap is only half a K-step (bf16: desc.kh = 8) */
+int qt_pack_stem_weight(int dtype, const float* w_oihw, void* dst, int taps, void* stream);
+/* [O][kh][kw][I] f32 gradient -> OIHW f32 (.grad), optionally accumulating */
+int qt_unpack_conv_wgrad(const float* dw, float* grad_oihw, int O, int I, int kh, int kw, int accumulate, void* stream);
+int qt_unpack_stem_wgrad(const float* dw, float* grad_oihw, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm2d (torch defaults eps 1e-5, momentum 0.1; replaces nn.BatchNorm2d of
+ * torchvision's ResNet-18 in train() and eval() mode) and fused activations.
+ * ------------------------------------------------------------------------ */
+/* partial[rows][2][C] (from qt_conv2d_igemm) -> batch mean / invstd, scale = gamma*invstd,
+ * shift = beta - mean*scale; updates running stats (unbiased var) if given. */
+/* partial buffers must have room for qt_stats_capacity_rows(rows) rows (long row
+ * counts are folded 256:1 into the spare rows before the final reduction). */
+int qt_stats_capacity_rows(int rows);
+int qt_bn_finalize(float* partial, int rows, int C, long long count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics */
+int qt_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int C, float* scale, float* shift, void* stream);
+/* out = relu?( y*scale+shift + (residual ? residual*res_scale+res_shift : 0) ), [M][C] */
+int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
+              const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C, void* stream);
+/* backward: g = d(loss)/d(BN output) (masked by `mask` > 0 if given) */
+int qt_bn_bwd_partial_rows(long long M, int C);
+int qt_bn_bwd_reduce(int dtype, const void* g, const void* mask, const void* y, const float* mean, const float* invstd,
+                     float* partial, long long M, int C, void* stream);
+int qt_bn_bwd_finalize(float* partial, int rows, int C, long long count, const float* gamma, const float* invstd,
+                       float* dgamma, float* dbeta, int accumulate, float* coef /*[3][C]*/, void* stream);
+int qt_bn_bwd_apply(int dtype, const void* g, const void* mask, const void* y, const float* mean, const float* invstd,
+                    const float* coef, void* dy, void* g_out, long long M, int C, void* stream);
+
+/* stem: relu(y*scale+shift) then MaxPool2d(3,2,1): [B][112][112][64] -> [B][56][56][64]
+ * (torchvision bn1/relu/maxpool, Quadtree_from scratch/models.py:224-226); argmax (u8, optional)
+ * records the winning tap for the backward. */
+int qt_stem_pool(int dtype, const void* y, const float* scale, const float* shift, void* pooled,
+                 unsigned char* argmax, int batch, void* stream);
+int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
+                     const float* shift, void* g, int batch, void* stream);
+/* AdaptiveAvgPool2d(1,1)+flatten into columns [col0, col0+C) of the fused feature
+ * matrix (Quadtree_from scratch/models.py:242,289-294) and its backward fused with the
+ * ReLU mask of the pooled map. */
+int qt_avgpool(int dtype, const void* x, void* dst, int batch, int hw, int C, int ld, int col0, void* stream);
+int qt_avgpool_bwd(int dtype, const void* d, const void* x, void* g, int batch, int hw, int C, int ld, int col0,
+                   void* stream);
+/* quadrant head tail: MaxPool2d(2,2) (7->3) + flatten(1) + torch.cat placement
+ * (Quadtree_from scratch/models.py:237,284-294): q [B*4][7][7][128] -> dst[b][col0 + quad*1152 + c*9 + ph*3 + pw] */
+int qt_quad_pool(int dtype, const void* q, void* dst, int batch, int ld, int col0, void* stream);
+int qt_quad_pool_bwd(int dtype, const void* d, const void* q, void* dq, int batch, int ld, int col0, void* stream);
+/* nn.Dropout (Quadtree_from scratch/models.py:258,269), in place, counter-hash RNG */
+int qt_dropout(int dtype, void* x, long long rows, int cols, int ld, unsigned long long seed, float p, void* stream);
+/* g = act > 0 ? g*mul : 0 (ReLU / dropout backward from the forward output) */
+int qt_relu_mask_scale(int dtype, void* g, const void* act, long long n, float mul, void* stream);
+/* out[c] (+)= sum_r x[r*ld+c]  (bias gradients) */
+int qt_col_sum(int dtype, const void* x, long long rows, int cols, int ld, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Thin dense products (nn.Linear 47->94->256 and 2688->12 and their gradients,
+ * Quadtree_from scratch/models.py:255-260,270): C[m][n] = relu?(acc? + bias[n] +
+ * sum_k A[m*ars+k*aks] * B[n*brs+k*bks]).
+ * ------------------------------------------------------------------------ */
+typedef struct qt_gemm_small_desc {
+  int M, N, K;
+  int a_dtype, b_dtype, c_dtype;
+  long long a_row_stride, a_k_stride;
+  long long b_row_stride, b_k_stride;
+  long long c_row_stride;
+  int relu, accumulate;
+} qt_gemm_small_desc;
+int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, const float* bias, void* C,
+                  void* stream);
+
+/* ------------------------------------------------------------------------
+ * Whole-network executor.  One plan = one model variant at a maximum batch:
+ *   QT_MODEL_QUADTREE         QuadtreeCNN  (Quadtree_from scratch/models.py:214-305;
+ *                             resnet/models.py:70-180 with `mode`)
+ *   QT_MODEL_STANDARD_RESNET  StandardResNetCNN (resnet/models.py:7-65)
+ * The tensor table lists every parameter / buffer under the reference's
+ * state_dict key (first-seen `base_cnn.*` names); the caller
+ * passes one device pointer per entry (f32, reference layouts: OIHW conv
+ * weights, [out][in] linear weights, int64 num_batches_tracked).
+ *   qt_plan_pack_weights : casts/permutes the master weights into the packed
+ *                          operands (call after every optimizer step)
+ *   qt_plan_forward      : model(image[B,3,224,224] f32 NCHW, numerical[B,47] f32)
+ *                          -> logits[B,num_classes] f32   (forward of models.py:273-305);
+ *                          training != 0: BatchNorm batch statistics + running-stat
+ *                          update, dropout with `seed`
+ *   qt_plan_backward     : loss.backward() of Quadtree_train.py:65 given dlogits;
+ *                          grads[i] (f32, same layout as tensors[i]) is written
+ *                          (not accumulated) when non-NULL; QT_BWD_HEAD = classifier,
+ *                          numerical MLP and quadrant head, QT_BWD_BACKBONE = ResNet
+ *                          stages and stem (lets the caller start the gradient
+ *                          all-reduce of the head while the backbone runs).
+ * ------------------------------------------------------------------------ */
+enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1 };
+enum { QT_MODE_FUSION = 0, QT_MODE_IMAGE_ONLY = 1, QT_MODE_NUMERICAL_ONLY = 2 };
+enum { QT_BWD_HEAD = 1, QT_BWD_BACKBONE = 2, QT_BWD_ALL = 3 };
+
+typedef struct qt_plan_desc {
+  int dtype;
+  int batch;          /* maximum images per call */
+  int num_classes;
+  int model;
+  int mode;
+  int numerical_dim;  /* 47 */
+  float dropout_p;    /* 0.5 */
+  float bn_eps;       /* 1e-5 */
+  float bn_momentum;  /* 0.1 */
+} qt_plan_desc;
+
+typedef struct qt_plan qt_plan;
+
+int qt_plan_create(const qt_plan_desc* desc, qt_plan** out);
+void qt_plan_destroy(qt_plan* plan);
+int qt_plan_num_tensors(const qt_plan* plan);
+const char* qt_plan_tensor_name(const qt_plan* plan, int i);
+int qt_plan_tensor_kind(const qt_plan* plan, int i);            /* 0 parameter, 1 f32 buffer, 2 int64 counter */
+int qt_plan_tensor_shape(const qt_plan* plan, int i, int* dims4); /* returns ndim */
+size_t qt_plan_workspace_bytes(const qt_plan* plan);
+/* byte offset inside the workspace of a named activation / gradient buffer:
+ * "stem.pooled", "block<0-7>.out|.a1|.gout", "conv<i>.y|.gy", "fused", "dfused", "hidden" */
+int qt_plan_find_buffer(const qt_plan* plan, const char* name, size_t* offset);
+int qt_plan_init_workspace(qt_plan* plan, void* workspace, void* stream);
+int qt_plan_pack_weights(qt_plan* plan, void* workspace, void* const* tensors, int for_backward, void* stream);
+int qt_plan_forward(qt_plan* plan, void* workspace, void* const* tensors, const float* image, const float* numerical,
+                    float* logits, int batch, int training, unsigned long long seed, void* stream);
+int qt_plan_backward(qt_plan* plan, void* workspace, void* const* tensors, float* const* grads, const float* numerical,
+                     const float* dlogits, int phases, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,12 @@
+"""MI355X-native QuadtreeCNN hot path (forward/backward of the multimodal
+Sun-Salutation pose classifier) behind the reference's nn.Module surface.
+
+The directory name is not a Python identifier; import it with
+    importlib.import_module("multimodal-hierarchical-cnn-for-sun-salutation-pose-classification_amd")
+or put `<this dir>/quadtree_from_scratch` (or `/resnet`) on sys.path and keep the
+reference's `from models import get_model`.
+"""
+from ._lib import LIB_PATH, QtError  # noqa: F401
+from .quadtree import QuadtreeCNN, StandardResNetCNN  # noqa: F401
+
+__all__ = ["QuadtreeCNN", "StandardResNetCNN", "QtError", "LIB_PATH"]

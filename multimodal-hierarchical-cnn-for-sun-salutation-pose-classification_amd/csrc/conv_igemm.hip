@@ -120,11 +120,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   uint4 ra[RA], rw[RW];
   const int ksteps_per_tap = p.KC / BK;
-  const int nk = p.ntaps * ksteps_per_tap;
+  const int nk = (p.ntaps * p.KC) / BK;
 
+  // A K-step is 128 bytes of K per row.  Normally that is a slice of one tap
+  // (tap uniform over the workgroup); when a tap is only 64 bytes (the packed
+  // bf16 stem) a K-step spans two taps and the tap depends on the chunk.
+  const int sub = p.KC * (int)sizeof(T) < kRowBytes;
   auto load_stage = [&](int ks) {
-    const int tap = ks / ksteps_per_tap;
-    const int c0 = (ks - tap * ksteps_per_tap) * BK;
+    int tap, c0;
+    if (sub) {
+      tap = ks * 2 + (chunk >> 2);
+      c0 = -(chunk >> 2) * (BK / 2);  // chunk*EPC + c0 = element inside the tap
+    } else {
+      tap = ks / ksteps_per_tap;
+      c0 = (ks - tap * ksteps_per_tap) * BK;
+    }
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -350,8 +360,9 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG(d->mode == QT_CONV_FWD || d->mode == QT_CONV_DGRAD, "qt_conv2d_igemm: bad mode %d", d->mode);
   QT_CHECK_ARG(io->src && io->weight && io->dst, "qt_conv2d_igemm: null src/weight/dst");
   const int bk = d->dtype == QT_F32 ? 32 : 64;
-  QT_CHECK_ARG(d->k_per_tap > 0 && d->k_per_tap % bk == 0,
-               "qt_conv2d_igemm: k_per_tap=%d must be a multiple of %d", d->k_per_tap, bk);
+  QT_CHECK_ARG(d->k_per_tap > 0 && (d->k_per_tap % bk == 0 || (2 * d->k_per_tap == bk && (d->kh * d->kw) % 2 == 0)),
+               "qt_conv2d_igemm: k_per_tap=%d must be a multiple of %d (or half of it with an even tap count)",
+               d->k_per_tap, bk);
   QT_CHECK_ARG(d->n_out > 0 && d->n_out % 8 == 0, "qt_conv2d_igemm: n_out=%d must be a multiple of 8", d->n_out);
   QT_CHECK_ARG(d->batch > 0 && d->out_h > 0 && d->out_w > 0 && d->in_h > 0 && d->in_w > 0,
                "qt_conv2d_igemm: bad geometry");

@@ -1,0 +1,791 @@
+// HBM-bound kernels around the MFMA convolutions: BatchNorm statistics /
+// apply / backward, ReLU + residual, stem max-pool, global average pool,
+// quadrant max-pool + concat, dropout, column sums.  All activations NHWC with
+// 8 channels (16 B bf16 / 32 B f32) per thread, f32 arithmetic.
+//
+// Reference ops replaced: nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d /
+// nn.AdaptiveAvgPool2d inside torchvision's ResNet-18 as wired at
+// /root/reference/Quadtree_from scratch/models.py:222-243; the quadrant head's
+// ReLU + MaxPool2d(2,2) + flatten + torch.cat at :236-237,284-294; nn.Dropout at
+// :258,269; and their autograd backward.
+#include <type_traits>
+
+#include "qt_common.h"
+
+namespace {
+
+int grid_for(long long total, int block = 256, int cap = 16384) {
+  long long g = (total + block - 1) / block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) { QtVec8<float>::load(p, v); }
+
+// ---------------------------------------------------------------------------------
+// BatchNorm (training) statistics: partial[rows][2][C] -> mean / invstd / scale / shift
+// + running statistics update (torch: momentum 0.1, unbiased running variance).
+// ---------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) {
+      s1 += (double)partial[((long long)r * 2 + 0) * C + c];
+      s2 += (double)partial[((long long)r * 2 + 1) * C + c];
+    }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    scale[c] = (float)((double)g * is);
+    shift[c] = (float)((double)b - m * (double)g * is);
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  }
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+}
+
+// stage 1 of a long partial-row reduction: block (cb, s) sums rows [256 s, 256 s + 256)
+// of partial[rows][2][C] into row (rows + s).
+__global__ void stats_stage1_kernel(float* partial, int rows, int C) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * 256;
+  int r1 = r0 + 256;
+  if (r1 > rows) r1 = rows;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      s1 += partial[((long long)r * 2 + 0) * C + c];
+      s2 += partial[((long long)r * 2 + 1) * C + c];
+    }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const long long o = (long long)(rows + blockIdx.y) * 2;
+    partial[(o + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    partial[(o + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rvar[c] + eps);
+  const float s = gamma[c] * is;
+  scale[c] = s;
+  shift[c] = beta[c] - rmean[c] * s;
+}
+
+// out = relu?( y*scale + shift + (res ? res*res_scale + res_shift : 0) )
+template <typename T>
+__global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                              const T* __restrict__ res, const float* __restrict__ rscale,
+                              const float* __restrict__ rshift, int relu, T* __restrict__ out, long long M, int C) {
+  const int cgs = C >> 3;
+  const long long total = M * cgs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cgs) * 8;
+    const long long off = i * 8;
+    float v[8], sc[8], sh[8];
+    QtVec8<T>::load(y + off, v);
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+    if (res) {
+      float r[8];
+      QtVec8<T>::load(res + off, r);
+      if (rscale) {
+        float rs[8], rb[8];
+        load8f(rscale + c0, rs);
+        load8f(rshift + c0, rb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e] * rs[e] + rb[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    QtVec8<T>::store(out + off, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNorm backward.  g = gradient w.r.t. the BN output (ReLU mask already
+// applied, or applied here from `mask` > 0).  pass 1: per-block partial sums of
+// g and g*xhat;  pass 2 (after bn_bwd_finalize): dy = a*(g - b - xhat*c).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ mask,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ partial, long long M, int C,
+                                                            int rows_per_block) {
+  extern __shared__ float red[];  // [RL][C][2]
+  const int cgs = C >> 3;
+  const int RL = 256 / cgs;  // row lanes
+  const int cg = threadIdx.x % cgs, rl = threadIdx.x / cgs;
+  const int c0 = cg * 8;
+  float mu[8], is[8];
+  load8f(mean + c0, mu);
+  load8f(invstd + c0, is);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  long long r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  if (rl < RL)
+    for (long long r = r_begin + rl; r < r_end; r += RL) {
+      const long long off = r * C + c0;
+      float gv[8], yv[8];
+      QtVec8<T>::load(g + off, gv);
+      QtVec8<T>::load(y + off, yv);
+      if (mask) {
+        float mv[8];
+        QtVec8<T>::load(mask + off, mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += gv[e];
+        s2[e] += gv[e] * (yv[e] - mu[e]) * is[e];
+      }
+    }
+  if (rl < RL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(rl * C + c0 + e) * 2 + 0] = s1[e];
+      red[(rl * C + c0 + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < RL; ++r) {
+      a += red[(r * C + c) * 2 + 0];
+      b += red[(r * C + c) * 2 + 1];
+    }
+    partial[((long long)blockIdx.x * 2 + 0) * C + c] = a;
+    partial[((long long)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// coef[0][c] = gamma*invstd, coef[1][c] = sum_g/M, coef[2][c] = sum_gxhat/M
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* dgamma, float* dbeta, int accumulate, float* coef) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) {
+      s1 += (double)partial[((long long)r * 2 + 0) * C + c];
+      s2 += (double)partial[((long long)r * 2 + 1) * C + c];
+    }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[C + c] = (float)(s1 / count);
+    coef[2 * C + c] = (float)(s2 / count);
+  }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ mask, const T* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ coef, T* __restrict__ dy, T* __restrict__ g_out,
+                                    long long M, int C) {
+  const int cgs = C >> 3;
+  const long long total = M * cgs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cgs) * 8;
+    const long long off = i * 8;
+    float gv[8], yv[8], mu[8], is[8], ca[8], cb[8], cc[8];
+    QtVec8<T>::load(g + off, gv);
+    QtVec8<T>::load(y + off, yv);
+    if (mask) {
+      float mv[8];
+      QtVec8<T>::load(mask + off, mv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
+    }
+    if (g_out) QtVec8<T>::store(g_out + off, gv);
+    load8f(mean + c0, mu);
+    load8f(invstd + c0, is);
+    load8f(coef + c0, ca);
+    load8f(coef + C + c0, cb);
+    load8f(coef + 2 * C + c0, cc);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ca[e] * (gv[e] - cb[e] - (yv[e] - mu[e]) * is[e] * cc[e]);
+    QtVec8<T>::store(dy + off, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Stem: a = relu(y*scale+shift) on [B][112][112][64]; 3x3/2 pad 1 max pool -> [B][56][56][64]
+// (+ argmax position 0..8 in scan order, first maximum wins like ATen).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, T* __restrict__ pooled,
+                                 unsigned char* __restrict__ argmax, int batch) {
+  constexpr int H = 112, W = 112, C = 64, PH = 56, PW = 56;
+  const long long total = (long long)batch * PH * PW * (C / 8);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % (C / 8)) * 8;
+    const int pw = (int)((i / (C / 8)) % PW);
+    const int ph = (int)((i / ((C / 8) * PW)) % PH);
+    const int n = (int)(i / ((long long)(C / 8) * PW * PH));
+    float sc[8], sh[8];
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+    float best[8];
+    int bidx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -INFINITY;
+      bidx[e] = 0;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ph * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = pw * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v[8];
+        QtVec8<T>::load(y + (((long long)n * H + h) * W + w) * C + c0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+          if (a > best[e]) {
+            best[e] = a;
+            bidx[e] = kh * 3 + kw;
+          }
+        }
+      }
+    }
+    const long long off = (((long long)n * PH + ph) * PW + pw) * C + c0;
+    QtVec8<T>::store(pooled + off, best);
+    if (argmax) {
+      uint2 pk;
+      pk.x = bidx[0] | (bidx[1] << 8) | (bidx[2] << 16) | (bidx[3] << 24);
+      pk.y = bidx[4] | (bidx[5] << 8) | (bidx[6] << 16) | (bidx[7] << 24);
+      *reinterpret_cast<uint2*>(argmax + off) = pk;
+    }
+  }
+}
+
+// g[n][h][w][c] = (y*scale+shift > 0) * sum over the <=4 pooled cells whose argmax is (h,w)
+template <typename T>
+__global__ void stem_pool_bwd_kernel(const T* __restrict__ dpooled, const unsigned char* __restrict__ argmax,
+                                     const T* __restrict__ y, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, T* __restrict__ g, int batch) {
+  constexpr int H = 112, W = 112, C = 64, PH = 56, PW = 56;
+  const long long total = (long long)batch * H * W * (C / 8);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % (C / 8)) * 8;
+    const int w = (int)((i / (C / 8)) % W);
+    const int h = (int)((i / ((C / 8) * W)) % H);
+    const int n = (int)(i / ((long long)(C / 8) * W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // pooled rows covering h: 2*ph-1 <= h <= 2*ph+1
+    const int ph_lo = h >> 1, ph_hi = (h + 1) >> 1;
+    const int pw_lo = w >> 1, pw_hi = (w + 1) >> 1;
+    for (int ph = ph_lo; ph <= ph_hi; ++ph) {
+      if (ph >= PH) continue;
+      const int kh = h - (ph * 2 - 1);
+      for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+        if (pw >= PW) continue;
+        const int kw = w - (pw * 2 - 1);
+        const int me = kh * 3 + kw;
+        const long long off = (((long long)n * PH + ph) * PW + pw) * C + c0;
+        const uint2 pk = *reinterpret_cast<const uint2*>(argmax + off);
+        float d[8];
+        QtVec8<T>::load(dpooled + off, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = ((e < 4 ? pk.x : pk.y) >> ((e & 3) * 8)) & 0xff;
+          if (idx == me) acc[e] += d[e];
+        }
+      }
+    }
+    const long long off = (((long long)n * H + h) * W + w) * C + c0;
+    float v[8], sc[8], sh[8];
+    QtVec8<T>::load(y + off, v);
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (v[e] * sc[e] + sh[e] > 0.f) ? acc[e] : 0.f;
+    QtVec8<T>::store(g + off, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Global average pool [B][HW][C] -> dst[b*ld + col0 + c], and its backward fused
+// with the ReLU mask of the pooled map:  g[b][p][c] = d[b*ld+col0+c]/HW * (x>0).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ dst, int batch, int HW, int C, int ld,
+                               int col0) {
+  const int cgs = C >> 3;
+  const int total = batch * cgs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c0 = (i % cgs) * 8, b = i / cgs;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float v[8];
+      QtVec8<T>::load(x + ((long long)b * HW + p) * C + c0, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] *= inv;
+    QtVec8<T>::store(dst + (long long)b * ld + col0 + c0, s);
+  }
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ d, const T* __restrict__ x, T* __restrict__ g, int batch,
+                                   int HW, int C, int ld, int col0) {
+  const int cgs = C >> 3;
+  const long long total = (long long)batch * HW * cgs;
+  const float inv = 1.f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cgs) * 8;
+    const int b = (int)(i / ((long long)cgs * HW));
+    float dv[8], xv[8];
+    QtVec8<T>::load(d + (long long)b * ld + col0 + c0, dv);
+    QtVec8<T>::load(x + i * 8, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dv[e] = xv[e] > 0.f ? dv[e] * inv : 0.f;
+    QtVec8<T>::store(g + i * 8, dv);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Quadrant head tail: q[B*4][7][7][128] (already conv+bias+ReLU) -> 2x2/2 max pool
+// (floor: 7->3) -> dst[b*ld + col0 + quad*1152 + c*9 + ph*3 + pw]  (flatten(1) of NCHW,
+// then torch.cat order of models.py:291-294).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void quad_pool_kernel(const T* __restrict__ q, T* __restrict__ dst, int batch, int ld, int col0) {
+  constexpr int C = 128;
+  const int total = batch * 4 * 9 * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int cell = (i / C) % 9;
+    const int img = i / (C * 9);  // b*4 + quad
+    const int ph = cell / 3, pw = cell % 3;
+    const T* s = q + (((long long)img * 7 + ph * 2) * 7 + pw * 2) * C + c;
+    float m = qt_to_f32<T>(s[0]);
+    m = fmaxf(m, qt_to_f32<T>(s[C]));
+    m = fmaxf(m, qt_to_f32<T>(s[7 * C]));
+    m = fmaxf(m, qt_to_f32<T>(s[8 * C]));
+    const int b = img >> 2, quad = img & 3;
+    if constexpr (sizeof(T) == 4)
+      dst[(long long)b * ld + col0 + quad * 1152 + c * 9 + cell] = m;
+    else
+      dst[(long long)b * ld + col0 + quad * 1152 + c * 9 + cell] = (bf16_t)m;
+  }
+}
+
+template <typename T>
+__global__ void quad_pool_bwd_kernel(const T* __restrict__ d, const T* __restrict__ q, T* __restrict__ dq, int batch,
+                                     int ld, int col0) {
+  constexpr int C = 128;
+  const int total = batch * 4 * 49 * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int pix = (i / C) % 49;
+    const int img = i / (C * 49);
+    const int h = pix / 7, w = pix % 7;
+    float out = 0.f;
+    if (h < 6 && w < 6) {
+      const int ph = h >> 1, pw = w >> 1;
+      const T* s = q + (((long long)img * 7 + ph * 2) * 7 + pw * 2) * C + c;
+      const float v0 = qt_to_f32<T>(s[0]), v1 = qt_to_f32<T>(s[C]), v2 = qt_to_f32<T>(s[7 * C]),
+                  v3 = qt_to_f32<T>(s[8 * C]);
+      int am = 0;
+      float best = v0;
+      if (v1 > best) { best = v1; am = 1; }
+      if (v2 > best) { best = v2; am = 2; }
+      if (v3 > best) { best = v3; am = 3; }
+      const int me = (h & 1) * 2 + (w & 1);
+      if (am == me && best > 0.f) {  // best > 0: ReLU passes gradient
+        const int b = img >> 2, quad = img & 3;
+        out = qt_to_f32<T>(d[(long long)b * ld + col0 + quad * 1152 + c * 9 + ph * 3 + pw]);
+      }
+    }
+    if constexpr (sizeof(T) == 4)
+      dq[i] = out;
+    else
+      dq[i] = (bf16_t)out;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Dropout (inverted, keep-probability 1-p) with a counter-based hash RNG:
+// keep(i) depends only on (seed, i), so backward re-derives the mask from the
+// forward output (kept and positive  <=>  out > 0 after the preceding ReLU).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + i * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32);
+}
+
+template <typename T>
+__global__ void dropout_kernel(T* __restrict__ x, long long rows, int cols, int ld, unsigned long long seed, float p) {
+  const long long total = rows * cols;
+  const float inv = 1.f / (1.f - p);
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    const int c = (int)(i - r * cols);
+    T* e = x + r * ld + c;
+    const bool keep = hash_u32(seed, (unsigned long long)i) >= thr;
+    const float v = keep ? qt_to_f32<T>(*e) * inv : 0.f;
+    if constexpr (sizeof(T) == 4)
+      *e = v;
+    else
+      *e = (bf16_t)v;
+  }
+}
+
+// g = (act > 0) ? g * mul : 0     (ReLU [+ dropout] backward from the forward output)
+template <typename T>
+__global__ void relu_mask_scale_kernel(T* __restrict__ g, const T* __restrict__ act, long long n, float mul) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = qt_to_f32<T>(act[i]) > 0.f ? qt_to_f32<T>(g[i]) * mul : 0.f;
+    if constexpr (sizeof(T) == 4)
+      g[i] = v;
+    else
+      g[i] = (bf16_t)v;
+  }
+}
+
+// out[c] (+)= sum_r x[r*ld + c]
+template <typename T>
+__global__ void col_sum_kernel(const T* __restrict__ x, long long rows, int cols, int ld, float* __restrict__ out,
+                               int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < cols)
+    for (long long r = rl; r < rows; r += 4) s += qt_to_f32<T>(x[r * ld + c]);
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    out[c] = accumulate ? out[c] + s : s;
+  }
+}
+
+}  // namespace
+
+#define QT_DT_OK(dtype, name) QT_CHECK_ARG((dtype) == QT_F32 || (dtype) == QT_BF16, name ": bad dtype %d", (dtype))
+
+// Long row counts are first folded 256:1 into the spare rows behind `rows`.
+static int fold_partial(float*& partial, int& rows, int C, hipStream_t s) {
+  if (rows <= 512) return QT_OK;
+  const int S = qt_cdiv(rows, 256);
+  hipLaunchKernelGGL(stats_stage1_kernel, dim3(qt_cdiv(C, 64), S), dim3(256), 0, s, partial, rows, C);
+  QT_CHECK_LAUNCH();
+  partial += (long long)rows * 2 * C;
+  rows = S;
+  return QT_OK;
+}
+
+extern "C" int qt_stats_capacity_rows(int rows) { return rows <= 512 ? rows : rows + qt_cdiv(rows, 256); }
+
+extern "C" int qt_bn_finalize(float* partial, int rows, int C, long long count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float momentum, float eps, float* mean, float* invstd,
+                              float* scale, float* shift, void* stream) {
+  QT_CHECK_ARG(partial && rows > 0 && C > 0 && count > 0 && mean && invstd && scale && shift,
+               "qt_bn_finalize: bad argument");
+  QT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "qt_bn_finalize: running stats must come in pairs");
+  if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
+                     rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                     mean, invstd, scale, shift);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+  QT_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "qt_bn_eval_affine: bad argument");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(qt_cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), gamma,
+                     beta, running_mean, running_var, eps, C, scale, shift);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
+                         const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C,
+                         void* stream) {
+  QT_DT_OK(dtype, "qt_bn_act");
+  QT_CHECK_ARG(y && scale && shift && out && M > 0 && C > 0 && C % 8 == 0, "qt_bn_act: bad argument");
+  QT_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "qt_bn_act: res_scale/res_shift must come in pairs");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(M * (C / 8));
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift,
+                       (const float*)residual, res_scale, res_shift, relu, (float*)out, M, C);
+  else
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                       (const bf16_t*)residual, res_scale, res_shift, relu, (bf16_t*)out, M, C);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+static int bn_bwd_rows_per_block(long long M, int C) {
+  const int RL = 256 / (C / 8);
+  long long rpb = (M + 2047) / 2048;  // at most 2048 blocks
+  long long min_rows = (long long)RL * 8;
+  if (rpb < min_rows) rpb = min_rows;
+  return (int)rpb;
+}
+
+extern "C" int qt_bn_bwd_partial_rows(long long M, int C) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048) return QT_ERR_INVALID_ARG;
+  return qt_cdiv(M, bn_bwd_rows_per_block(M, C));
+}
+
+extern "C" int qt_bn_bwd_reduce(int dtype, const void* g, const void* mask, const void* y, const float* mean,
+                                const float* invstd, float* partial, long long M, int C, void* stream) {
+  QT_DT_OK(dtype, "qt_bn_bwd_reduce");
+  QT_CHECK_ARG(g && y && mean && invstd && partial && M > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0,
+               "qt_bn_bwd_reduce: bad argument (C=%d)", C);
+  const int rpb = bn_bwd_rows_per_block(M, C);
+  const int grid = qt_cdiv(M, rpb);
+  const int RL = 256 / (C / 8);
+  const int lds = RL * C * 2 * 4;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, s, (const float*)g, (const float*)mask,
+                       (const float*)y, mean, invstd, partial, M, C, rpb);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, (const bf16_t*)g,
+                       (const bf16_t*)mask, (const bf16_t*)y, mean, invstd, partial, M, C, rpb);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_bn_bwd_finalize(float* partial, int rows, int C, long long count, const float* gamma,
+                                  const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef,
+                                  void* stream) {
+  QT_CHECK_ARG(partial && rows > 0 && C > 0 && count > 0 && invstd && coef, "qt_bn_bwd_finalize: bad argument");
+  if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partial, rows, C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_bn_bwd_apply(int dtype, const void* g, const void* mask, const void* y, const float* mean,
+                               const float* invstd, const float* coef, void* dy, void* g_out, long long M, int C,
+                               void* stream) {
+  QT_DT_OK(dtype, "qt_bn_bwd_apply");
+  QT_CHECK_ARG(g && y && mean && invstd && coef && dy && M > 0 && C > 0 && C % 8 == 0, "qt_bn_bwd_apply: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(M * (C / 8));
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)mask,
+                       (const float*)y, mean, invstd, coef, (float*)dy, (float*)g_out, M, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)mask,
+                       (const bf16_t*)y, mean, invstd, coef, (bf16_t*)dy, (bf16_t*)g_out, M, C);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_stem_pool(int dtype, const void* y, const float* scale, const float* shift, void* pooled,
+                            unsigned char* argmax, int batch, void* stream) {
+  QT_DT_OK(dtype, "qt_stem_pool");
+  QT_CHECK_ARG(y && scale && shift && pooled && batch > 0, "qt_stem_pool: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)batch * 56 * 56 * 8);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift,
+                       (float*)pooled, argmax, batch);
+  else
+    hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                       (bf16_t*)pooled, argmax, batch);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
+                                const float* scale, const float* shift, void* g, int batch, void* stream) {
+  QT_DT_OK(dtype, "qt_stem_pool_bwd");
+  QT_CHECK_ARG(dpooled && argmax && y && scale && shift && g && batch > 0, "qt_stem_pool_bwd: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)batch * 112 * 112 * 8);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dpooled, argmax,
+                       (const float*)y, scale, shift, (float*)g, batch);
+  else
+    hipLaunchKernelGGL(stem_pool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dpooled, argmax,
+                       (const bf16_t*)y, scale, shift, (bf16_t*)g, batch);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+template <typename F>
+static void by_dtype(int dtype, F&& f) {
+  if (dtype == QT_F32)
+    f(static_cast<float*>(nullptr));
+  else
+    f(static_cast<bf16_t*>(nullptr));
+}
+#define QT_T(tag) std::remove_pointer_t<decltype(tag)>
+
+extern "C" int qt_avgpool(int dtype, const void* x, void* dst, int batch, int hw, int C, int ld, int col0,
+                          void* stream) {
+  QT_DT_OK(dtype, "qt_avgpool");
+  QT_CHECK_ARG(x && dst && batch > 0 && hw > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && col0 % 8 == 0 && col0 + C <= ld,
+               "qt_avgpool: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(avgpool_kernel<T>, dim3(grid_for((long long)batch * (C / 8), 64)), dim3(64), 0, s,
+                       (const T*)x, (T*)dst, batch, hw, C, ld, col0);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_avgpool_bwd(int dtype, const void* d, const void* x, void* g, int batch, int hw, int C, int ld,
+                              int col0, void* stream) {
+  QT_DT_OK(dtype, "qt_avgpool_bwd");
+  QT_CHECK_ARG(d && x && g && batch > 0 && hw > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && col0 % 8 == 0 && col0 + C <= ld,
+               "qt_avgpool_bwd: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(grid_for((long long)batch * hw * (C / 8))), dim3(256), 0, s,
+                       (const T*)d, (const T*)x, (T*)g, batch, hw, C, ld, col0);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_quad_pool(int dtype, const void* q, void* dst, int batch, int ld, int col0, void* stream) {
+  QT_DT_OK(dtype, "qt_quad_pool");
+  QT_CHECK_ARG(q && dst && batch > 0 && col0 >= 0 && col0 + 4 * 1152 <= ld, "qt_quad_pool: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(quad_pool_kernel<T>, dim3(grid_for((long long)batch * 4 * 9 * 128)), dim3(256), 0, s,
+                       (const T*)q, (T*)dst, batch, ld, col0);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_quad_pool_bwd(int dtype, const void* d, const void* q, void* dq, int batch, int ld, int col0,
+                                void* stream) {
+  QT_DT_OK(dtype, "qt_quad_pool_bwd");
+  QT_CHECK_ARG(d && q && dq && batch > 0 && col0 >= 0 && col0 + 4 * 1152 <= ld, "qt_quad_pool_bwd: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(quad_pool_bwd_kernel<T>, dim3(grid_for((long long)batch * 4 * 49 * 128)), dim3(256), 0, s,
+                       (const T*)d, (const T*)q, (T*)dq, batch, ld, col0);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_dropout(int dtype, void* x, long long rows, int cols, int ld, unsigned long long seed, float p,
+                          void* stream) {
+  QT_DT_OK(dtype, "qt_dropout");
+  QT_CHECK_ARG(x && rows > 0 && cols > 0 && ld >= cols && p >= 0.f && p < 1.f, "qt_dropout: bad argument (p=%f)", p);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(dropout_kernel<T>, dim3(grid_for(rows * cols)), dim3(256), 0, s, (T*)x, rows, cols, ld, seed, p);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_relu_mask_scale(int dtype, void* g, const void* act, long long n, float mul, void* stream) {
+  QT_DT_OK(dtype, "qt_relu_mask_scale");
+  QT_CHECK_ARG(g && act && n > 0, "qt_relu_mask_scale: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(relu_mask_scale_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (T*)g, (const T*)act, n, mul);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_col_sum(int dtype, const void* x, long long rows, int cols, int ld, float* out, int accumulate,
+                          void* stream) {
+  QT_DT_OK(dtype, "qt_col_sum");
+  QT_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "qt_col_sum: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  by_dtype(dtype, [&](auto tag) {
+    using T = QT_T(tag);
+    hipLaunchKernelGGL(col_sum_kernel<T>, dim3(qt_cdiv(cols, 64)), dim3(256), 0, s, (const T*)x, rows, cols, ld, out,
+                       accumulate);
+  });
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

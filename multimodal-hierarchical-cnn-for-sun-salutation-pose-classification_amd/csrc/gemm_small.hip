@@ -1,0 +1,90 @@
+// Small dense products that are too thin for MFMA tiles (K=47 MLP input, N=12
+// logits, their gradients).  f32 arithmetic; operands may be f32 or bf16 with
+// arbitrary element strides, so the same kernel serves forward, data-gradient
+// and weight-gradient of
+//   numerical_mlp  (/root/reference/Quadtree_from scratch/models.py:255-260)
+//   classifier.3   (/root/reference/Quadtree_from scratch/models.py:270).
+#include "qt_common.h"
+
+namespace {
+
+struct SmallArgs {
+  const void* A;
+  const void* B;
+  const float* bias;
+  void* C;
+  long long ars, aks, brs, bks, crs;
+  int M, N, K;
+  int a_bf16, b_bf16, c_bf16;
+  int relu, accumulate;
+};
+
+__device__ __forceinline__ float ld(const void* p, long long i, int is_bf16) {
+  return is_bf16 ? (float)static_cast<const bf16_t*>(p)[i] : static_cast<const float*>(p)[i];
+}
+
+__device__ __forceinline__ void finish(const SmallArgs& a, int m, int n, float acc) {
+  if (a.bias) acc += a.bias[n];
+  const long long ci = (long long)m * a.crs + n;
+  if (a.accumulate) acc += ld(a.C, ci, a.c_bf16);
+  if (a.relu) acc = fmaxf(acc, 0.f);
+  if (a.c_bf16)
+    static_cast<bf16_t*>(a.C)[ci] = (bf16_t)acc;
+  else
+    static_cast<float*>(a.C)[ci] = acc;
+}
+
+// one thread per output element (short K)
+__global__ void gemm_small_thread_kernel(SmallArgs a) {
+  const long long total = (long long)a.M * a.N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % a.N), m = (int)(i / a.N);
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k)
+      acc += ld(a.A, (long long)m * a.ars + k * a.aks, a.a_bf16) * ld(a.B, (long long)n * a.brs + k * a.bks, a.b_bf16);
+    finish(a, m, n, acc);
+  }
+}
+
+// one wave per output element (long K), 64-lane shuffle reduction
+__global__ __launch_bounds__(256) void gemm_small_wave_kernel(SmallArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)a.M * a.N;
+  for (long long i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < total; i += (long long)gridDim.x * 4) {
+    const int n = (int)(i % a.N), m = (int)(i / a.N);
+    float acc = 0.f;
+    for (int k = lane; k < a.K; k += 64)
+      acc += ld(a.A, (long long)m * a.ars + k * a.aks, a.a_bf16) * ld(a.B, (long long)n * a.brs + k * a.bks, a.b_bf16);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) finish(a, m, n, acc);
+  }
+}
+
+}  // namespace
+
+extern "C" int qt_gemm_small(const qt_gemm_small_desc* d, const void* A, const void* B, const float* bias, void* C,
+                             void* stream) {
+  QT_CHECK_ARG(d && A && B && C, "qt_gemm_small: null argument");
+  QT_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "qt_gemm_small: bad shape %dx%dx%d", d->M, d->N, d->K);
+  for (int t : {d->a_dtype, d->b_dtype, d->c_dtype})
+    QT_CHECK_ARG(t == QT_F32 || t == QT_BF16, "qt_gemm_small: bad dtype %d", t);
+  SmallArgs a;
+  a.A = A; a.B = B; a.bias = bias; a.C = C;
+  a.ars = d->a_row_stride; a.aks = d->a_k_stride; a.brs = d->b_row_stride; a.bks = d->b_k_stride; a.crs = d->c_row_stride;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.a_bf16 = d->a_dtype == QT_BF16; a.b_bf16 = d->b_dtype == QT_BF16; a.c_bf16 = d->c_dtype == QT_BF16;
+  a.relu = d->relu; a.accumulate = d->accumulate;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long total = (long long)d->M * d->N;
+  if (d->K <= 96) {
+    long long g = (total + 255) / 256;
+    hipLaunchKernelGGL(gemm_small_thread_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, a);
+  } else {
+    long long g = (total + 3) / 4;
+    hipLaunchKernelGGL(gemm_small_wave_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, s, a);
+  }
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

@@ -1,0 +1,801 @@
+// Native executor ("plan") for the QuadtreeCNN / StandardResNetCNN hot path.
+//
+// One object describes the whole network for a fixed maximum batch: the tensor
+// table (names = the reference's state_dict keys), the workspace
+// layout in HBM and the launch sequence.  The host language makes three calls per
+// training step (pack weights, forward, backward); every kernel is enqueued from
+// here on the caller's stream, no synchronisation, no allocation.
+//
+// Graph restated (not copied) from
+//   /root/reference/Quadtree_from scratch/models.py:216-305  (QuadtreeCNN)
+//   /root/reference/resnet/models.py:7-65,70-180              (StandardResNetCNN, modes)
+// and torchvision's ResNet-18 BasicBlock wiring.
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "qt_common.h"
+
+namespace {
+
+constexpr int kImg = 224;
+
+struct TensorInfo {
+  std::string name;
+  int kind;  // 0 parameter f32, 1 buffer f32, 2 int64 counter
+  int ndim;
+  int shape[4];
+};
+
+struct BnL {
+  int gamma, beta, rmean, rvar, nbt, C;
+  size_t mean, invstd, scale, shift, coef;
+};
+
+struct ConvL {
+  int w, bias;  // tensor indices (bias -1 if none)
+  int cin, cout, k, stride, pad, hin, hout;
+  int bn;  // -1 if none
+  size_t w_fwd, w_dgrad, dw;
+  size_t y, gy;
+};
+
+struct Block {
+  int conv1, conv2, ds;
+  size_t a1, out, gout, gtmp;
+};
+
+struct LinL {
+  int w, b, in, out;
+  size_t w_fwd, w_dgrad;
+};
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct qt_plan {
+  qt_plan_desc d;
+  int esz;
+  std::vector<TensorInfo> tensors;
+  std::vector<BnL> bns;
+  std::vector<ConvL> convs;  // 0 stem, 1..19 blocks, 20 quadrant conv (if present)
+  std::vector<Block> blocks;
+  int quad_conv = -1;
+  bool has_image = true, has_numerical = false, standard = false;
+  LinL mlp0{}, mlp1{}, cls0{}, cls3{};
+  int fused_ld = 0, img_cols = 0, mlp_col0 = 0, hidden_dim = 0;
+  // workspace offsets
+  size_t ws_bytes = 0;
+  size_t xpad = 0, p0 = 0, argmax = 0, g_p0 = 0;
+  size_t q = 0, dq = 0, fused = 0, dfused = 0, h1 = 0, dh1 = 0, hidden = 0, dhidden = 0;
+  size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
+  // state of the last forward
+  int last_batch = 0, last_training = 0;
+  unsigned long long last_seed = 0;
+
+  int add_tensor(const std::string& name, int kind, std::initializer_list<int> shape) {
+    TensorInfo t;
+    t.name = name;
+    t.kind = kind;
+    t.ndim = (int)shape.size();
+    int i = 0;
+    for (int s : shape) t.shape[i++] = s;
+    for (; i < 4; ++i) t.shape[i] = 1;
+    tensors.push_back(t);
+    return (int)tensors.size() - 1;
+  }
+  int add_bn(const std::string& prefix, int C) {
+    BnL b;
+    b.C = C;
+    b.gamma = add_tensor(prefix + ".weight", 0, {C});
+    b.beta = add_tensor(prefix + ".bias", 0, {C});
+    b.rmean = add_tensor(prefix + ".running_mean", 1, {C});
+    b.rvar = add_tensor(prefix + ".running_var", 1, {C});
+    b.nbt = add_tensor(prefix + ".num_batches_tracked", 2, {});
+    bns.push_back(b);
+    return (int)bns.size() - 1;
+  }
+  int add_conv(const std::string& wname, int cin, int cout, int k, int stride, int pad, int hin, int bn, bool bias) {
+    ConvL c;
+    c.w = add_tensor(wname + ".weight", 0, {cout, cin, k, k});
+    c.bias = bias ? add_tensor(wname + ".bias", 0, {cout}) : -1;
+    c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = pad;
+    c.hin = hin; c.hout = (hin + 2 * pad - k) / stride + 1;
+    c.bn = bn;
+    convs.push_back(c);
+    return (int)convs.size() - 1;
+  }
+  LinL add_linear(const std::string& name, int in, int out) {
+    LinL l;
+    l.w = add_tensor(name + ".weight", 0, {out, in});
+    l.b = add_tensor(name + ".bias", 0, {out});
+    l.in = in; l.out = out;
+    l.w_fwd = l.w_dgrad = 0;
+    return l;
+  }
+};
+
+namespace {
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes);
+    return o;
+  }
+};
+
+void build_graph(qt_plan* p) {
+  const qt_plan_desc& d = p->d;
+  p->standard = d.model == QT_MODEL_STANDARD_RESNET;
+  p->has_image = p->standard || d.mode != QT_MODE_NUMERICAL_ONLY;
+  p->has_numerical = !p->standard && d.mode != QT_MODE_IMAGE_ONLY;
+  // ---- backbone (always present in the tensor table: state_dict parity) ----
+  {
+    const int w = p->add_tensor("base_cnn.conv1.weight", 0, {64, 3, 7, 7});
+    const int bn = p->add_bn("base_cnn.bn1", 64);
+    ConvL c;
+    c.w = w; c.bias = -1; c.cin = 3; c.cout = 64; c.k = 7; c.stride = 2; c.pad = 3; c.hin = kImg; c.hout = 112; c.bn = bn;
+    p->convs.push_back(c);
+  }
+  int h = 56, cin = 64;
+  for (int L = 1; L <= 4; ++L) {
+    const int cout = 64 << (L - 1);
+    for (int b = 0; b < 2; ++b) {
+      const std::string pre = "base_cnn.layer" + std::to_string(L) + "." + std::to_string(b);
+      const int stride = (b == 0 && L > 1) ? 2 : 1;
+      Block blk;
+      // tensor order follows torchvision's BasicBlock: conv1, bn1, conv2, bn2, downsample
+      const int w1 = p->add_tensor(pre + ".conv1.weight", 0, {cout, cin, 3, 3});
+      const int bn1 = p->add_bn(pre + ".bn1", cout);
+      const int w2 = p->add_tensor(pre + ".conv2.weight", 0, {cout, cout, 3, 3});
+      const int bn2 = p->add_bn(pre + ".bn2", cout);
+      ConvL c1;
+      c1.w = w1; c1.bias = -1; c1.cin = cin; c1.cout = cout; c1.k = 3; c1.stride = stride; c1.pad = 1;
+      c1.hin = h; c1.hout = (h + 2 - 3) / stride + 1; c1.bn = bn1;
+      p->convs.push_back(c1);
+      blk.conv1 = (int)p->convs.size() - 1;
+      ConvL c2;
+      c2.w = w2; c2.bias = -1; c2.cin = cout; c2.cout = cout; c2.k = 3; c2.stride = 1; c2.pad = 1;
+      c2.hin = c1.hout; c2.hout = c1.hout; c2.bn = bn2;
+      p->convs.push_back(c2);
+      blk.conv2 = (int)p->convs.size() - 1;
+      blk.ds = -1;
+      if (stride != 1 || cin != cout) {
+        const int wd = p->add_tensor(pre + ".downsample.0.weight", 0, {cout, cin, 1, 1});
+        const int bnd = p->add_bn(pre + ".downsample.1", cout);
+        ConvL cd;
+        cd.w = wd; cd.bias = -1; cd.cin = cin; cd.cout = cout; cd.k = 1; cd.stride = stride; cd.pad = 0;
+        cd.hin = h; cd.hout = c1.hout; cd.bn = bnd;
+        p->convs.push_back(cd);
+        blk.ds = (int)p->convs.size() - 1;
+      }
+      p->blocks.push_back(blk);
+      h = c1.hout;
+      cin = cout;
+    }
+  }
+  p->add_tensor("base_cnn.fc.weight", 0, {1000, 512});  // present in the state_dict, never used
+  p->add_tensor("base_cnn.fc.bias", 0, {1000});
+  if (!p->standard) {
+    p->quad_conv = p->add_conv("quadrant_processor.0", 256, 128, 3, 1, 1, 7, -1, true);
+    p->mlp0 = p->add_linear("numerical_mlp.0", d.numerical_dim, d.numerical_dim * 2);
+    p->mlp1 = p->add_linear("numerical_mlp.3", d.numerical_dim * 2, 256);
+    p->img_cols = 512 + 4 * 1152;
+    p->fused_ld = (p->has_image ? p->img_cols : 0) + (p->has_numerical ? 256 : 0);
+    p->mlp_col0 = p->has_image ? p->img_cols : 0;
+  } else {
+    p->img_cols = 512;
+    p->fused_ld = 512;
+    p->mlp_col0 = 0;
+  }
+  p->hidden_dim = p->standard ? 256 : p->fused_ld / 2;
+  p->cls0 = p->add_linear("classifier.0", p->fused_ld, p->hidden_dim);
+  p->cls3 = p->add_linear("classifier.3", p->hidden_dim, d.num_classes);
+}
+
+void layout_workspace(qt_plan* p) {
+  Bump ws;
+  const size_t B = (size_t)p->d.batch;
+  const size_t es = (size_t)p->esz;
+  // constants
+  p->ones = ws.take(2048 * 4);
+  p->zeros = ws.take(2048 * 4);
+  // statistics scratch: the stem has the most partial rows
+  {
+    const int rows = qt_stats_capacity_rows(qt_cdiv((long long)B * 112 * 112, 128));
+    size_t bytes = (size_t)rows * 2 * 64 * 4;
+    const size_t bwd = (size_t)qt_stats_capacity_rows(2048) * 2 * 512 * 4;
+    p->stats = ws.take(bytes > bwd ? bytes : bwd);
+  }
+  for (auto& b : p->bns) {
+    b.mean = ws.take(b.C * 4);
+    b.invstd = ws.take(b.C * 4);
+    b.scale = ws.take(b.C * 4);
+    b.shift = ws.take(b.C * 4);
+    b.coef = ws.take(3 * b.C * 4);
+  }
+  // packed weights + KRSC gradient scratch
+  for (size_t i = 0; i < p->convs.size(); ++i) {
+    ConvL& c = p->convs[i];
+    const size_t n = (i == 0) ? (size_t)64 * 8 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
+    c.w_fwd = ws.take(n * es);
+    c.w_dgrad = ws.take(n * es);
+    c.dw = ws.take(n * 4);
+  }
+  for (LinL* l : {&p->cls0}) {
+    l->w_fwd = ws.take((size_t)l->in * l->out * es);
+    l->w_dgrad = ws.take((size_t)l->in * l->out * es);
+  }
+  if (p->has_image) {
+    p->xpad = ws.take(B * QT_STEM_PAD_H * QT_STEM_PAD_W * 4 * es);
+    p->p0 = ws.take(B * 56 * 56 * 64 * es);
+    p->g_p0 = ws.take(B * 56 * 56 * 64 * es);
+    p->argmax = ws.take(B * 56 * 56 * 64);
+    for (size_t i = 0; i < p->convs.size(); ++i) {
+      ConvL& c = p->convs[i];
+      const size_t imgs = ((int)i == p->quad_conv) ? B * 4 : B;
+      const size_t n = imgs * c.hout * c.hout * c.cout;
+      c.y = ws.take(n * es);
+      c.gy = ws.take(n * es);
+    }
+    for (auto& blk : p->blocks) {
+      const ConvL& c2 = p->convs[blk.conv2];
+      const size_t n = B * c2.hout * c2.hout * c2.cout;
+      blk.a1 = ws.take(n * es);
+      blk.out = ws.take(n * es);
+      blk.gout = ws.take(n * es);
+      const ConvL& c1 = p->convs[blk.conv1];
+      blk.gtmp = blk.ds >= 0 ? ws.take(B * c1.hin * c1.hin * c1.cin * es) : 0;
+    }
+    p->gbase_tmp = ws.take(B * 14 * 14 * 256 * es);
+  }
+  if (!p->standard) {
+    p->q = p->convs[p->quad_conv].y;
+    p->dq = p->convs[p->quad_conv].gy;
+    p->h1 = ws.take(B * p->mlp0.out * 4);
+    p->dh1 = ws.take(B * p->mlp0.out * 4);
+  }
+  p->fused = ws.take(B * p->fused_ld * es);
+  p->dfused = ws.take(B * p->fused_ld * es);
+  p->hidden = ws.take(B * p->hidden_dim * es);
+  p->dhidden = ws.take(B * p->hidden_dim * es);
+  p->ws_bytes = ws.off;
+}
+
+// ------------------------------------------------------------------------------
+struct Exec {
+  qt_plan* p;
+  unsigned char* ws;
+  void* const* T;  // tensor pointers
+  void* stream;
+  int B;
+  int dt;
+  int status = QT_OK;
+
+  template <typename X = void> X* at(size_t off) const { return reinterpret_cast<X*>(ws + off); }
+  float* tf(int idx) const { return idx < 0 ? nullptr : static_cast<float*>(T[idx]); }
+  bool ok() const { return status == QT_OK; }
+  void run(int st) {
+    if (status == QT_OK && st != QT_OK) status = st;
+  }
+
+  qt_conv_desc conv_desc(const ConvL& c, int mode) const {
+    qt_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dt;
+    d.mode = mode;
+    d.batch = B;
+    d.kh = d.kw = c.k;
+    d.stride = c.stride;
+    d.pad = c.pad;
+    if (mode == QT_CONV_FWD) {
+      d.in_h = d.in_w = c.hin; d.out_h = d.out_w = c.hout;
+      d.k_per_tap = c.cin; d.n_out = c.cout;
+      d.src_pix_stride = c.cin; d.src_row_stride = c.hin * c.cin; d.src_img_stride = (long long)c.hin * c.hin * c.cin;
+    } else {
+      d.in_h = d.in_w = c.hout; d.out_h = d.out_w = c.hin;
+      d.k_per_tap = c.cout; d.n_out = c.cin;
+      d.src_pix_stride = c.cout; d.src_row_stride = c.hout * c.cout; d.src_img_stride = (long long)c.hout * c.hout * c.cout;
+    }
+    return d;
+  }
+  // bf16: a 32-element tap is half a K-step, so the forward runs 8 row taps (the
+  // 8th has zero weights); the weight gradient always uses the 7 real taps.
+  int stem_taps() const { return dt == QT_BF16 ? 8 : 7; }
+  qt_conv_desc stem_desc(bool for_wgrad = false) const {
+    qt_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dt; d.mode = QT_CONV_FWD; d.batch = B;
+    d.in_h = QT_STEM_PAD_H; d.in_w = QT_STEM_PAD_W; d.out_h = d.out_w = 112;
+    d.k_per_tap = 32; d.n_out = 64; d.kh = for_wgrad ? 7 : stem_taps(); d.kw = 1; d.stride = 2; d.pad = 0;
+    d.src_pix_stride = 4; d.src_row_stride = QT_STEM_PAD_W * 4;
+    d.src_img_stride = (long long)QT_STEM_PAD_H * QT_STEM_PAD_W * 4;
+    return d;
+  }
+  qt_conv_desc quad_desc(int mode) const {
+    const ConvL& c = p->convs[p->quad_conv];
+    qt_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dt; d.mode = mode; d.batch = B; d.kh = d.kw = 3; d.stride = 1; d.pad = 1; d.quad = 1;
+    if (mode == QT_CONV_FWD) {
+      d.in_h = d.in_w = 7; d.out_h = d.out_w = 7; d.k_per_tap = c.cin; d.n_out = c.cout;
+      d.src_pix_stride = c.cin; d.src_row_stride = 14 * c.cin; d.src_img_stride = 14ll * 14 * c.cin;
+    } else {
+      d.in_h = d.in_w = 7; d.out_h = d.out_w = 14; d.k_per_tap = c.cout; d.n_out = c.cin;
+      d.src_pix_stride = c.cout; d.src_row_stride = 7 * c.cout; d.src_img_stride = 49ll * c.cout;
+    }
+    return d;
+  }
+  qt_conv_desc linear_desc(int in, int out, int mode) const {
+    qt_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dt; d.mode = mode; d.batch = B; d.in_h = d.in_w = d.out_h = d.out_w = 1;
+    d.kh = d.kw = 1; d.stride = 1; d.pad = 0;
+    if (mode == QT_CONV_FWD) {
+      d.k_per_tap = in; d.n_out = out; d.src_pix_stride = in; d.src_row_stride = in; d.src_img_stride = in;
+    } else {
+      d.k_per_tap = out; d.n_out = in; d.src_pix_stride = out; d.src_row_stride = out; d.src_img_stride = out;
+    }
+    return d;
+  }
+
+  void igemm(const qt_conv_desc& d, const void* src, const void* w, void* dst, const float* scale, const float* shift,
+             const void* res, const void* mask, float* stats, int relu) {
+    if (!ok()) return;
+    qt_conv_desc dd = d;
+    dd.relu = relu;
+    qt_conv_io io = {src, w, dst, scale, shift, res, mask, stats};
+    run(qt_conv2d_igemm(&dd, &io, stream));
+  }
+
+  long long rows_of(const ConvL& c) const { return (long long)B * c.hout * c.hout; }
+
+  // conv (+ train-mode statistics -> scale/shift of its BatchNorm)
+  void conv_bn_stats(const ConvL& c, const qt_conv_desc& d, const void* src, bool training) {
+    BnL& bn = p->bns[c.bn];
+    if (training) {
+      igemm(d, src, at(c.w_fwd), at(c.y), nullptr, nullptr, nullptr, nullptr, at<float>(p->stats), 0);
+      if (!ok()) return;
+      const int rows = qt_conv2d_stats_rows(&d);
+      run(qt_bn_finalize(at<float>(p->stats), rows, bn.C, rows_of(c), tf(bn.gamma), tf(bn.beta), tf(bn.rmean),
+                         tf(bn.rvar), static_cast<long long*>(T[bn.nbt]), p->d.bn_momentum, p->d.bn_eps,
+                         at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.scale), at<float>(bn.shift), stream));
+    } else {
+      run(qt_bn_eval_affine(tf(bn.gamma), tf(bn.beta), tf(bn.rmean), tf(bn.rvar), p->d.bn_eps, bn.C,
+                            at<float>(bn.scale), at<float>(bn.shift), stream));
+    }
+  }
+};
+
+int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, void* stream) {
+  Exec e{p, static_cast<unsigned char*>(workspace), T, stream, p->d.batch, p->d.dtype};
+  if (p->has_image) {
+    for (size_t i = 0; i < p->convs.size(); ++i) {
+      const ConvL& c = p->convs[i];
+      if (i == 0) {
+        e.run(qt_pack_stem_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), e.stem_taps(), stream));
+      } else {
+        e.run(qt_pack_conv_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout,
+                                  c.cin, c.k, c.k, stream));
+      }
+    }
+  }
+  e.run(qt_pack_conv_weight(e.dt, e.tf(p->cls0.w), e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr,
+                            p->cls0.out, p->cls0.in, 1, 1, stream));
+  return e.status;
+}
+
+int forward(qt_plan* p, void* workspace, void* const* T, const float* image, const float* numerical, float* logits,
+            int batch, int training, unsigned long long seed, void* stream) {
+  Exec e{p, static_cast<unsigned char*>(workspace), T, stream, batch, p->d.dtype};
+  const int dt = e.dt;
+  const bool tr = training != 0;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (p->has_image) {
+    // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
+    e.run(qt_pack_stem_input(dt, image, e.at(p->xpad), batch, stream));
+    const ConvL& c0 = p->convs[0];
+    const BnL& bn0 = p->bns[c0.bn];
+    const qt_conv_desc sd = e.stem_desc();
+    e.conv_bn_stats(c0, sd, e.at(p->xpad), tr);
+    if (tr) {
+      e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), e.at(p->p0),
+                         e.at<unsigned char>(p->argmax), batch, stream));
+    } else {
+      e.igemm(sd, e.at(p->xpad), e.at(c0.w_fwd), e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), nullptr,
+              nullptr, nullptr, 1);
+      e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(p->ones), e.at<float>(p->zeros), e.at(p->p0), nullptr, batch,
+                         stream));
+    }
+    // ---- residual stages ----
+    size_t x = p->p0;
+    for (const Block& blk : p->blocks) {
+      const ConvL& c1 = p->convs[blk.conv1];
+      const ConvL& c2 = p->convs[blk.conv2];
+      const BnL& b1 = p->bns[c1.bn];
+      const BnL& b2 = p->bns[c2.bn];
+      const qt_conv_desc d1 = e.conv_desc(c1, QT_CONV_FWD), d2 = e.conv_desc(c2, QT_CONV_FWD);
+      const long long M = e.rows_of(c2);
+      e.conv_bn_stats(c1, d1, e.at(x), tr);
+      if (tr) {
+        e.run(qt_bn_act(dt, e.at(c1.y), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr, nullptr, nullptr, 1,
+                        e.at(blk.a1), M, c1.cout, stream));
+      } else {
+        e.igemm(d1, e.at(x), e.at(c1.w_fwd), e.at(blk.a1), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr,
+                nullptr, nullptr, 1);
+      }
+      e.conv_bn_stats(c2, d2, e.at(blk.a1), tr);
+      if (blk.ds >= 0) {
+        const ConvL& cd = p->convs[blk.ds];
+        const BnL& bd = p->bns[cd.bn];
+        const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
+        e.conv_bn_stats(cd, dd, e.at(x), tr);
+        if (tr) {
+          e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(cd.y),
+                          e.at<float>(bd.scale), e.at<float>(bd.shift), 1, e.at(blk.out), M, c2.cout, stream));
+        } else {
+          e.igemm(dd, e.at(x), e.at(cd.w_fwd), e.at(cd.y), e.at<float>(bd.scale), e.at<float>(bd.shift), nullptr,
+                  nullptr, nullptr, 0);
+          e.igemm(d2, e.at(blk.a1), e.at(c2.w_fwd), e.at(blk.out), e.at<float>(b2.scale), e.at<float>(b2.shift),
+                  e.at(cd.y), nullptr, nullptr, 1);
+        }
+      } else {
+        if (tr) {
+          e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(x), nullptr, nullptr, 1,
+                          e.at(blk.out), M, c2.cout, stream));
+        } else {
+          e.igemm(d2, e.at(blk.a1), e.at(c2.w_fwd), e.at(blk.out), e.at<float>(b2.scale), e.at<float>(b2.shift),
+                  e.at(x), nullptr, nullptr, 1);
+        }
+      }
+      x = blk.out;
+    }
+    // ---- global branch: avgpool(layer4) -> fused[:, 0:512] ----
+    e.run(qt_avgpool(dt, e.at(p->blocks[7].out), e.at(p->fused), batch, 49, 512, p->fused_ld, 0, stream));
+    // ---- quadrant branch on layer3's output ----
+    if (!p->standard) {
+      const ConvL& cq = p->convs[p->quad_conv];
+      e.igemm(e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), e.at(cq.w_fwd), e.at(p->q), nullptr, e.tf(cq.bias),
+              nullptr, nullptr, nullptr, 1);
+      e.run(qt_quad_pool(dt, e.at(p->q), e.at(p->fused), batch, p->fused_ld, 512, stream));
+    }
+  }
+  if (p->has_numerical) {
+    qt_gemm_small_desc g;
+    memset(&g, 0, sizeof(g));
+    g.M = batch; g.N = p->mlp0.out; g.K = p->mlp0.in;
+    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+    g.a_row_stride = p->mlp0.in; g.a_k_stride = 1; g.b_row_stride = p->mlp0.in; g.b_k_stride = 1;
+    g.c_row_stride = p->mlp0.out; g.relu = 1;
+    e.run(qt_gemm_small(&g, numerical, e.tf(p->mlp0.w), e.tf(p->mlp0.b), e.at(p->h1), stream));
+    if (tr && p->d.dropout_p > 0.f)
+      e.run(qt_dropout(QT_F32, e.at(p->h1), batch, p->mlp0.out, p->mlp0.out, seed, p->d.dropout_p, stream));
+    g.N = p->mlp1.out; g.K = p->mlp1.in;
+    g.a_row_stride = p->mlp1.in; g.b_row_stride = p->mlp1.in; g.c_dtype = dt; g.c_row_stride = p->fused_ld; g.relu = 0;
+    e.run(qt_gemm_small(&g, e.at(p->h1), e.tf(p->mlp1.w), e.tf(p->mlp1.b),
+                        e.at<unsigned char>(p->fused) + (size_t)p->mlp_col0 * p->esz, stream));
+  }
+  // ---- classifier: Linear -> ReLU -> Dropout -> Linear ----
+  e.igemm(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD), e.at(p->fused), e.at(p->cls0.w_fwd), e.at(p->hidden),
+          nullptr, e.tf(p->cls0.b), nullptr, nullptr, nullptr, 1);
+  if (tr && p->d.dropout_p > 0.f)
+    e.run(qt_dropout(dt, e.at(p->hidden), batch, p->hidden_dim, p->hidden_dim, seed ^ 0xA5A5A5A55A5A5A5Aull,
+                     p->d.dropout_p, stream));
+  {
+    qt_gemm_small_desc g;
+    memset(&g, 0, sizeof(g));
+    g.M = batch; g.N = p->cls3.out; g.K = p->cls3.in;
+    g.a_dtype = dt; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+    g.a_row_stride = p->cls3.in; g.a_k_stride = 1; g.b_row_stride = p->cls3.in; g.b_k_stride = 1;
+    g.c_row_stride = p->cls3.out;
+    e.run(qt_gemm_small(&g, e.at(p->hidden), e.tf(p->cls3.w), e.tf(p->cls3.b), logits, stream));
+  }
+  (void)hs;
+  p->last_batch = batch;
+  p->last_training = training;
+  p->last_seed = seed;
+  return e.status;
+}
+
+// zero-fill helper (hipMemsetAsync is capture-safe)
+int zero(void* ptr, size_t bytes, void* stream) {
+  hipError_t err = hipMemsetAsync(ptr, 0, bytes, static_cast<hipStream_t>(stream));
+  if (err != hipSuccess) {
+    qt_set_error("hipMemsetAsync: %s", hipGetErrorString(err));
+    return QT_ERR_LAUNCH;
+  }
+  return QT_OK;
+}
+
+struct Bwd : Exec {
+  float* const* G;  // gradient pointers (same indexing as T), NULL = not wanted
+  float* gf(int idx) const { return idx < 0 ? nullptr : G[idx]; }
+
+  // BatchNorm backward for conv c given g (in gy or external): dy -> c.gy
+  void bn_backward(const ConvL& c, const void* g, void* g_out) {
+    if (!ok()) return;
+    const BnL& bn = p->bns[c.bn];
+    const long long M = rows_of(c);
+    float* part = at<float>(p->stats);
+    run(qt_bn_bwd_reduce(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), part, M, bn.C, stream));
+    if (!ok()) return;
+    const int rows = qt_bn_bwd_partial_rows(M, bn.C);
+    run(qt_bn_bwd_finalize(part, rows, bn.C, M, tf(bn.gamma), at<float>(bn.invstd), gf(bn.gamma), gf(bn.beta), 0,
+                           at<float>(bn.coef), stream));
+    run(qt_bn_bwd_apply(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.coef),
+                        at(c.gy), g_out, M, bn.C, stream));
+  }
+  // weight gradient of conv c: dy = c.gy, x = src
+  void wgrad(const ConvL& c, const qt_conv_desc& fwd_desc, const void* src, bool stem) {
+    if (!ok() || !gf(c.w)) return;
+    const size_t n = stem ? (size_t)64 * 7 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
+    if (!stem && c.k == 1) {  // [O][1][I] is already OIHW
+      run(zero(gf(c.w), n * 4, stream));
+      run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, gf(c.w), stream));
+      return;
+    }
+    run(zero(at(c.dw), n * 4, stream));
+    run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, at<float>(c.dw), stream));
+    if (stem)
+      run(qt_unpack_stem_wgrad(at<float>(c.dw), gf(c.w), 0, stream));
+    else
+      run(qt_unpack_conv_wgrad(at<float>(c.dw), gf(c.w), c.cout, c.cin, c.k, c.k, 0, stream));
+  }
+};
+
+int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const float* numerical,
+             const float* dlogits, int phases, void* stream) {
+  Bwd e;
+  e.p = p; e.ws = static_cast<unsigned char*>(workspace); e.T = T; e.stream = stream; e.B = p->last_batch;
+  e.dt = p->d.dtype; e.G = G;
+  const int dt = e.dt;
+  const int B = e.B;
+  const bool tr = p->last_training != 0;
+  const float drop_mul = (tr && p->d.dropout_p > 0.f) ? 1.f / (1.f - p->d.dropout_p) : 1.f;
+  bool backbone_grads = false;
+  if (p->has_image)
+    for (size_t i = 0; i < p->convs.size(); ++i) {
+      if ((int)i == p->quad_conv) continue;
+      if (G[p->convs[i].w]) backbone_grads = true;
+    }
+  if (backbone_grads && !tr) {
+    qt_set_error("qt_plan_backward: backbone gradients in eval() mode are not implemented");
+    return QT_ERR_UNSUPPORTED;
+  }
+
+  if (phases & QT_BWD_HEAD) {
+    qt_gemm_small_desc g;
+    // ---- classifier.3 ----
+    if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, B, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, stream));
+    if (e.gf(p->cls3.w)) {
+      memset(&g, 0, sizeof(g));
+      g.M = p->cls3.out; g.N = p->cls3.in; g.K = B;
+      g.a_dtype = QT_F32; g.b_dtype = dt; g.c_dtype = QT_F32;
+      g.a_row_stride = 1; g.a_k_stride = p->cls3.out; g.b_row_stride = 1; g.b_k_stride = p->cls3.in;
+      g.c_row_stride = p->cls3.in;
+      e.run(qt_gemm_small(&g, dlogits, e.at(p->hidden), nullptr, e.gf(p->cls3.w), stream));
+    }
+    memset(&g, 0, sizeof(g));
+    g.M = B; g.N = p->cls3.in; g.K = p->cls3.out;
+    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = dt;
+    g.a_row_stride = p->cls3.out; g.a_k_stride = 1; g.b_row_stride = 1; g.b_k_stride = p->cls3.in;
+    g.c_row_stride = p->cls3.in;
+    e.run(qt_gemm_small(&g, dlogits, e.tf(p->cls3.w), nullptr, e.at(p->dhidden), stream));
+    e.run(qt_relu_mask_scale(dt, e.at(p->dhidden), e.at(p->hidden), (long long)B * p->hidden_dim, drop_mul, stream));
+    // ---- classifier.0 ----
+    if (e.gf(p->cls0.b))
+      e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, stream));
+    const qt_conv_desc lf = e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD);
+    if (e.gf(p->cls0.w)) {
+      e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, stream));
+      e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), stream));
+    }
+    const bool need_dfused = p->has_numerical || (p->has_image && (!p->standard || backbone_grads));
+    if (need_dfused)
+      e.igemm(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_DGRAD), e.at(p->dhidden), e.at(p->cls0.w_dgrad),
+              e.at(p->dfused), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    // ---- numerical MLP ----
+    if (p->has_numerical) {
+      const unsigned char* dz = e.at<unsigned char>(p->dfused) + (size_t)p->mlp_col0 * p->esz;
+      if (e.gf(p->mlp1.b)) e.run(qt_col_sum(dt, dz, B, p->mlp1.out, p->fused_ld, e.gf(p->mlp1.b), 0, stream));
+      if (e.gf(p->mlp1.w)) {
+        memset(&g, 0, sizeof(g));
+        g.M = p->mlp1.out; g.N = p->mlp1.in; g.K = B;
+        g.a_dtype = dt; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+        g.a_row_stride = 1; g.a_k_stride = p->fused_ld; g.b_row_stride = 1; g.b_k_stride = p->mlp1.in;
+        g.c_row_stride = p->mlp1.in;
+        e.run(qt_gemm_small(&g, dz, e.at(p->h1), nullptr, e.gf(p->mlp1.w), stream));
+      }
+      memset(&g, 0, sizeof(g));
+      g.M = B; g.N = p->mlp1.in; g.K = p->mlp1.out;
+      g.a_dtype = dt; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+      g.a_row_stride = p->fused_ld; g.a_k_stride = 1; g.b_row_stride = 1; g.b_k_stride = p->mlp1.in;
+      g.c_row_stride = p->mlp1.in;
+      e.run(qt_gemm_small(&g, dz, e.tf(p->mlp1.w), nullptr, e.at(p->dh1), stream));
+      e.run(qt_relu_mask_scale(QT_F32, e.at(p->dh1), e.at(p->h1), (long long)B * p->mlp0.out, drop_mul, stream));
+      if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, p->mlp0.out, p->mlp0.out, e.gf(p->mlp0.b), 0, stream));
+      if (e.gf(p->mlp0.w)) {
+        memset(&g, 0, sizeof(g));
+        g.M = p->mlp0.out; g.N = p->mlp0.in; g.K = B;
+        g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+        g.a_row_stride = 1; g.a_k_stride = p->mlp0.out; g.b_row_stride = 1; g.b_k_stride = p->mlp0.in;
+        g.c_row_stride = p->mlp0.in;
+        e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), stream));
+      }
+    }
+    // ---- quadrant head (weights are trainable in every variant) ----
+    if (p->has_image && !p->standard) {
+      const ConvL& cq = p->convs[p->quad_conv];
+      e.run(qt_quad_pool_bwd(dt, e.at(p->dfused), e.at(p->q), e.at(p->dq), B, p->fused_ld, 512, stream));
+      if (e.gf(cq.bias)) e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, stream));
+      e.wgrad(cq, e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), false);
+    }
+  }
+
+  if ((phases & QT_BWD_BACKBONE) && backbone_grads) {
+    // gradient of layer4's output through avgpool (+ ReLU mask of the block output)
+    e.run(qt_avgpool_bwd(dt, e.at(p->dfused), e.at(p->blocks[7].out), e.at(p->blocks[7].gout), B, 49, 512, p->fused_ld,
+                         0, stream));
+    for (int bi = 7; bi >= 0; --bi) {
+      const Block& blk = p->blocks[bi];
+      const ConvL& c1 = p->convs[blk.conv1];
+      const ConvL& c2 = p->convs[blk.conv2];
+      const size_t x = bi == 0 ? p->p0 : p->blocks[bi - 1].out;
+      const qt_conv_desc f1 = e.conv_desc(c1, QT_CONV_FWD), f2 = e.conv_desc(c2, QT_CONV_FWD);
+      // bn2 / conv2
+      e.bn_backward(c2, e.at(blk.gout), nullptr);
+      e.wgrad(c2, f2, e.at(blk.a1), false);
+      e.igemm(e.conv_desc(c2, QT_CONV_DGRAD), e.at(c2.gy), e.at(c2.w_dgrad), e.at(c1.gy), nullptr, nullptr, nullptr,
+              e.at(blk.a1), nullptr, 0);
+      // bn1 / conv1
+      e.bn_backward(c1, e.at(c1.gy), nullptr);
+      e.wgrad(c1, f1, e.at(x), false);
+      // gradient w.r.t. the block input = conv1 dgrad + identity path (+ quadrant head for layer3's output)
+      const void* resid = e.at(blk.gout);
+      if (blk.ds >= 0) {
+        const ConvL& cd = p->convs[blk.ds];
+        e.bn_backward(cd, e.at(blk.gout), nullptr);
+        e.wgrad(cd, e.conv_desc(cd, QT_CONV_FWD), e.at(x), false);
+        e.igemm(e.conv_desc(cd, QT_CONV_DGRAD), e.at(cd.gy), e.at(cd.w_dgrad), e.at(blk.gtmp), nullptr, nullptr,
+                nullptr, nullptr, nullptr, 0);
+        resid = e.at(blk.gtmp);
+      }
+      if (bi == 6 && !p->standard) {
+        const ConvL& cq = p->convs[p->quad_conv];
+        e.igemm(e.quad_desc(QT_CONV_DGRAD), e.at(p->dq), e.at(cq.w_dgrad), e.at(p->gbase_tmp), nullptr, nullptr, resid,
+                nullptr, nullptr, 0);
+        resid = e.at(p->gbase_tmp);
+      }
+      void* gprev = bi == 0 ? e.at(p->g_p0) : e.at(p->blocks[bi - 1].gout);
+      const void* mask = bi == 0 ? nullptr : e.at(x);
+      e.igemm(e.conv_desc(c1, QT_CONV_DGRAD), e.at(c1.gy), e.at(c1.w_dgrad), gprev, nullptr, nullptr, resid, mask,
+              nullptr, 0);
+    }
+    // ---- stem ----
+    const ConvL& c0 = p->convs[0];
+    const BnL& bn0 = p->bns[c0.bn];
+    e.run(qt_stem_pool_bwd(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
+                           e.at<float>(bn0.shift), e.at(c0.gy), B, stream));
+    e.bn_backward(c0, e.at(c0.gy), nullptr);
+    e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
+  }
+  return e.status;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
+  QT_CHECK_ARG(desc && out, "qt_plan_create: null argument");
+  QT_CHECK_ARG(desc->dtype == QT_F32 || desc->dtype == QT_BF16, "qt_plan_create: bad dtype %d", desc->dtype);
+  QT_CHECK_ARG(desc->batch > 0 && desc->batch <= 4096, "qt_plan_create: batch %d out of range", desc->batch);
+  QT_CHECK_ARG(desc->num_classes > 0 && desc->num_classes <= 4096, "qt_plan_create: bad num_classes");
+  QT_CHECK_ARG(desc->model == QT_MODEL_QUADTREE || desc->model == QT_MODEL_STANDARD_RESNET, "qt_plan_create: bad model");
+  QT_CHECK_ARG(desc->model == QT_MODEL_STANDARD_RESNET ||
+                   (desc->mode >= QT_MODE_FUSION && desc->mode <= QT_MODE_NUMERICAL_ONLY),
+               "qt_plan_create: bad mode %d", desc->mode);
+  QT_CHECK_ARG(desc->numerical_dim > 0 && desc->numerical_dim <= 1024, "qt_plan_create: bad numerical_dim");
+  QT_CHECK_ARG(desc->dropout_p >= 0.f && desc->dropout_p < 1.f, "qt_plan_create: bad dropout_p");
+  qt_plan* p = new qt_plan();
+  p->d = *desc;
+  p->esz = desc->dtype == QT_F32 ? 4 : 2;
+  build_graph(p);
+  layout_workspace(p);
+  *out = p;
+  return QT_OK;
+}
+
+extern "C" void qt_plan_destroy(qt_plan* p) { delete p; }
+extern "C" int qt_plan_num_tensors(const qt_plan* p) { return p ? (int)p->tensors.size() : QT_ERR_INVALID_ARG; }
+extern "C" const char* qt_plan_tensor_name(const qt_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->tensors.size()) ? p->tensors[i].name.c_str() : nullptr;
+}
+extern "C" int qt_plan_tensor_kind(const qt_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->tensors.size()) ? p->tensors[i].kind : QT_ERR_INVALID_ARG;
+}
+extern "C" int qt_plan_tensor_shape(const qt_plan* p, int i, int* dims) {
+  if (!p || !dims || i < 0 || i >= (int)p->tensors.size()) return QT_ERR_INVALID_ARG;
+  for (int k = 0; k < 4; ++k) dims[k] = p->tensors[i].shape[k];
+  return p->tensors[i].ndim;
+}
+extern "C" size_t qt_plan_workspace_bytes(const qt_plan* p) { return p ? p->ws_bytes : 0; }
+
+// Named views into the workspace (tests / Grad-CAM style introspection): the offset of
+// an activation or gradient buffer for the plan's maximum batch.
+extern "C" int qt_plan_find_buffer(const qt_plan* p, const char* name, size_t* offset) {
+  QT_CHECK_ARG(p && name && offset, "qt_plan_find_buffer: null argument");
+  const std::string n(name);
+  auto blockno = [&](const char* prefix) -> int {
+    const size_t len = strlen(prefix);
+    if (n.compare(0, len, prefix) != 0) return -1;
+    return atoi(n.c_str() + len);
+  };
+  auto suffix = [&](const char* suf) {
+    const size_t len = strlen(suf);
+    return n.size() >= len && n.compare(n.size() - len, len, suf) == 0;
+  };
+  if (n == "fused") { *offset = p->fused; return QT_OK; }
+  if (n == "dfused") { *offset = p->dfused; return QT_OK; }
+  if (n == "hidden") { *offset = p->hidden; return QT_OK; }
+  if (n == "stem.pooled") { *offset = p->p0; return QT_OK; }
+  if (n == "stem.gpooled") { *offset = p->g_p0; return QT_OK; }
+  int b = blockno("block");
+  if (b >= 0 && b < (int)p->blocks.size()) {
+    const Block& blk = p->blocks[b];
+    if (suffix(".out")) { *offset = blk.out; return QT_OK; }
+    if (suffix(".gout")) { *offset = blk.gout; return QT_OK; }
+    if (suffix(".a1")) { *offset = blk.a1; return QT_OK; }
+  }
+  int c = blockno("conv");
+  if (c >= 0 && c < (int)p->convs.size()) {
+    if (suffix(".y")) { *offset = p->convs[c].y; return QT_OK; }
+    if (suffix(".gy")) { *offset = p->convs[c].gy; return QT_OK; }
+  }
+  qt_set_error("qt_plan_find_buffer: unknown buffer '%s'", name);
+  return QT_ERR_INVALID_ARG;
+}
+
+extern "C" int qt_plan_init_workspace(qt_plan* p, void* workspace, void* stream) {
+  QT_CHECK_ARG(p && workspace, "qt_plan_init_workspace: null argument");
+  // ones / zeros vectors used as identity BatchNorm affine in eval mode
+  std::vector<float> one(2048, 1.f);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e1 = hipMemcpyAsync(static_cast<unsigned char*>(workspace) + p->ones, one.data(), 2048 * 4,
+                                 hipMemcpyHostToDevice, s);
+  hipError_t e2 = hipMemsetAsync(static_cast<unsigned char*>(workspace) + p->zeros, 0, 2048 * 4, s);
+  hipError_t e3 = hipStreamSynchronize(s);  // `one` is a host temporary
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    qt_set_error("qt_plan_init_workspace: HIP error");
+    return QT_ERR_LAUNCH;
+  }
+  return QT_OK;
+}
+
+extern "C" int qt_plan_pack_weights(qt_plan* p, void* workspace, void* const* tensors, int for_backward, void* stream) {
+  QT_CHECK_ARG(p && workspace && tensors, "qt_plan_pack_weights: null argument");
+  return pack_weights(p, workspace, tensors, for_backward, stream);
+}
+
+extern "C" int qt_plan_forward(qt_plan* p, void* workspace, void* const* tensors, const float* image,
+                               const float* numerical, float* logits, int batch, int training,
+                               unsigned long long seed, void* stream) {
+  QT_CHECK_ARG(p && workspace && tensors && logits, "qt_plan_forward: null argument");
+  QT_CHECK_ARG(batch > 0 && batch <= p->d.batch, "qt_plan_forward: batch %d exceeds the plan's %d", batch, p->d.batch);
+  QT_CHECK_ARG(!p->has_image || image, "qt_plan_forward: image required");
+  QT_CHECK_ARG(!p->has_numerical || numerical, "qt_plan_forward: numerical input required");
+  QT_CHECK_ARG(((uintptr_t)workspace % 256) == 0, "qt_plan_forward: workspace must be 256-byte aligned");
+  return forward(p, workspace, tensors, image, numerical, logits, batch, training, seed, stream);
+}
+
+extern "C" int qt_plan_backward(qt_plan* p, void* workspace, void* const* tensors, float* const* grads,
+                                const float* numerical, const float* dlogits, int phases, void* stream) {
+  QT_CHECK_ARG(p && workspace && tensors && grads && dlogits, "qt_plan_backward: null argument");
+  QT_CHECK_ARG(p->last_batch > 0, "qt_plan_backward: no forward pass recorded");
+  QT_CHECK_ARG(!p->has_numerical || numerical, "qt_plan_backward: numerical input required");
+  return backward(p, workspace, tensors, grads, numerical, dlogits, phases, stream);
+}

@@ -1,0 +1,218 @@
+"""Host side of the plan executor: binds a model's tensors to a `qt_plan`
+(include/qtcnn.h) and exposes it to autograd as ONE differentiable function
+(image, numerical, *parameters) -> logits.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every
+FLOP of the hot path is issued by libqtcnn_hip.so.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import QtError
+
+QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET = 0, 1
+MODES = {"fusion": 0, "image_only": 1, "numerical_only": 2}
+QT_BWD_HEAD, QT_BWD_BACKBONE = 1, 2
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", ctypes.c_int), ("batch", ctypes.c_int), ("num_classes", ctypes.c_int),
+        ("model", ctypes.c_int), ("mode", ctypes.c_int), ("numerical_dim", ctypes.c_int),
+        ("dropout_p", ctypes.c_float), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float),
+    ]
+
+
+def default_compute_dtype():
+    """bf16 is the throughput build; QTCNN_DTYPE=f32 selects the exact-f32 MFMA
+    parity build of the same kernels."""
+    name = os.environ.get("QTCNN_DTYPE", "bf16").lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    raise QtError(f"QTCNN_DTYPE={name!r}: expected bf16 or f32")
+
+
+def _bind_api(L):
+    if getattr(L, "_plan_bound", False):
+        return
+    L.qt_plan_create.argtypes = [ctypes.POINTER(PlanDesc), ctypes.POINTER(ctypes.c_void_p)]
+    L.qt_plan_destroy.argtypes = [ctypes.c_void_p]
+    L.qt_plan_destroy.restype = None
+    L.qt_plan_num_tensors.argtypes = [ctypes.c_void_p]
+    L.qt_plan_tensor_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.qt_plan_tensor_name.restype = ctypes.c_char_p
+    L.qt_plan_tensor_kind.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.qt_plan_tensor_shape.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.qt_plan_workspace_bytes.argtypes = [ctypes.c_void_p]
+    L.qt_plan_workspace_bytes.restype = ctypes.c_size_t
+    L.qt_plan_init_workspace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.qt_plan_pack_weights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.qt_plan_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p]
+    L.qt_plan_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.qt_plan_find_buffer.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    L._plan_bound = True
+
+
+class PlanEngine:
+    """One qt_plan + its workspace for one (model variant, device, dtype, max batch)."""
+
+    def __init__(self, model_kind, mode, num_classes, numerical_dim, dropout_p, batch, dtype, device):
+        self.L = _lib.lib()
+        _bind_api(self.L)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise QtError("the QuadtreeCNN plan runs on an AMD GPU only (device must be cuda:N); no CPU fallback")
+        self.dtype = dtype
+        self.max_batch = int(batch)
+        self.num_classes = num_classes
+        desc = PlanDesc(_lib.qt_dtype(dtype), self.max_batch, num_classes, model_kind, MODES.get(mode, 0),
+                        numerical_dim, float(dropout_p), 1e-5, 0.1)
+        handle = ctypes.c_void_p()
+        _lib.check(self.L.qt_plan_create(ctypes.byref(desc), ctypes.byref(handle)), "qt_plan_create")
+        self.handle = handle
+        n = self.L.qt_plan_num_tensors(handle)
+        self.names, self.kinds, self.shapes = [], [], []
+        dims = (ctypes.c_int * 4)()
+        for i in range(n):
+            self.names.append(self.L.qt_plan_tensor_name(handle, i).decode())
+            self.kinds.append(self.L.qt_plan_tensor_kind(handle, i))
+            nd = self.L.qt_plan_tensor_shape(handle, i, dims)
+            self.shapes.append(tuple(dims[k] for k in range(nd)))
+        self.index = {name: i for i, name in enumerate(self.names)}
+        nbytes = self.L.qt_plan_workspace_bytes(handle)
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-self.workspace.data_ptr()) % 256
+            self.ws_ptr = ctypes.c_void_p(self.workspace.data_ptr() + off)
+            _lib.check(self.L.qt_plan_init_workspace(handle, self.ws_ptr, _lib.stream_ptr()), "qt_plan_init_workspace")
+        self.workspace_bytes = nbytes
+        self._tensor_ptrs = (ctypes.c_void_p * n)()
+        self._packed_version = None
+        self.fwd_counter = 0
+        self.grad_sync = None  # optional callable(bucket: Tensor, phase: int) for data parallelism
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.L.qt_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def buffer(self, name, shape):
+        """View of a named workspace buffer as a tensor of the compute dtype (debug / tests)."""
+        off = ctypes.c_size_t()
+        _lib.check(self.L.qt_plan_find_buffer(self.handle, name.encode(), ctypes.byref(off)), "qt_plan_find_buffer")
+        base = (self.ws_ptr.value - self.workspace.data_ptr()) + off.value
+        n = int(torch.Size(shape).numel()) * (2 if self.dtype == torch.bfloat16 else 4)
+        return self.workspace[base:base + n].view(self.dtype).view(shape)
+
+    # -- binding --------------------------------------------------------------
+    def bind(self, tensors):
+        """tensors: dict state_dict-key -> tensor living on self.device."""
+        for i, name in enumerate(self.names):
+            t = tensors.get(name)
+            if t is None:
+                raise QtError(f"model is missing tensor {name!r} required by the plan")
+            if tuple(t.shape) != self.shapes[i]:
+                raise QtError(f"{name}: shape {tuple(t.shape)} != plan shape {self.shapes[i]}")
+            want = torch.int64 if self.kinds[i] == 2 else torch.float32
+            if t.dtype != want or t.device != self.device or not t.is_contiguous():
+                raise QtError(f"{name}: expected contiguous {want} on {self.device}, got {t.dtype} on {t.device}")
+            self._tensor_ptrs[i] = t.data_ptr()
+
+    def pack_weights(self, version, for_backward):
+        key = (version, bool(for_backward))
+        if self._packed_version is not None and self._packed_version[0] == version and \
+                (self._packed_version[1] or not for_backward):
+            return
+        _lib.check(self.L.qt_plan_pack_weights(self.handle, self.ws_ptr, self._tensor_ptrs, int(for_backward),
+                                               _lib.stream_ptr()), "qt_plan_pack_weights")
+        self._packed_version = key
+
+    # -- execution --------------------------------------------------------------
+    def forward(self, image, numerical, training, seed):
+        batch = int(image.shape[0]) if image is not None else int(numerical.shape[0])
+        logits = torch.empty(batch, self.num_classes, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.qt_plan_forward(self.handle, self.ws_ptr, self._tensor_ptrs,
+                                          _lib.ptr(image), _lib.ptr(numerical), _lib.ptr(logits), batch,
+                                          int(training), ctypes.c_ulonglong(seed), _lib.stream_ptr()),
+                   "qt_plan_forward")
+        self.fwd_counter += 1
+        return logits
+
+    def backward(self, dlogits, numerical, wanted):
+        """wanted: list of (plan tensor index, shape) in the order gradients are
+        returned.  Gradients are views of one flat f32 buffer laid out
+        [head | backbone] so a data-parallel caller can all-reduce two buckets."""
+        head = [w for w in wanted if not self.names[w[0]].startswith("base_cnn.")]
+        body = [w for w in wanted if self.names[w[0]].startswith("base_cnn.")]
+        sizes = {idx: int(torch.Size(shape).numel()) for idx, shape in wanted}
+        # keep every view 16-byte aligned
+        offs, total = {}, 0
+        for idx, _ in head + body:
+            offs[idx] = total
+            total += (sizes[idx] + 3) // 4 * 4
+        head_elems = sum((sizes[i] + 3) // 4 * 4 for i, _ in head)
+        flat = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
+        grad_ptrs = (ctypes.c_void_p * len(self.names))()
+        views = {}
+        for idx, shape in wanted:
+            v = flat[offs[idx]:offs[idx] + sizes[idx]].view(shape)
+            views[idx] = v
+            grad_ptrs[idx] = v.data_ptr()
+        for phase in (QT_BWD_HEAD, QT_BWD_BACKBONE):
+            _lib.check(self.L.qt_plan_backward(self.handle, self.ws_ptr, self._tensor_ptrs, grad_ptrs,
+                                               _lib.ptr(numerical), _lib.ptr(dlogits), phase, _lib.stream_ptr()),
+                       "qt_plan_backward")
+            if self.grad_sync is not None:
+                bucket = flat[:head_elems] if phase == QT_BWD_HEAD else flat[head_elems:total]
+                if bucket.numel():
+                    self.grad_sync(bucket, phase)
+        if self.grad_sync is not None:
+            self.grad_sync(None, 0)  # join
+        return [views[idx] for idx, _ in wanted]
+
+
+class PlanFunction(torch.autograd.Function):
+    """(image, numerical, *parameters) -> logits as a single autograd node."""
+
+    @staticmethod
+    def forward(ctx, owner, image, numerical, *params):
+        engine = owner._engine
+        training = owner.training
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
+        logits = engine.forward(image, numerical, training, seed)
+        ctx.owner = owner
+        ctx.engine = engine
+        ctx.fwd_id = engine.fwd_counter
+        ctx.numerical = numerical
+        ctx.param_index = owner._param_plan_index
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        engine = ctx.engine
+        if ctx.fwd_id != engine.fwd_counter:
+            raise QtError("backward() after a later forward() on the same model: the plan keeps one set of "
+                          "activations; call backward before the next forward")
+        needs = ctx.needs_input_grad[3:]
+        wanted = [(ctx.param_index[i], ctx.param_shapes[i]) for i, need in enumerate(needs)
+                  if need and ctx.param_index[i] >= 0]
+        grads = engine.backward(dlogits.contiguous().float(), ctx.numerical, wanted)
+        out, k = [], 0
+        for i, need in enumerate(needs):
+            if need and ctx.param_index[i] >= 0:
+                out.append(grads[k])
+                k += 1
+            else:
+                out.append(None)
+        return (None, None, None, *out)

@@ -1,0 +1,184 @@
+"""nn.Module surface of the reference models, executed by the HIP plan.
+
+Drop-in counterparts (same constructor arguments, attribute tree, state_dict
+keys, forward signature, train()/eval() semantics) of
+  QuadtreeCNN        /root/reference/Quadtree_from scratch/models.py:214-305
+                     /root/reference/resnet/models.py:70-180   (`mode`, frozen backbone)
+  StandardResNetCNN  /root/reference/resnet/models.py:7-65
+"""
+import torch
+import torch.nn as nn
+
+from . import engine as _engine
+from . import modules as M
+from ._lib import QtError
+
+IMAGE_HW = 224
+
+
+class _PlanModel(nn.Module):
+    """Shared machinery: lazily builds a PlanEngine for the current device /
+    batch / dtype, binds parameters + buffers by state_dict key and routes
+    forward through PlanFunction."""
+
+    _model_kind = _engine.QT_MODEL_QUADTREE
+
+    def _init_plan_state(self, compute_dtype=None, max_batch=None):
+        self.compute_dtype = compute_dtype or _engine.default_compute_dtype()
+        self._max_batch_hint = max_batch
+        self._engine = None
+        self._engine_key = None
+        self._param_list = None
+        self._param_plan_index = None
+
+    # engines hold device memory and ctypes handles: keep them out of pickles / deepcopy
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_engine", "_engine_key", "_param_list", "_param_plan_index"):
+            state[k] = None
+        return state
+
+    def _plan_mode(self):
+        return getattr(self, "mode", "fusion")
+
+    def _ensure_engine(self, batch, device):
+        key = (str(device), self.compute_dtype)
+        if self._engine is not None and self._engine_key == key and batch <= self._engine.max_batch:
+            return self._engine
+        cap = max(batch, self._max_batch_hint or 0)
+        self._engine = None  # free the old workspace first
+        self._engine = _engine.PlanEngine(self._model_kind, self._plan_mode(), self.num_classes,
+                                          self.numerical_feature_dim, self.dropout_rate, cap,
+                                          self.compute_dtype, device)
+        self._engine_key = key
+        self._param_list = None
+        return self._engine
+
+    def _bind(self, eng):
+        tensors = dict(self.named_parameters())
+        tensors.update(dict(self.named_buffers()))
+        eng.bind(tensors)
+        if self._param_list is None:
+            named = list(self.named_parameters())
+            self._param_list = [p for _, p in named]
+            self._param_plan_index = [
+                -1 if n.startswith("base_cnn.fc.") else eng.index.get(n, -1) for n, _ in named]
+        return sum(p._version for p in self._param_list)
+
+    def _run(self, image_input, numerical_input):
+        ref = image_input if image_input is not None else numerical_input
+        device = ref.device
+        if device.type != "cuda":
+            raise QtError("this build of the model runs on an AMD GPU only: move the model and its inputs "
+                          "to cuda:N (there is no CPU fallback for the product path)")
+        batch = int(ref.shape[0])
+        if image_input is not None:
+            if image_input.dim() != 4 or tuple(image_input.shape[1:]) != (3, IMAGE_HW, IMAGE_HW):
+                raise ValueError(f"image_input must be [B,3,{IMAGE_HW},{IMAGE_HW}], got {tuple(image_input.shape)}")
+            image_input = image_input.contiguous().float()
+        if numerical_input is not None:
+            if numerical_input.dim() != 2 or numerical_input.shape[1] != self.numerical_feature_dim or \
+                    numerical_input.shape[0] != batch:
+                raise ValueError(f"numerical_input must be [{batch},{self.numerical_feature_dim}], "
+                                 f"got {tuple(numerical_input.shape)}")
+            numerical_input = numerical_input.contiguous().float()
+        with torch.cuda.device(device):
+            eng = self._ensure_engine(batch, device)
+            version = self._bind(eng)
+            need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
+            eng.pack_weights(version, need_bwd)
+            return _engine.PlanFunction.apply(self, image_input, numerical_input, *self._param_list)
+
+
+class QuadtreeCNN(_PlanModel):
+    def __init__(self, num_classes, cnn_feature_dim=512, numerical_feature_dim=47, dropout_rate=0.5,
+                 mode="fusion", freeze_backbone=False, compute_dtype=None, max_batch=None):
+        super().__init__()
+        if cnn_feature_dim != 512:
+            raise ValueError("the gfx950 kernels are specialised for cnn_feature_dim=512 (the reference default)")
+        self.mode = mode
+        self.num_classes = num_classes
+        self.numerical_feature_dim = numerical_feature_dim
+        self.dropout_rate = dropout_rate
+
+        self.base_cnn = M.ResNet18()
+        M.load_pretrained_resnet18(self.base_cnn)
+        if freeze_backbone:
+            for param in self.base_cnn.parameters():
+                param.requires_grad = False
+        b = self.base_cnn
+        self.features_extractor = nn.Sequential(b.conv1, b.bn1, b.relu, b.maxpool, b.layer1, b.layer2, b.layer3)
+        self.quadrant_processor = nn.Sequential(
+            M.Conv2d(256, cnn_feature_dim // 4, 3, padding=1), M.ReLU(inplace=True), M.MaxPool2d(2, 2))
+        self.global_processor = nn.Sequential(b.layer4, b.avgpool)
+        self.image_feature_dim = 512 + (cnn_feature_dim // 4) * 3 * 3 * 4
+        assert self.image_feature_dim == 5120, f"Image feature dim mismatch: Expected 5120, got {self.image_feature_dim}"
+        self.numerical_mlp = nn.Sequential(
+            M.Linear(numerical_feature_dim, numerical_feature_dim * 2), M.ReLU(inplace=True),
+            M.Dropout(dropout_rate), M.Linear(numerical_feature_dim * 2, cnn_feature_dim // 2))
+        self.numerical_output_dim = cnn_feature_dim // 2
+        if mode == "fusion":
+            width = self.image_feature_dim + self.numerical_output_dim
+        elif mode == "image_only":
+            width = self.image_feature_dim
+        elif mode == "numerical_only":
+            width = self.numerical_output_dim
+        else:
+            raise ValueError(f"Invalid mode: {mode}. Choose from 'fusion', 'image_only', 'numerical_only', "
+                             "'standard_resnet_only'.")
+        self.final_classifier_input_dim = width
+        self.combined_feature_dim = width
+        self.classifier = nn.Sequential(
+            M.Linear(width, width // 2), M.ReLU(inplace=True), M.Dropout(dropout_rate),
+            M.Linear(width // 2, num_classes))
+        # Grad-CAM attributes of resnet/models.py:131-139
+        self.gradients = None
+        self.activations = None
+        self._init_plan_state(compute_dtype, max_batch)
+
+    def save_gradient_hook(self, module, grad_input, grad_output):
+        self.gradients = grad_output[0]
+
+    def save_activation_hook(self, module, input, output):
+        self.activations = output
+
+    def forward(self, image_input, numerical_input):
+        # inputs of an unused branch may be uninitialised memory (torch.empty dummies,
+        # /root/reference/experiment/test_on_video_cnn.py:264-271): never touch them
+        if self.mode == "numerical_only":
+            image_input = None
+        if self.mode == "image_only":
+            numerical_input = None
+        return self._run(image_input, numerical_input)
+
+
+class StandardResNetCNN(_PlanModel):
+    _model_kind = _engine.QT_MODEL_STANDARD_RESNET
+
+    def __init__(self, num_classes, dropout_rate=0.5, compute_dtype=None, max_batch=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.numerical_feature_dim = 47
+        self.dropout_rate = dropout_rate
+        self.base_cnn = M.ResNet18()
+        M.load_pretrained_resnet18(self.base_cnn)
+        for param in self.base_cnn.parameters():
+            param.requires_grad = False
+        b = self.base_cnn
+        self.features_extractor = nn.Sequential(b.conv1, b.bn1, b.relu, b.maxpool, b.layer1, b.layer2, b.layer3,
+                                                b.layer4)
+        self.avgpool = b.avgpool
+        self.classifier = nn.Sequential(M.Linear(512, 256), M.ReLU(inplace=True), M.Dropout(dropout_rate),
+                                        M.Linear(256, num_classes))
+        self.gradients = None
+        self.activations = None
+        self._init_plan_state(compute_dtype, max_batch)
+
+    def save_gradient_hook(self, module, grad_input, grad_output):
+        self.gradients = grad_output[0]
+
+    def save_activation_hook(self, module, input, output):
+        self.activations = output
+
+    def forward(self, image_input, numerical_input=None):  # numerical_input is ignored (resnet/models.py:56)
+        return self._run(image_input, None)

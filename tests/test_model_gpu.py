@@ -1,0 +1,152 @@
+"""Whole-model GPU parity through the nn.Module boundary.
+
+* against the golden vectors produced by the reference itself (tests/golden/*.npz)
+* against the CPU oracle (oracle/quadtree_oracle.py) on other batch sizes.
+
+Metric: max|x - ref| / max|ref|.  The f32-MFMA build must meet
+1e-3 on logits (north-star tolerance); the bf16 throughput build is checked
+against a looser, stated bound (bf16 has 8 significand bits: 4e-2).
+"""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _util import ROOT, check_summary, pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = {torch.float32: 1e-3, torch.bfloat16: 4e-2}
+# Gradients.  Head parameters (no ReLU between them and the loss that can flip) must
+# match tightly.  Backbone gradients pass through 17 ReLU masks: a pre-activation that is
+# within rounding distance of zero takes the other branch under a different summation
+# order (measured here: 1 element in 100,352 of layer4.0's output at B=4 in the f32 build)
+# and that one flip moves every gradient below it by ~1 %.  So the f32 build is held to
+# 6e-2 max-norm AND cosine >= 0.999 on the sampled elements; the bf16 build (8-bit
+# significands: ~0.3 % of masks flip per layer) to cosine >= 0.85 and sums within 15 %.
+HEAD_TOL = {torch.float32: 1e-4, torch.bfloat16: 2.5e-1}
+BODY_TOL = {torch.float32: 6e-2, torch.bfloat16: None}
+BODY_COS = {torch.float32: 0.999, torch.bfloat16: 0.85}
+BUF_TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def _cos(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _oracle():
+    sys.path.insert(0, ROOT)
+    import oracle.quadtree_oracle as o
+    return o
+
+
+def build(kind, dt, dropout=0.5, mode="fusion", frozen=False):
+    P = pkg()
+    synth = pkg("synth")
+    if kind == "standard":
+        m = P.StandardResNetCNN(12, dropout_rate=dropout, compute_dtype=dt)
+    else:
+        m = P.QuadtreeCNN(12, dropout_rate=dropout, mode=mode, freeze_backbone=frozen, compute_dtype=dt)
+    m.load_state_dict(synth.synth_state_dict(m))
+    return m
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_eval_logits_match_reference_golden(dt, golden_eval):
+    dev = _dev()
+    synth = pkg("synth")
+    images = synth.synth_images(2, salt=0).to(dev)
+    feats = synth.synth_pose_features(2, salt=0).to(dev)
+    for name, kind, mode in [("qs_quadtree_eval", "quadtree", "fusion"), ("rn_fusion_eval", "quadtree", "fusion"),
+                             ("rn_image_only_eval", "quadtree", "image_only"),
+                             ("rn_numerical_only_eval", "quadtree", "numerical_only"),
+                             ("rn_standard_eval", "standard", None)]:
+        m = build(kind, dt, mode=mode or "fusion").to(dev).eval()
+        with torch.no_grad():
+            # the unused branch gets uninitialised memory, like the reference's callers do
+            f = torch.empty_like(feats) if mode == "image_only" else feats
+            logits = m(images, f) if kind != "standard" else m(images)
+        err = rel_err(logits.cpu(), golden_eval[f"{name}/logits"])
+        assert err <= LOGIT_TOL[dt], (name, err)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["qs_quadtree_train", "rn_fusion_train", "rn_standard_train"])
+def test_train_step_matches_reference_golden(dt, case, golden_train):
+    """train() mode (BatchNorm batch statistics), dropout p=0, CE loss, full backward."""
+    dev = _dev()
+    synth = pkg("synth")
+    B = 4
+    images = synth.synth_images(B, salt=1).to(dev)
+    feats = synth.synth_pose_features(B, salt=1).to(dev)
+    labels = synth.synth_labels(B, 12, salt=1).to(dev)
+    if case == "rn_standard_train":
+        m = build("standard", dt, dropout=0.0)
+    else:
+        m = build("quadtree", dt, dropout=0.0, frozen=(case == "rn_fusion_train"))
+    m = m.to(dev).train()
+    logits = m(images, feats)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_err(logits.detach().cpu(), golden_train[f"{case}/logits"]) <= LOGIT_TOL[dt]
+    assert abs(loss.item() - float(golden_train[f"{case}/loss"])) <= LOGIT_TOL[dt] * max(1.0, abs(float(golden_train[f"{case}/loss"]))) * 10
+    names = list(golden_train[f"{case}/grad_names"])
+    params = dict(m.named_parameters())
+    got_names = [n for n, p in params.items() if p.grad is not None]
+    assert sorted(got_names) == sorted(names)
+    from _util import summary
+    for n in names:
+        g = params[n].grad.detach().cpu()
+        pre = f"{case}/grad/{n}"
+        assert tuple(g.shape) == tuple(int(x) for x in golden_train[f"{pre}/shape"])
+        smp, gold = summary(g)["sample"], golden_train[f"{pre}/sample"]
+        err = float(np.abs(smp - gold).max()) / max(float(np.abs(gold).max()), 1e-30)
+        if n.startswith("base_cnn."):
+            assert _cos(smp, gold) >= BODY_COS[dt], (n, _cos(smp, gold))
+            if BODY_TOL[dt] is not None:
+                assert err <= BODY_TOL[dt], (n, err)
+            else:
+                gs = float(golden_train[f"{pre}/abssum"])
+                assert abs(summary(g)["abssum"] - gs) <= 0.15 * gs, n
+        else:
+            assert err <= HEAD_TOL[dt], (n, err)
+    # running statistics were updated with torch's momentum / unbiased-variance rule
+    bufs = dict(m.named_buffers())
+    for k in golden_train.files:
+        if k.startswith(f"{case}/buf/") and k.endswith("/shape"):
+            n = k[len(f"{case}/buf/"):-len("/shape")]
+            check_summary(bufs[n].cpu(), golden_train, f"{case}/buf/{n}", BUF_TOL[dt])
+    assert int(bufs["base_cnn.bn1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("dt", [torch.float32])
+def test_eval_matches_oracle_other_batches(dt):
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    m = build("quadtree", dt).to(dev).eval()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for B in (1, 5):
+        images = synth.synth_images(B, salt=7 + B)
+        feats = synth.synth_pose_features(B, salt=7 + B)
+        with torch.no_grad():
+            ref = o.quadtree_forward(sd, images, feats)
+            got = m(images.to(dev), feats.to(dev)).cpu()
+        assert rel_err(got, ref) <= LOGIT_TOL[dt]
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    _dev()
+    m = build("quadtree", torch.float32)
+    with pytest.raises(pkg().QtError):
+        m(torch.zeros(1, 3, 224, 224), torch.zeros(1, 47))
