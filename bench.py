@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one QuadtreeCNN training step (forward +
+backward + gradient all-reduce + Adam) at 224x224, batch 256 per GPU, bf16.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is what the reference's hot loop does per batch
+(/root/reference/Quadtree_from scratch/Quadtree_train.py:62-66): zero_grad,
+model(images, numerical), CrossEntropyLoss, backward, Adam(lr 1e-4, wd 1e-4).step.
+Inputs are synthetic and already resident in HBM; weights are the deterministic
+synthetic fill.  Rank 0 prints ONE JSON line (contract in the task statement)
+with two extra objects:
+  roofline      the MFMA implicit-GEMM kernels (dominant kernel family), timed per
+                launch with HIP events on their own stream in extra steps right
+                after the timed region (event pairs would perturb `value`)
+  cpu_baseline  the CPU oracle (torch fp32 restatement, "port") on this box's host
+                cores, bounded sample, N=1 only
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "multimodal-hierarchical-cnn-for-sun-salutation-pose-classification_amd"
+
+FWD_BWD_GFLOP_PER_IMAGE = 11.0792   # BASELINE.md section 3 (all parameters trainable)
+FWD_GFLOP_PER_IMAGE = 3.7718
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--forward-only", action="store_true", help="time eval-mode forward instead of the train step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, num_classes=12):
+    """The oracle (kind "port") on the host cores: fwd+bwd+Adam on a bounded sample."""
+    import oracle.quadtree_oracle as o  # checker only, never the product path
+    P = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("QTCNN_CPU_THREADS", "16"))))  # a 1-GPU box's CPU share is 16
+    torch.set_num_threads(cores)
+    holder = P.QuadtreeCNN(num_classes)  # parameter tree only (CPU tensors), never called
+    sd0 = synth.synth_state_dict(holder)
+    keys = o.trainable_keys(sd0, False)
+    sd = o.unique_params(sd0, keys)
+    params = [sd[k] for k in keys]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-4)
+    B = args.cpu_batch
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    f = torch.randn(B, 47, generator=g)
+    y = torch.randint(0, num_classes, (B,), generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = o.quadtree_forward(sd, x, f, train=True)
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        opt.step()
+
+    step()  # warm-up
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 or (time.perf_counter() - t0 < 8.0 and iters < 20):
+        step()
+        iters += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} train steps (fwd+bwd+Adam) of batch {B}, torch {torch.__version__} CPU fp32, "
+                      f"oracle/quadtree_oracle.py"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    dp = importlib.import_module(PKG + ".dp")
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    C, B = 12, args.batch
+    model = P.QuadtreeCNN(C, compute_dtype=dt, max_batch=B)
+    model.load_state_dict(synth.synth_state_dict(model))
+    model = model.to(dev)
+    if world > 1:
+        dp.attach_data_parallel(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
+    crit = torch.nn.CrossEntropyLoss()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(B, 3, 224, 224, device=dev, generator=g)
+    feats = torch.randn(B, 47, device=dev, generator=g)
+    labels = torch.randint(0, C, (B,), device=dev, generator=g)
+
+    if args.forward_only:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model(images, feats)
+    else:
+        model.train()
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(images, feats), labels)
+            loss.backward()
+            opt.step()
+            return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the MFMA kernels: per-launch HIP events in extra steps ----
+    roofline = None
+    eng = model._engine
+    if eng is not None and args.profile_steps > 0:
+        L = eng.L
+        L.qt_plan_profile_begin.argtypes = [ctypes.c_void_p]
+        L.qt_plan_profile_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+        L.qt_plan_profile_begin(eng.handle)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        fl, ms, ln = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int * 3)()
+        L.qt_plan_profile_end(eng.handle, fl, ms, ln)
+        kinds = ["conv_igemm_kernel fwd", "conv_igemm_kernel dgrad", "conv_wgrad_kernel"]
+        per = {}
+        for k in range(3):
+            if ln[k]:
+                per[kinds[k]] = {"launches_per_step": ln[k] // args.profile_steps,
+                                 "avg_us": round(1e3 * ms[k] / ln[k], 2),
+                                 "gflop_per_launch": round(fl[k] / ln[k] / 1e9, 3),
+                                 "tflops": round(fl[k] / (ms[k] * 1e-3) / 1e12, 1)}
+        nig = ln[0] + ln[1]
+        if nig:
+            ach = (fl[0] + fl[1]) / ((ms[0] + ms[1]) * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            roofline = {"kernel": "conv_igemm_kernel (implicit-GEMM conv, fwd + dgrad launches)",
+                        "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None,
+                        "avg_launch_us": round(1e3 * (ms[0] + ms[1]) / nig, 2),
+                        "gflop_per_launch": round((fl[0] + fl[1]) / nig / 1e9, 3),
+                        "mfma_ms_per_step": round(sum(ms) / args.profile_steps, 3),
+                        "steps_profiled": args.profile_steps, "by_kernel": per}
+
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    imgs = B * world * args.steps
+    value = imgs / elapsed
+    gflop_img = FWD_GFLOP_PER_IMAGE if args.forward_only else FWD_BWD_GFLOP_PER_IMAGE
+    out = {
+        "metric": "images/sec fwd QuadtreeCNN 224x224" if args.forward_only
+        else "images/sec fwd+bwd QuadtreeCNN 224x224 bs256",
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic (randn images / pose vectors resident in HBM, deterministic synthetic weights)",
+        "config": {"workload": "QuadtreeCNN (ResNet-18 layer3, 2x2 split, 47-feat fusion) "
+                               + ("eval forward" if args.forward_only else "train step fwd+bwd+Adam, all parameters trainable"),
+                   "global_batch": B * world, "per_gpu_batch": B, "image": "3x224x224", "num_classes": C,
+                   "parallelism": f"dp{world}"},
+        "model_mfma_util": round(gflop_img * value / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args)
+        except Exception as e:  # the checker must never take the measurement down
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

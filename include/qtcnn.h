@@ -231,6 +231,11 @@ size_t qt_plan_workspace_bytes(const qt_plan* plan);
 /* byte offset inside the workspace of a named activation / gradient buffer:
  * "stem.pooled", "block<0-7>.out|.a1|.gout", "conv<i>.y|.gy", "fused", "dfused", "hidden" */
 int qt_plan_find_buffer(const qt_plan* plan, const char* name, size_t* offset);
+/* Measurement aid (bench.py roofline): while enabled, every MFMA kernel launch is
+ * bracketed by HIP events on its stream; _end sums algorithmic FLOPs, milliseconds
+ * and launch counts per kind {0 igemm forward, 1 igemm dgrad, 2 wgrad}. */
+int qt_plan_profile_begin(qt_plan* plan);
+int qt_plan_profile_end(qt_plan* plan, double* flops3, double* ms3, int* launches3);
 int qt_plan_init_workspace(qt_plan* plan, void* workspace, void* stream);
 int qt_plan_pack_weights(qt_plan* plan, void* workspace, void* const* tensors, int for_backward, void* stream);
 int qt_plan_forward(qt_plan* plan, void* workspace, void* const* tensors, const float* image, const float* numerical,

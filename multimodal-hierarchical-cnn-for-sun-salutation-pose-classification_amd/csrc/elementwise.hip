@@ -29,12 +29,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, 
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long long* num_batches_tracked,
                                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][4][64];
+  __shared__ double red[2][16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rl; r < rows; r += 4) {
+    for (int r = rl; r < rows; r += 16) {
       s1 += (double)partial[((long long)r * 2 + 0) * C + c];
       s2 += (double)partial[((long long)r * 2 + 1) * C + c];
     }
@@ -42,8 +42,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, 
   red[1][rl][cl] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
-    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    s1 = s2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -62,21 +65,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, 
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
 }
 
-// stage 1 of a long partial-row reduction: block (cb, s) sums rows [256 s, 256 s + 256)
-// of partial[rows][2][C] into row (rows + s).
+// stage 1 of a long partial-row reduction: block (cb, s) sums rows [64 s, 64 s + 64)
+// of partial[rows][2][C] into row (rows + s).  256 threads = 64 channels x 4 row lanes.
+constexpr int kFold = 64;
 __global__ void stats_stage1_kernel(float* partial, int rows, int C) {
   __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  const int r0 = blockIdx.y * 256;
-  int r1 = r0 + 256;
+  const int r0 = blockIdx.y * kFold;
+  int r1 = r0 + kFold;
   if (r1 > rows) r1 = rows;
   float s1 = 0.f, s2 = 0.f;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 4) {
       s1 += partial[((long long)r * 2 + 0) * C + c];
       s2 += partial[((long long)r * 2 + 1) * C + c];
     }
+  }
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();
@@ -202,12 +208,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* dgamma, float* dbeta, int accumulate, float* coef) {
-  __shared__ double red[2][4][64];
+  __shared__ double red[2][16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rl; r < rows; r += 4) {
+    for (int r = rl; r < rows; r += 16) {
       s1 += (double)partial[((long long)r * 2 + 0) * C + c];
       s2 += (double)partial[((long long)r * 2 + 1) * C + c];
     }
@@ -215,8 +221,11 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
   red[1][rl][cl] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
-    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    s1 = s2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
@@ -515,22 +524,22 @@ __global__ void relu_mask_scale_kernel(T* __restrict__ g, const T* __restrict__ 
   }
 }
 
-// out[c] (+)= sum_r x[r*ld + c]
+// out[c] += sum over this block's row chunk of x[r*ld + c]  (out pre-zeroed unless accumulating)
 template <typename T>
 __global__ void col_sum_kernel(const T* __restrict__ x, long long rows, int cols, int ld, float* __restrict__ out,
-                               int accumulate) {
+                               int rows_per_block) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
   float s = 0.f;
   if (c < cols)
-    for (long long r = rl; r < rows; r += 4) s += qt_to_f32<T>(x[r * ld + c]);
+    for (long long r = r0 + rl; r < r1; r += 4) s += qt_to_f32<T>(x[r * ld + c]);
   red[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && c < cols) {
-    s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-    out[c] = accumulate ? out[c] + s : s;
-  }
+  if (rl == 0 && c < cols) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
 }  // namespace
@@ -539,8 +548,8 @@ __global__ void col_sum_kernel(const T* __restrict__ x, long long rows, int cols
 
 // Long row counts are first folded 256:1 into the spare rows behind `rows`.
 static int fold_partial(float*& partial, int& rows, int C, hipStream_t s) {
-  if (rows <= 512) return QT_OK;
-  const int S = qt_cdiv(rows, 256);
+  if (rows <= 128) return QT_OK;
+  const int S = qt_cdiv(rows, kFold);
   hipLaunchKernelGGL(stats_stage1_kernel, dim3(qt_cdiv(C, 64), S), dim3(256), 0, s, partial, rows, C);
   QT_CHECK_LAUNCH();
   partial += (long long)rows * 2 * C;
@@ -548,7 +557,7 @@ static int fold_partial(float*& partial, int& rows, int C, hipStream_t s) {
   return QT_OK;
 }
 
-extern "C" int qt_stats_capacity_rows(int rows) { return rows <= 512 ? rows : rows + qt_cdiv(rows, 256); }
+extern "C" int qt_stats_capacity_rows(int rows) { return rows <= 128 ? rows : rows + qt_cdiv(rows, kFold); }
 
 extern "C" int qt_bn_finalize(float* partial, int rows, int C, long long count, const float* gamma,
                               const float* beta, float* running_mean, float* running_var,
@@ -558,7 +567,7 @@ extern "C" int qt_bn_finalize(float* partial, int rows, int C, long long count, 
                "qt_bn_finalize: bad argument");
   QT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "qt_bn_finalize: running stats must come in pairs");
   if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(1024), 0, static_cast<hipStream_t>(stream), partial,
                      rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      mean, invstd, scale, shift);
   QT_CHECK_LAUNCH();
@@ -630,7 +639,7 @@ extern "C" int qt_bn_bwd_finalize(float* partial, int rows, int C, long long cou
                                   void* stream) {
   QT_CHECK_ARG(partial && rows > 0 && C > 0 && count > 0 && invstd && coef, "qt_bn_bwd_finalize: bad argument");
   if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      partial, rows, C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -781,10 +790,15 @@ extern "C" int qt_col_sum(int dtype, const void* x, long long rows, int cols, in
   QT_DT_OK(dtype, "qt_col_sum");
   QT_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "qt_col_sum: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)cols * 4, s) != hipSuccess) {
+    qt_set_error("qt_col_sum: hipMemsetAsync failed");
+    return QT_ERR_LAUNCH;
+  }
+  const int rpb = 128;
   by_dtype(dtype, [&](auto tag) {
     using T = QT_T(tag);
-    hipLaunchKernelGGL(col_sum_kernel<T>, dim3(qt_cdiv(cols, 64)), dim3(256), 0, s, (const T*)x, rows, cols, ld, out,
-                       accumulate);
+    hipLaunchKernelGGL(col_sum_kernel<T>, dim3(qt_cdiv(cols, 64), qt_cdiv(rows, rpb)), dim3(256), 0, s, (const T*)x,
+                       rows, cols, ld, out, rpb);
   });
   QT_CHECK_LAUNCH();
   return QT_OK;

@@ -72,6 +72,11 @@ struct qt_plan {
   size_t xpad = 0, p0 = 0, argmax = 0, g_p0 = 0;
   size_t q = 0, dq = 0, fused = 0, dfused = 0, h1 = 0, dh1 = 0, hidden = 0, dhidden = 0;
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
+  // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
+  // the launch stream around every igemm / wgrad launch while enabled
+  struct Timed { hipEvent_t a, b; double flops; int kind; };
+  bool profiling = false;
+  std::vector<Timed> timed;
   // state of the last forward
   int last_batch = 0, last_training = 0;
   unsigned long long last_seed = 0;
@@ -350,7 +355,32 @@ struct Exec {
     qt_conv_desc dd = d;
     dd.relu = relu;
     qt_conv_io io = {src, w, dst, scale, shift, res, mask, stats};
+    const int slot = begin_timed(conv_flops(d), d.mode == QT_CONV_FWD ? 0 : 1);
     run(qt_conv2d_igemm(&dd, &io, stream));
+    end_timed(slot);
+  }
+
+  // algorithmic FLOPs (2*MAC of the convolution as the reference computes it: the
+  // 7x7x3 stem counts 147 taps, a stride-2 dgrad counts the forward conv's MACs)
+  double conv_flops(const qt_conv_desc& d) const {
+    const double imgs = (double)d.batch * (d.quad ? 4 : 1);
+    const double fwd_pixels = d.mode == QT_CONV_FWD ? (double)d.out_h * d.out_w : (double)d.in_h * d.in_w;
+    const bool stem = d.k_per_tap == 32 && d.kw == 1 && d.stride == 2 && d.n_out == 64;
+    const double k = stem ? 147.0 : (double)d.kh * d.kw * d.k_per_tap;
+    return 2.0 * imgs * fwd_pixels * k * d.n_out;
+  }
+  int begin_timed(double flops, int kind) {
+    if (!p->profiling) return -1;
+    qt_plan::Timed t;
+    if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
+    t.flops = flops;
+    t.kind = kind;
+    hipEventRecord(t.a, static_cast<hipStream_t>(stream));
+    p->timed.push_back(t);
+    return (int)p->timed.size() - 1;
+  }
+  void end_timed(int slot) {
+    if (slot >= 0) hipEventRecord(p->timed[slot].b, static_cast<hipStream_t>(stream));
   }
 
   long long rows_of(const ConvL& c) const { return (long long)B * c.hout * c.hout; }
@@ -536,11 +566,15 @@ struct Bwd : Exec {
     const size_t n = stem ? (size_t)64 * 7 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
     if (!stem && c.k == 1) {  // [O][1][I] is already OIHW
       run(zero(gf(c.w), n * 4, stream));
+      const int slot = begin_timed(conv_flops(fwd_desc), 2);
       run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, gf(c.w), stream));
+      end_timed(slot);
       return;
     }
     run(zero(at(c.dw), n * 4, stream));
+    const int slot = begin_timed(conv_flops(fwd_desc), 2);
     run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, at<float>(c.dw), stream));
+    end_timed(slot);
     if (stem)
       run(qt_unpack_stem_wgrad(at<float>(c.dw), gf(c.w), 0, stream));
     else
@@ -593,7 +627,9 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     const qt_conv_desc lf = e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD);
     if (e.gf(p->cls0.w)) {
       e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, stream));
+      const int slot = e.begin_timed(e.conv_flops(lf), 2);
       e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), stream));
+      e.end_timed(slot);
     }
     const bool need_dfused = p->has_numerical || (p->has_image && (!p->standard || backbone_grads));
     if (need_dfused)
@@ -758,6 +794,35 @@ extern "C" int qt_plan_find_buffer(const qt_plan* p, const char* name, size_t* o
   }
   qt_set_error("qt_plan_find_buffer: unknown buffer '%s'", name);
   return QT_ERR_INVALID_ARG;
+}
+
+// ---- per-launch MFMA kernel timing (kinds: 0 igemm forward, 1 igemm dgrad, 2 wgrad) ----
+extern "C" int qt_plan_profile_begin(qt_plan* p) {
+  QT_CHECK_ARG(p, "qt_plan_profile_begin: null plan");
+  for (auto& t : p->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  p->timed.clear();
+  p->profiling = true;
+  return QT_OK;
+}
+// Stops profiling, waits for the recorded events and sums per kind:
+// flops[3], ms[3], launches[3].
+extern "C" int qt_plan_profile_end(qt_plan* p, double* flops, double* ms, int* launches) {
+  QT_CHECK_ARG(p && flops && ms && launches, "qt_plan_profile_end: null argument");
+  p->profiling = false;
+  for (int k = 0; k < 3; ++k) { flops[k] = 0; ms[k] = 0; launches[k] = 0; }
+  int st = QT_OK;
+  for (auto& t : p->timed) {
+    float dt = 0.f;
+    if (hipEventSynchronize(t.b) != hipSuccess || hipEventElapsedTime(&dt, t.a, t.b) != hipSuccess) {
+      qt_set_error("qt_plan_profile_end: event query failed");
+      st = QT_ERR_LAUNCH;
+    } else if (t.kind >= 0 && t.kind < 3) {
+      flops[t.kind] += t.flops; ms[t.kind] += dt; launches[t.kind] += 1;
+    }
+    hipEventDestroy(t.a); hipEventDestroy(t.b);
+  }
+  p->timed.clear();
+  return st;
 }
 
 extern "C" int qt_plan_init_workspace(qt_plan* p, void* workspace, void* stream) {

@@ -1,0 +1,85 @@
+"""Data parallelism for the QuadtreeCNN train step: one process per GPU,
+replicated weights, each rank runs the plan on its shard of the batch, one
+gradient all-reduce (RCCL over xGMI; `nccl` backend of torch.distributed) per
+step.  The reference has no distributed code at all; message
+sizes and overlap plan are in SURVEY.md 8(e).
+
+The plan's backward hands over its flat f32 gradient buffer in two buckets, in
+the order they become final:
+  phase 1 (head)      classifier + numerical MLP + quadrant conv  (~57 % of the bytes,
+                      ready before any backbone kernel has run)
+  phase 2 (backbone)  ResNet-18 stages + stem
+Each bucket is averaged across ranks on a dedicated communication stream while
+the compute stream continues with the backbone backward; the compute stream
+waits for the communication stream once, at the end of backward.  BatchNorm
+statistics stay per replica (the reference has no SyncBN).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch, rank, world_size):
+    """[begin, end) of the samples of `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(int(global_batch), int(world_size))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class GradBucketReducer:
+    """callable(bucket, phase): average `bucket` over the process group.
+    phase 0 / bucket None = join (make the results visible to the compute stream)."""
+
+    def __init__(self, process_group=None, average=True):
+        self.group = process_group
+        self.average = average
+        self.world = dist.get_world_size(process_group)
+        self.comm_stream = None
+        self.bytes_reduced = 0
+        self._avg_ok = dist.get_backend(process_group) == "nccl"
+
+    def __call__(self, bucket, phase):
+        if bucket is None:
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            return
+        self.bytes_reduced += bucket.numel() * bucket.element_size()
+        if self.world == 1:
+            return
+        if bucket.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=bucket.device)
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            bucket.record_stream(self.comm_stream)
+            with torch.cuda.stream(self.comm_stream):
+                if self.average and self._avg_ok:
+                    dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.average:
+                        bucket.div_(self.world)
+        else:  # gloo on CPU tensors (tests)
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                bucket.div_(self.world)
+
+
+def broadcast_state(model, src=0, process_group=None):
+    """Replicate rank `src`'s parameters and buffers (aliased tensors once)."""
+    seen = set()
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.data_ptr() in seen:
+            continue
+        seen.add(t.data_ptr())
+        dist.broadcast(t.data, src=src, group=process_group)
+
+
+def attach_data_parallel(model, process_group=None, broadcast=True):
+    """Make `model` (a QuadtreeCNN / StandardResNetCNN of this package) average its
+    gradients over the process group inside backward().  The training loop itself
+    (reference: Quadtree_from scratch/Quadtree_train.py:60-66) stays unchanged."""
+    if broadcast:
+        broadcast_state(model, 0, process_group)
+    model._grad_sync = GradBucketReducer(process_group)
+    if getattr(model, "_engine", None) is not None:
+        model._engine.grad_sync = model._grad_sync
+    return model

@@ -30,11 +30,12 @@ class _PlanModel(nn.Module):
         self._engine_key = None
         self._param_list = None
         self._param_plan_index = None
+        self._grad_sync = None  # set by dp.attach_data_parallel
 
     # engines hold device memory and ctypes handles: keep them out of pickles / deepcopy
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_engine", "_engine_key", "_param_list", "_param_plan_index"):
+        for k in ("_engine", "_engine_key", "_param_list", "_param_plan_index", "_grad_sync"):
             state[k] = None
         return state
 
@@ -52,6 +53,7 @@ class _PlanModel(nn.Module):
                                           self.compute_dtype, device)
         self._engine_key = key
         self._param_list = None
+        self._engine.grad_sync = self._grad_sync
         return self._engine
 
     def _bind(self, eng):
