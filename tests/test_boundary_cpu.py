@@ -1,0 +1,136 @@
+"""CPU: the drop-in boundary (module tree, state_dict layout, factories, error
+behaviour) and the C-ABI library (loads, exports every symbol of include/qtcnn.h).
+No compute is issued here: there is no GPU in this container."""
+import ctypes
+import importlib
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _util import PKG, ROOT, pkg
+
+
+def test_state_dict_layout_matches_reference(golden_eval):
+    P = pkg()
+    m = P.QuadtreeCNN(12)
+    assert list(m.state_dict().keys()) == list(golden_eval["meta/state_dict_keys_quadtree"])
+    assert [n for n, _ in m.named_parameters()] == list(golden_eval["meta/param_names_quadtree"])
+    assert len(m.state_dict()) == 252 and len(list(m.parameters())) == 72
+    s = P.StandardResNetCNN(12)
+    assert list(s.state_dict().keys()) == list(golden_eval["meta/state_dict_keys_standard"])
+    # aliased keys share storage (triple alias of the backbone)
+    sd = m.state_dict()
+    assert sd["base_cnn.conv1.weight"].data_ptr() == sd["features_extractor.0.weight"].data_ptr()
+    assert sd["base_cnn.layer4.0.conv1.weight"].data_ptr() == sd["global_processor.0.0.conv1.weight"].data_ptr()
+    assert sum(p.numel() for p in m.parameters()) == 26_499_028
+
+
+def _load_dropin(sub):
+    path = os.path.join(ROOT, PKG, sub, "models.py")
+    spec = importlib.util.spec_from_file_location(f"dropin_{sub}", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_dropin_models_surface(golden_eval, capsys):
+    qs = _load_dropin("quadtree_from_scratch")
+    rn = _load_dropin("resnet")
+    m = qs.get_model("quadtree", 12, "cpu")
+    assert "Trainable Parameters" in capsys.readouterr().out
+    assert all(p.requires_grad for p in m.parameters())
+    with pytest.raises(TypeError):  # reference: StandardMultimodalCNN is `pass` (models.py:211-213,318-319)
+        qs.get_model("resnet50", 12, "cpu")
+    with pytest.raises(RuntimeError):
+        qs.get_model("hierarchical_quadtree", 12, "cpu")
+    for mode in ("fusion", "image_only", "numerical_only"):
+        q = rn.get_model(12, "cpu", mode=mode, print_num_params=False)
+        trainable = sum(p.numel() for p in q.parameters() if p.requires_grad)
+        assert trainable == int(golden_eval[f"meta/trainable_{mode}"])
+        assert not any(p.requires_grad for p in q.base_cnn.parameters())
+        assert q.mode == mode and q.gradients is None and q.activations is None
+    s = rn.get_model(12, "cpu", mode="standard_resnet_only", print_num_params=False)
+    assert type(s).__name__ == "StandardResNetCNN" and len(s.state_dict()) == 246
+    with pytest.raises(ValueError):
+        rn.QuadtreeCNN(12, mode="bogus")
+    # hookable layer4 module and the hook methods of resnet/models.py:135-139
+    assert isinstance(q.base_cnn.layer4, torch.nn.Module)
+    q.save_activation_hook(None, None, "a")
+    q.save_gradient_hook(None, None, ("g",))
+    assert q.activations == "a" and q.gradients == "g"
+
+
+def test_no_cpu_fallback():
+    P = pkg()
+    m = P.QuadtreeCNN(12)
+    with pytest.raises(P.QtError):
+        m(torch.zeros(1, 3, 224, 224), torch.zeros(1, 47))
+    with pytest.raises(P.QtError):
+        m.base_cnn.conv1(torch.zeros(1, 3, 224, 224))
+
+
+def test_input_validation_happens_before_any_device_work():
+    P = pkg()
+    m = P.QuadtreeCNN(12)
+    with pytest.raises((ValueError, P.QtError)):
+        m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 47))
+
+
+def test_synth_rule_is_deterministic_and_alias_consistent():
+    P, synth = pkg(), pkg("synth")
+    a = synth.synth_state_dict(P.QuadtreeCNN(12))
+    b = synth.synth_state_dict(P.QuadtreeCNN(12))
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["base_cnn.layer1.0.conv1.weight"], a["features_extractor.4.0.conv1.weight"])
+    assert float(a["base_cnn.bn1.running_var"].min()) > 0.5
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = os.path.join(ROOT, PKG, "libqtcnn_hip.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__ as g
+        g.build()
+    header = open(os.path.join(ROOT, "include", "qtcnn.h")).read()
+    declared = set(re.findall(r"\b(qt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"qt_plan_desc", "qt_conv_desc", "qt_dtype", "qt_status"}
+    assert len(declared) >= 40
+    lib = ctypes.CDLL(lib_path)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.qt_version.restype = ctypes.c_int
+    assert lib.qt_version() >= 100
+
+
+def test_plan_tensor_table_matches_module_tree():
+    """qt_plan_create touches no GPU: the tensor table must name exactly the model's tensors."""
+    P = pkg()
+    eng = pkg("engine")
+    L = pkg("_lib").lib()
+    eng._bind_api(L)
+    for kind, model in ((0, P.QuadtreeCNN(12)), (1, P.StandardResNetCNN(12))):
+        desc = eng.PlanDesc(1, 8, 12, kind, 0, 47, 0.5, 1e-5, 0.1)
+        h = ctypes.c_void_p()
+        assert L.qt_plan_create(ctypes.byref(desc), ctypes.byref(h)) == 0
+        tensors = dict(model.named_parameters())
+        tensors.update(dict(model.named_buffers()))
+        dims = (ctypes.c_int * 4)()
+        n = L.qt_plan_num_tensors(h)
+        names = set()
+        for i in range(n):
+            name = L.qt_plan_tensor_name(h, i).decode()
+            names.add(name)
+            nd = L.qt_plan_tensor_shape(h, i, dims)
+            assert name in tensors, name
+            assert tuple(dims[k] for k in range(nd)) == tuple(tensors[name].shape), name
+        assert names == set(tensors.keys())
+        assert L.qt_plan_workspace_bytes(h) > 0
+        L.qt_plan_destroy(h)
+    bad = eng.PlanDesc(5, 8, 12, 0, 0, 47, 0.5, 1e-5, 0.1)
+    assert L.qt_plan_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    L.qt_last_error.restype = ctypes.c_char_p
+    assert b"dtype" in L.qt_last_error()

@@ -1,0 +1,72 @@
+"""CPU: the oracle restatement is pinned by the vectors the reference itself produced
+(tests/golden/*.npz, generator tests/golden/make_golden.py)."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _util import ROOT, check_summary, pkg, rel_err, summary
+
+sys.path.insert(0, ROOT)
+import oracle.quadtree_oracle as o  # noqa: E402
+
+TOL = 2e-5  # same torch CPU kernels, different call graph (functional vs nn.Module): rounding only
+
+
+def _sd(kind="quadtree", mode="fusion"):
+    P, synth = pkg(), pkg("synth")
+    m = P.StandardResNetCNN(12) if kind == "standard" else P.QuadtreeCNN(12, mode=mode)
+    return synth.synth_state_dict(m)
+
+
+def test_oracle_eval_logits_and_taps(golden_eval):
+    torch.set_num_threads(8)
+    synth = pkg("synth")
+    x, f = synth.synth_images(2, salt=0), synth.synth_pose_features(2, salt=0)
+    taps = {}
+    with torch.no_grad():
+        logits = o.quadtree_forward(_sd(), x, f, taps=taps)
+    assert rel_err(logits, golden_eval["qs_quadtree_eval/logits"]) <= TOL
+    for name in ("stem", "layer1", "layer2", "layer3", "layer4", "numerical_features", "hidden"):
+        check_summary(taps[name], golden_eval, f"qs_quadtree_eval/tap/{name}", TOL)
+    for mode in ("fusion", "image_only", "numerical_only"):
+        with torch.no_grad():
+            logits = o.quadtree_forward(_sd(mode=mode), x, f, mode=mode)
+        assert rel_err(logits, golden_eval[f"rn_{mode}_eval/logits"]) <= TOL
+    with torch.no_grad():
+        logits = o.standard_resnet_forward(_sd("standard"), x)
+    assert rel_err(logits, golden_eval["rn_standard_eval/logits"]) <= TOL
+
+
+def test_oracle_rejects_bad_mode():
+    with pytest.raises(ValueError):
+        o.quadtree_forward({}, None, None, mode="standard_resnet_only")
+
+
+@pytest.mark.parametrize("case,frozen", [("qs_quadtree_train", False), ("rn_fusion_train", True)])
+def test_oracle_train_step(case, frozen, golden_train):
+    torch.set_num_threads(8)
+    synth = pkg("synth")
+    B = 4
+    x, f, y = synth.synth_images(B, salt=1), synth.synth_pose_features(B, salt=1), synth.synth_labels(B, 12, salt=1)
+    sd0 = _sd()
+    keys = o.trainable_keys(sd0, frozen)
+    sd = o.unique_params(sd0, keys)
+    logits = o.quadtree_forward(sd, x, f, train=True, dropout_p=0.0)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    assert rel_err(logits.detach(), golden_train[f"{case}/logits"]) <= TOL
+    assert abs(loss.item() - float(golden_train[f"{case}/loss"])) <= 1e-4
+    names = list(golden_train[f"{case}/grad_names"])
+    assert sorted(names) == sorted(keys)
+    for n in names:
+        pre = f"{case}/grad/{n}"
+        smp, gold = summary(sd[n].grad)["sample"], golden_train[f"{pre}/sample"]
+        # rounding-level differences may flip an isolated ReLU (see tests/test_model_gpu.py)
+        tol = 5e-2 if n.startswith("base_cnn.") else 1e-4
+        assert float(np.abs(smp - gold).max()) <= tol * max(float(np.abs(gold).max()), 1e-30), n
+    for k in golden_train.files:
+        if k.startswith(f"{case}/buf/") and k.endswith("/shape"):
+            n = k[len(f"{case}/buf/"):-len("/shape")]
+            check_summary(sd[n], golden_train, f"{case}/buf/{n}", 1e-5)
