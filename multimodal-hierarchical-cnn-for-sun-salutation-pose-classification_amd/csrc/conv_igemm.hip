@@ -7,7 +7,7 @@
 //
 // GEMM view:  D[n][m] = sum_{tap,k} W[n][tap][k] * X[pixel(m) shifted by tap][k]
 //   m = destination pixel (image, oh, ow) flattened, n = destination channel.
-// Workgroup = 256 threads = 4 waves (2x2), tile BM pixels x BN channels,
+// Workgroup = WM x WN waves, tile BM pixels x BN channels (256x128 / 8 waves or 128x128 / 4),
 // K-step = 128 bytes of K per row (64 bf16 / 32 f32).  Both operand tiles are
 // staged global -> registers -> LDS (zero fill of the halo happens in the
 // register stage), double buffered, one barrier per K-step; the LDS image is
@@ -43,14 +43,39 @@ struct ConvArgs {
 
 constexpr int kRowBytes = 128;  // bytes of K per row per K-step
 
-template <typename T, int BM, int BN, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+// 128 bytes of zeros: the LDS-DMA source of halo pixels and of rows past the tensor's end
+__device__ uint4 qt_zero_page[8];
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to the 1 KiB
+// at LDS byte address `lds_addr` (wave-uniform).  Issued from inline asm on purpose: the
+// compiler then neither counts it in vmcnt nor fences later LDS reads with vmcnt(0), so
+// the ring below can keep stages in flight across barriers with counted waits (the
+// kernel's own s_waitcnt vmcnt(N) + s_barrier order the data before it is read).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)p);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int NT = 64 * WM * WN;   // threads
+  constexpr int RG = NT / 8;         // rows staged per pass of the whole workgroup
   constexpr int BK = kRowBytes / (int)sizeof(T);
-  constexpr int RA = BM / 32;  // pixel rows staged per thread
-  constexpr int RW = BN / 32;  // weight rows staged per thread
-  constexpr int TM = BM / 32;  // 16-wide pixel tiles per wave
-  constexpr int TN = BN / 32;  // 16-wide channel tiles per wave
+  constexpr int RA = BM / RG;        // pixel rows staged per thread
+  constexpr int RW = BN / RG;        // weight rows staged per thread
+  constexpr int TM = BM / WM / 16;   // 16-wide pixel tiles per wave
+  constexpr int TN = BN / WN / 16;   // 16-wide channel tiles per wave
   constexpr int STAGE_BYTES = (BM + BN) * kRowBytes;
+  static_assert(RA >= 1 && RW >= 1 && BM % RG == 0 && BN % RG == 0, "tile / thread-count mismatch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const T* __restrict__ src = static_cast<const T*>(p.src);
@@ -58,22 +83,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
 
   const int bid = qt_xcd_remap(blockIdx.x, p.gridM * p.gridN);
   const int mt = bid / p.gridN, nt = bid - mt * p.gridN;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread staging rows -------------------------------------------------
-  const int chunk = tid & 7;  // 16-byte chunk inside the 128-byte row
-  const int rbase = tid >> 3;  // 0..31
+  // Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 8 rows x
+  // 128 B, lane-linear in LDS.  The XOR chunk swizzle therefore sits on the SOURCE side:
+  // LDS slot (lane&7) of row r receives source chunk (lane&7)^(r&7).
+  const int rbase = tid >> 3;  // row inside an RG-row group
+  const int chunk = (tid & 7) ^ (rbase & 7);  // source 16-byte chunk of this lane
+  // Per staged pixel row: a base pointer (tap (0,0), this lane's chunk) and one validity
+  // bit per tap, both computed once; a K-step then costs one shift/test and one 64-bit
+  // add per row.  (Stride-2 data gradients keep the general per-step gather.)
   long long a_base[RA];
   int a_oh[RA], a_ow[RA];
+  const T* a_ptr[RA];
+  unsigned a_mask[RA];
   const int OHW = p.OH * p.OW;
+  const bool slow = DGRAD && p.stride == 2;
+  auto axis_ok = [&](int o, int k, int extent) -> bool {
+    if (!DGRAD) return (unsigned)(o * p.stride - p.pad + k) < (unsigned)extent;
+    const int t = o + p.pad - k;
+    return t >= 0 && !(t & (p.stride - 1)) && (t >> (p.stride - 1)) < extent;  // stride is 1 or 2
+  };
+  auto tap_src = [&](int oh, int ow, int kh, int kw, int& ih, int& iw) -> bool {
+    bool ok;
+    if (!DGRAD) {
+      ih = oh * p.stride - p.pad + kh;
+      iw = ow * p.stride - p.pad + kw;
+      ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+    } else {
+      const int th = oh + p.pad - kh, tw = ow + p.pad - kw;
+      ok = th >= 0 && tw >= 0;
+      if (p.stride == 2) {
+        ok = ok && !((th | tw) & 1);
+        ih = th >> 1;
+        iw = tw >> 1;
+      } else {
+        ih = th;
+        iw = tw;
+      }
+      ok = ok && ih < p.IH && iw < p.IW;
+    }
+    return ok;
+  };
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = m0 + rbase + 32 * i;
+    const int m = m0 + rbase + RG * i;
+    a_base[i] = 0;
+    a_oh[i] = a_ow[i] = 0;
+    a_mask[i] = 0;
+    a_ptr[i] = src;
     if (m < p.M) {
       int img = m / OHW;
       int rem = m - img * OHW;
@@ -102,10 +166,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       a_base[i] = base;
       a_oh[i] = oh;
       a_ow[i] = ow;
-    } else {
-      a_base[i] = 0;
-      a_oh[i] = -100000;  // every tap invalid
-      a_ow[i] = -100000;
+      // validity is separable: tap (kh,kw) is valid iff row tap kh and column tap kw are
+      unsigned vw = 0, mask = 0;
+      const int KH = p.ntaps / p.KW;
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (axis_ok(ow, kw, p.IW)) vw |= 1u << kw;
+      for (int kh = 0; kh < KH; ++kh)
+        if (axis_ok(oh, kh, p.IH)) mask |= vw << (kh * p.KW);
+      a_mask[i] = mask;
+      const long long h0 = DGRAD ? (oh + p.pad) : (oh * p.stride - p.pad);
+      const long long w0 = DGRAD ? (ow + p.pad) : (ow * p.stride - p.pad);
+      a_ptr[i] = src + base + h0 * p.src_row_stride + w0 * p.src_pix_stride + chunk * (16 / (int)sizeof(T));
     }
   }
   const int ktot = p.ntaps * p.KC;
@@ -113,77 +184,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   bool w_ok[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
-    const int n = n0 + rbase + 32 * i;
+    const int n = n0 + rbase + RG * i;
     w_ok[i] = n < p.N;
     w_ptr[i] = wgt + (long long)(w_ok[i] ? n : 0) * ktot + chunk * (16 / (int)sizeof(T));
   }
 
-  uint4 ra[RA], rw[RW];
-  const int ksteps_per_tap = p.KC / BK;
   const int nk = (p.ntaps * p.KC) / BK;
 
   // A K-step is 128 bytes of K per row.  Normally that is a slice of one tap
   // (tap uniform over the workgroup); when a tap is only 64 bytes (the packed
   // bf16 stem) a K-step spans two taps and the tap depends on the chunk.
   const int sub = p.KC * (int)sizeof(T) < kRowBytes;
-  auto load_stage = [&](int ks) {
-    int tap, c0;
-    if (sub) {
-      tap = ks * 2 + (chunk >> 2);
-      c0 = -(chunk >> 2) * (BK / 2);  // chunk*EPC + c0 = element inside the tap
+  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
+  const unsigned smem_base = lds_addr_of(smem);
+  // uniform (tap, channel offset) of the NEXT stage to issue; stages are issued in order
+  int nx_kh = 0, nx_kw = 0, nx_tap = 0, nx_c0 = 0;
+  auto dma_stage = [&](int ks, int buf) {
+    const unsigned sa = smem_base + buf * STAGE_BYTES + wave * (8 * kRowBytes);  // LDS byte addresses
+    const unsigned sw = sa + BM * kRowBytes;
+    if (slow) {
+      // stride-2 data gradient: general gather
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        int ih, iw;
+        const bool ok = ((a_mask[i] >> nx_tap) & 1u) && tap_src(a_oh[i], a_ow[i], nx_kh, nx_kw, ih, iw);
+        const T* g = ok ? src + a_base[i] + (long long)ih * p.src_row_stride + (long long)iw * p.src_pix_stride +
+                              nx_c0 + chunk * (16 / (int)sizeof(T))
+                        : zero_src;
+        glds16(g, sa + i * (RG * kRowBytes));
+      }
     } else {
-      tap = ks / ksteps_per_tap;
-      c0 = (ks - tap * ksteps_per_tap) * BK;
-    }
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int ih, iw;
-      bool ok;
-      if (!DGRAD) {
-        ih = a_oh[i] * p.stride - p.pad + kh;
-        iw = a_ow[i] * p.stride - p.pad + kw;
-        ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      int tap;
+      long long toff;
+      if (sub) {  // two 64-byte taps per K-step (KW == 1): the tap depends on the lane's chunk
+        tap = ks * 2 + (chunk >> 2);
+        toff = (long long)tap * p.src_row_stride - (chunk >> 2) * (BK / 2);
       } else {
-        const int th = a_oh[i] + p.pad - kh, tw = a_ow[i] + p.pad - kw;
-        ok = th >= 0 && tw >= 0;
-        if (p.stride == 2) {
-          ok = ok && !((th | tw) & 1);
-          ih = th >> 1;
-          iw = tw >> 1;
-        } else {
-          ih = th;
-          iw = tw;
-        }
-        ok = ok && ih < p.IH && iw < p.IW;
+        tap = nx_tap;
+        toff = (long long)nx_kh * p.src_row_stride + (long long)nx_kw * p.src_pix_stride;
+        toff = (DGRAD ? -toff : toff) + nx_c0;
       }
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const T* g = src + a_base[i] + (long long)ih * p.src_row_stride +
-                     (long long)iw * p.src_pix_stride + c0 + chunk * (16 / (int)sizeof(T));
-        v = *reinterpret_cast<const uint4*>(g);
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const T* g = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + toff : zero_src;
+        glds16(g, sa + i * (RG * kRowBytes));
       }
-      ra[i] = v;
+    }
+    nx_c0 += BK;
+    if (nx_c0 >= p.KC) {
+      nx_c0 = 0;
+      ++nx_tap;
+      if (++nx_kw == p.KW) {
+        nx_kw = 0;
+        ++nx_kh;
+      }
     }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (w_ok[i]) v = *reinterpret_cast<const uint4*>(w_ptr[i] + (long long)ks * BK);
-      rw[i] = v;
-    }
-  };
-  auto store_stage = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE_BYTES;
-    unsigned char* sw = sa + BM * kRowBytes;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int r = rbase + 32 * i;
-      *reinterpret_cast<uint4*>(sa + r * kRowBytes + ((chunk ^ (r & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int r = rbase + 32 * i;
-      *reinterpret_cast<uint4*>(sw + r * kRowBytes + ((chunk ^ (r & 7)) << 4)) = rw[i];
+      const T* g = w_ok[i] ? w_ptr[i] + (long long)ks * BK : zero_src;
+      glds16(g, sw + i * (RG * kRowBytes));
     }
   };
 
@@ -195,12 +254,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   const int frow = lane & 15, fk = lane >> 4;
 
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
+  // NSTAGE-deep LDS ring.  Stage s lives in buffer s % NSTAGE; NSTAGE-1 stages are in
+  // flight.  Per K-step: wait until this wave's DMAs of stage ks have landed (counted
+  // vmcnt leaves the younger stages in flight), barrier (=> every wave's part of stage ks
+  // is visible and nobody still reads the buffer about to be refilled), issue stage
+  // ks+NSTAGE-1, then the MFMAs of stage ks.
+  constexpr int DPS = RA + RW;  // DMA instructions per wave per stage
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nk) dma_stage(s0, s0);
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_stage(ks + 1);
+    const int buf = ks % NSTAGE;
+    if (NSTAGE >= 3 && ks + NSTAGE - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (ks + NSTAGE - 1 < nk) dma_stage(ks + NSTAGE - 1, (ks + NSTAGE - 1) % NSTAGE);
     const unsigned char* sa = smem + buf * STAGE_BYTES;
     const unsigned char* sw = sa + BM * kRowBytes;
 #pragma unroll
@@ -208,12 +278,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       uint4 fw[TN], fa[TM];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const int r = wn * (BN / 2) + i * 16 + frow;
+        const int r = wn * (BN / WN) + i * 16 + frow;
         fw[i] = *reinterpret_cast<const uint4*>(sw + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        const int r = wm * (BM / 2) + j * 16 + frow;
+        const int r = wm * (BM / WM) + j * 16 + frow;
         fa[j] = *reinterpret_cast<const uint4*>(sa + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
       }
 #pragma unroll
@@ -221,9 +291,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[i], fa[j]);
     }
-    if (ks + 1 < nk) store_stage(buf ^ 1);
-    __syncthreads();
   }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all reads done before the epilogue reuses LDS
 
   // ---- epilogue: accumulators -> LDS f32 [BM][BN] (chunk-swizzled) -------------
   // lane holds channels n = 4*(lane>>4)+r of pixel (lane&15) for each 16x16 tile.
@@ -232,14 +301,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int pm = wm * (BM / 2) + j * 16 + frow;
-      const int c16 = (wn * (BN / 2) + i * 16 + fk * 4) >> 2;  // 16-byte chunk index
+      const int pm = wm * (BM / WM) + j * 16 + frow;
+      const int c16 = (wn * (BN / WN) + i * 16 + fk * 4) >> 2;  // 16-byte chunk index
       *reinterpret_cast<f32x4*>(smem + pm * ROWB + ((c16 ^ (pm & 7)) << 4)) = acc[i][j];
     }
   __syncthreads();
 
   constexpr int TPR = BN / 8;          // threads per pixel row (8 channels each)
-  constexpr int RPP = 256 / TPR;       // rows per pass
+  constexpr int RPP = NT / TPR;        // rows per pass
   constexpr int NPASS = BM / RPP;
   const int cg = tid % TPR, r0 = tid / TPR;
   const int nbase = n0 + cg * 8;
@@ -315,12 +384,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 }
 
-template <typename T, int BM, int BN, bool DGRAD>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int EPI = BM * BN * 4;
-  constexpr int LDS = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, DGRAD>;
+  constexpr int LDS = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, DGRAD>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -334,16 +404,30 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs args = a;
   args.gridM = qt_cdiv(a.M, BM);
   args.gridN = qt_cdiv(a.N, BN);
-  hipLaunchKernelGGL(kern, dim3(args.gridM * args.gridN), dim3(256), LDS, stream, args);
+  hipLaunchKernelGGL(kern, dim3(args.gridM * args.gridN), dim3(64 * WM * WN), LDS, stream, args);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
 
+// Tile selection.  Large pixel counts use 256-pixel tiles, 8 waves and a 3-deep ring
+// (one workgroup per CU); small ones (layer4, the classifier) keep 128-pixel tiles with
+// 4 waves and two workgroups per CU so that the grid still covers the chip.
+// Measured (B=256, bf16): the 256-pixel tile only wins for K-loops of >= 36 steps; the
+// per-CU L2->LDS rate (~70 GB/s) bounds both shapes, and the short-K layers are dominated
+// by the per-tile prologue / epilogue, where two resident workgroups overlap better.
+inline int tile_m(long long M, int N, int ksteps) { return (M >= 256 * 256 && ksteps >= 36 && N > 64) ? 256 : 128; }
+
+template <typename T, bool DGRAD>
+int dispatch2(const ConvArgs& a, hipStream_t stream) {
+  const int bm = tile_m(a.M, a.N, a.ntaps * a.KC * (int)sizeof(T) / kRowBytes);
+  if (a.N <= 64) return launch<T, 128, 64, 2, 2, 2, DGRAD>(a, stream);
+  if (bm == 256) return launch<T, 256, 128, 4, 2, 3, DGRAD>(a, stream);
+  return launch<T, 128, 128, 2, 2, 2, DGRAD>(a, stream);
+}
+
 template <typename T>
 int dispatch(const qt_conv_desc* d, const ConvArgs& a, hipStream_t stream) {
-  const bool dg = d->mode == QT_CONV_DGRAD;
-  if (a.N <= 64) return dg ? launch<T, 128, 64, true>(a, stream) : launch<T, 128, 64, false>(a, stream);
-  return dg ? launch<T, 128, 128, true>(a, stream) : launch<T, 128, 128, false>(a, stream);
+  return d->mode == QT_CONV_DGRAD ? dispatch2<T, true>(a, stream) : dispatch2<T, false>(a, stream);
 }
 
 }  // namespace
@@ -351,7 +435,8 @@ int dispatch(const qt_conv_desc* d, const ConvArgs& a, hipStream_t stream) {
 extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   if (!d) return QT_ERR_INVALID_ARG;
   const long long M = (long long)d->batch * (d->quad && d->mode == QT_CONV_FWD ? 4 : 1) * d->out_h * d->out_w;
-  return qt_cdiv(M, 128);
+  const int esz = d->dtype == QT_F32 ? 4 : 2;
+  return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
 }
 
 extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
@@ -369,6 +454,8 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG(d->kh > 0 && d->kw > 0 && (d->stride == 1 || d->stride == 2) && d->pad >= 0,
                "qt_conv2d_igemm: bad filter geometry kh=%d kw=%d stride=%d pad=%d", d->kh, d->kw, d->stride, d->pad);
   QT_CHECK_ARG(!(d->quad && d->stride != 1), "qt_conv2d_igemm: quadrant mode needs stride 1");
+  QT_CHECK_ARG(d->kh * d->kw <= 32, "qt_conv2d_igemm: at most 32 taps (kh*kw=%d)", d->kh * d->kw);
+  QT_CHECK_ARG(2 * d->k_per_tap != bk || d->kw == 1, "qt_conv2d_igemm: half-K-step taps need kw == 1");
   const int esz = d->dtype == QT_F32 ? 4 : 2;
   QT_CHECK_ARG(((uintptr_t)io->src % 16) == 0 && ((uintptr_t)io->weight % 16) == 0 && ((uintptr_t)io->dst % 16) == 0,
                "qt_conv2d_igemm: pointers must be 16-byte aligned");

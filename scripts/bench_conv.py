@@ -1,0 +1,67 @@
+"""Developer aid: time single launches of the MFMA kernels through the C ABI (GPU box)."""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _util import pkg
+L = pkg("_lib")
+dev = torch.device("cuda:0")
+
+def desc(dt, mode, B, H, Cin, Cout, k, s, p):
+    Ho = (H + 2 * p - k) // s + 1
+    d = L.ConvDesc(); d.dtype = L.qt_dtype(dt); d.mode = mode; d.batch = B
+    d.kh = d.kw = k; d.stride = s; d.pad = p
+    if mode == L.QT_CONV_FWD:
+        d.in_h = d.in_w = H; d.out_h = d.out_w = Ho; d.k_per_tap = Cin; d.n_out = Cout
+        d.src_pix_stride = Cin; d.src_row_stride = H * Cin; d.src_img_stride = H * H * Cin
+    else:
+        d.in_h = d.in_w = Ho; d.out_h = d.out_w = H; d.k_per_tap = Cout; d.n_out = Cin
+        d.src_pix_stride = Cout; d.src_row_stride = Ho * Cout; d.src_img_stride = Ho * Ho * Cout
+    return d, Ho
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+def bench(kind, B, H, Cin, Cout, k, s, p, dt=torch.bfloat16):
+    st = L.stream_ptr()
+    if kind == "wgrad":
+        d, Ho = desc(dt, L.QT_CONV_FWD, B, H, Cin, Cout, k, s, p)
+        x = torch.randn(B, H, H, Cin, device=dev).to(dt); dy = torch.randn(B, Ho, Ho, Cout, device=dev).to(dt)
+        dw = torch.zeros(Cout, k * k, Cin, device=dev)
+        fn = lambda: L.check(L.lib().qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dy), L.ptr(x), L.ptr(dw), st))
+    else:
+        mode = L.QT_CONV_FWD if kind == "fwd" else L.QT_CONV_DGRAD
+        d, Ho = desc(dt, mode, B, H, Cin, Cout, k, s, p)
+        if kind == "fwd":
+            x = torch.randn(B, H, H, Cin, device=dev).to(dt); w = torch.randn(Cout, k * k, Cin, device=dev).to(dt)
+            y = torch.empty(B * Ho * Ho, Cout, device=dev, dtype=dt)
+        else:
+            x = torch.randn(B, Ho, Ho, Cout, device=dev).to(dt); w = torch.randn(Cin, k * k, Cout, device=dev).to(dt)
+            y = torch.empty(B * H * H, Cin, device=dev, dtype=dt)
+        io = L.ConvIO(L.ptr(x), L.ptr(w), L.ptr(y), None, None, None, None, None)
+        fn = lambda: L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), st))
+    us = timeit(fn)
+    Ho = (H + 2 * p - k) // s + 1
+    fl = 2.0 * B * Ho * Ho * Cout * Cin * k * k
+    print(f"{kind:6s} B{B} H{H} {Cin:4d}->{Cout:4d} k{k} s{s}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+if __name__ == "__main__":
+    B = 256
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "ksweep"):
+        for cin in (64, 128, 256, 512):
+            bench("fwd", B, 28, cin, 128, 3, 1, 1)
+    if which in ("all", "layers"):
+        for kind in ("fwd", "dgrad", "wgrad"):
+            bench(kind, B, 56, 64, 64, 3, 1, 1)
+            bench(kind, B, 28, 128, 128, 3, 1, 1)
+            bench(kind, B, 14, 256, 256, 3, 1, 1)
+            bench(kind, B, 7, 512, 512, 3, 1, 1)
+            bench(kind, B, 56, 64, 128, 3, 2, 1)
+            bench(kind, B, 56, 64, 128, 1, 2, 0)
