@@ -43,28 +43,6 @@ struct ConvArgs {
 
 constexpr int kRowBytes = 128;  // bytes of K per row per K-step
 
-// 128 bytes of zeros: the LDS-DMA source of halo pixels and of rows past the tensor's end
-__device__ uint4 qt_zero_page[8];
-
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to the 1 KiB
-// at LDS byte address `lds_addr` (wave-uniform).  Issued from inline asm on purpose: the
-// compiler then neither counts it in vmcnt nor fences later LDS reads with vmcnt(0), so
-// the ring below can keep stages in flight across barriers with counted waits (the
-// kernel's own s_waitcnt vmcnt(N) + s_barrier order the data before it is read).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_addr)
-      : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)p);
-}
-
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
   constexpr int NT = 64 * WM * WN;   // threads

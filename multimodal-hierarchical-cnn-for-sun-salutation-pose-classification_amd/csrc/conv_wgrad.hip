@@ -59,9 +59,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int BNWP = STEM ? 256 : BNW;       // padded X tile width (elements)
   constexpr int RBB = BNWP * ES;
   constexpr int NBB = RBB / 32;
-  constexpr int CPA = RBA / 16, CPB = (BNW * ES) / 16;  // 16-byte chunks per row actually loaded
-  constexpr int LA = (KP * CPA) / 256;         // dY chunks per thread per step
-  constexpr int LB = (KP * CPB + 255) / 256;   // X chunks per thread per step
+  constexpr int CPRA = RBA / 16, CPRB = RBB / 16;  // 16-byte LDS slots per row
+  constexpr int CPB = (BNW * ES) / 16;             // slots of an X row that carry data
+  constexpr int LA = (KP * CPRA) / 256;            // dY DMA instructions per wave per step
+  constexpr int LB = (KP * CPRB) / 256;            // X DMA instructions per wave per step
   constexpr int STAGE = KP * (RBA + RBB);
   constexpr int TMW = BMW / 32, TNW = BNW / 32;
   static_assert(NBA == 4 || NBA == 8 || NBA == 16, "dY row must be 128/256/512 bytes");
@@ -85,25 +86,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
   auto key = [](int row, int nblk) { return nblk >= 8 ? (row & 7) : ((row >> 1) & 3); };
 
-  uint4 ra[LA], rb[LB];
-  auto load_stage = [&](int ks) {
+  // LDS-DMA staging (see conv_igemm.hip): thread = (row in pass, 16-byte LDS slot); the
+  // 32-byte-block swizzle sits on the source side, slot s of row r holds source chunk
+  // (((s>>1) ^ key(r)) << 1) | (s & 1).  Rows advance by a multiple of 8 per pass, so the
+  // source chunk of a thread is fixed.
+  constexpr int RPA = 256 / CPRA, RPB = 256 / CPRB;  // rows per pass
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sA = tid % CPRA, rA = tid / CPRA, sB = tid % CPRB, rB = tid / CPRB;
+  const int cA = (((sA >> 1) ^ key(rA, NBA)) << 1) | (sA & 1);
+  const bool a_col_ok = n0 + cA * EPC < p.N;
+  // X rows: the source chunk is fixed per thread when a pass covers a multiple of 8 rows,
+  // otherwise (f32 stem: 4 rows per pass) it is recomputed per pass from the row's key
+  auto b_chunk = [&](int row) { return (((sB >> 1) ^ key(row, NBB)) << 1) | (sB & 1); };
+  auto b_chunk_off = [&](int cB, bool& ok) -> long long {
+    if (STEM) {
+      ok = cB < CPB;
+      const int v0 = cB * EPC;  // virtual channel: (tap row, element)
+      return (long long)(v0 / p.KC) * p.tap_stride + (v0 % p.KC);
+    }
+    ok = cB < CPB && c0 + cB * EPC < p.KC;
+    return c0 + cB * EPC;
+  };
+  bool b_col_ok;
+  long long b_coff = b_chunk_off(b_chunk(rB), b_col_ok);
+  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
+  const unsigned smem_base = lds_addr_of(smem);
+  auto dma_stage = [&](int ks, int buf) {
     const int pb = pbeg + ks * KP;
+    const unsigned sa = smem_base + buf * STAGE + wave_u * 1024;
+    const unsigned sb = sa + KP * RBA;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int id = tid + 256 * i;
-      const int r = id / CPA, c = id - r * CPA;
-      const int m = pb + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < pend && n0 + c * EPC < p.N) v = *reinterpret_cast<const uint4*>(dy + (long long)m * p.N + n0 + c * EPC);
-      ra[i] = v;
+      const int m = pb + i * RPA + rA;
+      const T* g = (m < pend && a_col_ok) ? dy + (long long)m * p.N + n0 + cA * EPC : zero_src;
+      glds16(g, sa + i * (RPA * RBA));
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      const int id = tid + 256 * i;
-      const int r = id / CPB, c = id - r * CPB;
-      const int m = pb + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (r < KP && m < pend) {
+      const int m = pb + i * RPB + rB;
+      const T* g = zero_src;
+      if (RPB % 8 != 0) b_coff = b_chunk_off(b_chunk(i * RPB + rB), b_col_ok);
+      if (m < pend && b_col_ok) {
         unsigned img = fdiv((unsigned)m, p.div_ohw);
         unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
         unsigned oh = fdiv(rem, p.div_ow);
@@ -118,35 +141,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
         const int ih = (int)oh * p.stride - p.pad + kh;
         const int iw = (int)ow * p.stride - p.pad + kw;
-        if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
-          long long off = base + (long long)ih * p.x_row_stride + (long long)iw * p.x_pix_stride;
-          if (STEM) {
-            const int v0 = c * EPC;  // virtual channel: (tap row, element)
-            off += (long long)(v0 / p.KC) * p.tap_stride + (v0 % p.KC);
-            v = *reinterpret_cast<const uint4*>(x + off);
-          } else if (c0 + c * EPC < p.KC) {
-            v = *reinterpret_cast<const uint4*>(x + off + c0 + c * EPC);
-          }
-        }
+        if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+          g = x + base + (long long)ih * p.x_row_stride + (long long)iw * p.x_pix_stride + b_coff;
       }
-      rb[i] = v;
-    }
-  };
-  auto store_stage = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE;
-    unsigned char* sb = sa + KP * RBA;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      const int id = tid + 256 * i;
-      const int r = id / CPA, c = id - r * CPA;
-      *reinterpret_cast<uint4*>(sa + r * RBA + ((((c >> 1) ^ key(r, NBA)) << 5) | ((c & 1) << 4))) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      const int id = tid + 256 * i;
-      const int r = id / CPB, c = id - r * CPB;
-      if (r < KP)
-        *reinterpret_cast<uint4*>(sb + r * RBB + ((((c >> 1) ^ key(r, NBB)) << 5) | ((c & 1) << 4))) = rb[i];
+      glds16(g, sb + i * (RPB * RBB));
     }
   };
 
@@ -158,14 +156,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
   const int li = lane & 15, lg = lane >> 4;
 
-  if (nsteps > 0) {
-    load_stage(0);
-    store_stage(0);
-  }
-  __syncthreads();
+  if (nsteps > 0) dma_stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   for (int ks = 0; ks < nsteps; ++ks) {
     const int buf = ks & 1;
-    if (ks + 1 < nsteps) load_stage(ks + 1);
+    if (ks + 1 < nsteps) dma_stage(ks + 1, buf ^ 1);
     const unsigned char* sa = smem + buf * STAGE;
     const unsigned char* sb = sa + KP * RBA;
     if constexpr (sizeof(T) == 2) {
@@ -226,8 +221,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (ks + 1 < nsteps) store_stage(buf ^ 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
   // ---- accumulate: lane holds rows n = 4*lg + r, column c = li of each tile ----
@@ -275,7 +269,9 @@ int launch(WgradArgs a, hipStream_t stream) {
   a.tilesC = STEM ? 1 : qt_cdiv(a.KC, BNW);
   const int gtaps = STEM ? 1 : a.ntaps;
   const int base_blocks = a.tilesN * a.tilesC * gtaps;
-  int ksplit = qt_cdiv(1536, base_blocks);
+  // every workgroup ends with tile-sized f32 atomics (chip-wide ~1.3 TB/s): keep the grid at
+  // about two workgroups per CU instead of maximising the split
+  int ksplit = qt_cdiv(512, base_blocks);
   const int max_split = qt_cdiv(a.M, KP * 4);
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;

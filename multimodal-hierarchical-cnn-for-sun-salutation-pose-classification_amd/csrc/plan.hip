@@ -375,12 +375,12 @@ struct Exec {
     if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
     t.flops = flops;
     t.kind = kind;
-    hipEventRecord(t.a, static_cast<hipStream_t>(stream));
+    (void)hipEventRecord(t.a, static_cast<hipStream_t>(stream));
     p->timed.push_back(t);
     return (int)p->timed.size() - 1;
   }
   void end_timed(int slot) {
-    if (slot >= 0) hipEventRecord(p->timed[slot].b, static_cast<hipStream_t>(stream));
+    if (slot >= 0) (void)hipEventRecord(p->timed[slot].b, static_cast<hipStream_t>(stream));
   }
 
   long long rows_of(const ConvL& c) const { return (long long)B * c.hout * c.hout; }
@@ -799,7 +799,7 @@ extern "C" int qt_plan_find_buffer(const qt_plan* p, const char* name, size_t* o
 // ---- per-launch MFMA kernel timing (kinds: 0 igemm forward, 1 igemm dgrad, 2 wgrad) ----
 extern "C" int qt_plan_profile_begin(qt_plan* p) {
   QT_CHECK_ARG(p, "qt_plan_profile_begin: null plan");
-  for (auto& t : p->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   p->timed.clear();
   p->profiling = true;
   return QT_OK;
@@ -819,7 +819,7 @@ extern "C" int qt_plan_profile_end(qt_plan* p, double* flops, double* ms, int* l
     } else if (t.kind >= 0 && t.kind < 3) {
       flops[t.kind] += t.flops; ms[t.kind] += dt; launches[t.kind] += 1;
     }
-    hipEventDestroy(t.a); hipEventDestroy(t.b);
+    (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
   }
   p->timed.clear();
   return st;
