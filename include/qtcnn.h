@@ -68,6 +68,11 @@ typedef struct qt_conv_desc {
                 images with zero halo at the seam (models.py:277-287); DGRAD scatters
                 the per-quadrant gradient images back onto the un-split map */
   int relu;
+  /* optional strided destination (0 = dense [M][n_out]): row (img, oh, ow) is written to pixel
+   * (oh*dst_sub + dst_off_h, ow*dst_sub + dst_off_w) of a dst_h x dst_w image; residual and
+   * relu_mask are read at the same place.  Used to run the data gradient of a stride-2 conv as
+   * four stride-1 gathers, one per output-pixel parity class (qt_pack_dgrad_s2). */
+  int dst_sub, dst_h, dst_w, dst_off_h, dst_off_w;
 } qt_conv_desc;
 
 typedef struct qt_conv_io {
@@ -107,6 +112,13 @@ int qt_pack_stem_input(int dtype, const float* image_nchw, void* dst, int batch,
  * and/or [I][kh][kw][O] (w_dgrad); either may be NULL.  Linear layers: kh=kw=1. */
 int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int O, int I, int kh, int kw,
                         void* stream);
+/* Data-gradient operand of a stride-2 conv (k = 3 pad 1, or k = 1 pad 0) split by the parity
+ * (ph, pw) of the input pixel: class c = ph*2+pw gets [I][taps_c][O] with only the taps that
+ * reach it (k=3: 1,2,2,4 taps; k=1: 1,0,0,0), stored back to back in class order.  Row taps of
+ * class parity 0: {1}; parity 1: {2, 0} (source row i, i+1).  Element offsets of the four
+ * classes are returned in class_offset[4], tap grid in class_kh[4] / class_kw[4] (host arrays). */
+int qt_pack_dgrad_s2(int dtype, const float* w_oihw, void* dst, int O, int I, int k, long long* class_offset,
+                     int* class_kh, int* class_kw, void* stream);
 /* [64][3][7][7] -> [64][taps][8][4] for the packed stem; taps = 7, or 8 (8th row zero)
  * when a 32-element tap is only half a K-step (bf16: desc.kh = 8) */
 int qt_pack_stem_weight(int dtype, const float* w_oihw, void* dst, int taps, void* stream);

@@ -30,6 +30,8 @@ class ConvDesc(ctypes.Structure):
         ("src_img_stride", ctypes.c_longlong),
         ("src_row_stride", ctypes.c_int), ("src_pix_stride", ctypes.c_int),
         ("quad", ctypes.c_int), ("relu", ctypes.c_int),
+        ("dst_sub", ctypes.c_int), ("dst_h", ctypes.c_int), ("dst_w", ctypes.c_int),
+        ("dst_off_h", ctypes.c_int), ("dst_off_w", ctypes.c_int),
     ]
 
 

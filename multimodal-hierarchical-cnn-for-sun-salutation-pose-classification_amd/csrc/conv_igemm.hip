@@ -39,6 +39,10 @@ struct ConvArgs {
   int quad;
   int relu;
   int gridM, gridN;
+  // destination row mapping (0 = dense): row m = (img, oh, ow) of the OHxOW grid is written to
+  // pixel (oh*dst_sub + dst_oh, ow*dst_sub + dst_ow) of a dst_h x dst_w image
+  int dst_sub, dst_h, dst_w, dst_oh, dst_ow;
+  FastDiv div_ohw, div_ow;
 };
 
 constexpr int kRowBytes = 128;  // bytes of K per row per K-step
@@ -311,7 +315,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg + 1) ^ (r & 7)) << 4));
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if (m < p.M && n_ok) {
-      const long long off = (long long)m * p.N + nbase;
+      long long drow = m;
+      if (p.dst_sub) {
+        const unsigned img = fdiv((unsigned)m, p.div_ohw);
+        const unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
+        const unsigned oh = fdiv(rem, p.div_ow);
+        const unsigned ow = rem - oh * (unsigned)p.OW;
+        drow = ((long long)img * p.dst_h + oh * p.dst_sub + p.dst_oh) * p.dst_w + ow * p.dst_sub + p.dst_ow;
+      }
+      const long long off = drow * p.N + nbase;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         s1[e] += v[e];
@@ -460,6 +472,13 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw;
   a.stride = d->stride; a.pad = d->pad; a.quad = d->quad; a.relu = d->relu;
   a.gridM = a.gridN = 0;
+  a.dst_sub = d->dst_sub; a.dst_h = d->dst_h; a.dst_w = d->dst_w; a.dst_oh = d->dst_off_h; a.dst_ow = d->dst_off_w;
+  a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
+  a.div_ow = make_fastdiv((unsigned)d->out_w);
+  QT_CHECK_ARG(d->dst_sub == 0 || (d->dst_sub >= 1 && d->dst_h > 0 && d->dst_w > 0 && !io->stats_partial &&
+                                   (d->out_h - 1) * d->dst_sub + d->dst_off_h < d->dst_h &&
+                                   (d->out_w - 1) * d->dst_sub + d->dst_off_w < d->dst_w),
+               "qt_conv2d_igemm: bad destination mapping");
   hipStream_t s = static_cast<hipStream_t>(stream);
   return d->dtype == QT_F32 ? dispatch<float>(d, a, s) : dispatch<bf16_t>(d, a, s);
 }

@@ -18,21 +18,6 @@
 
 namespace {
 
-struct FastDiv {
-  unsigned mul, shr;
-};
-inline FastDiv make_fastdiv(unsigned d) {
-  FastDiv f;
-  unsigned s = 0;
-  while ((1ull << s) < d) ++s;
-  f.shr = s;
-  f.mul = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
-  return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
-  return (__umulhi(n, f.mul) + n) >> f.shr;  // exact for n < 2^31
-}
-
 struct WgradArgs {
   const void* dy;   // [M][N]
   const void* x;    // source activations

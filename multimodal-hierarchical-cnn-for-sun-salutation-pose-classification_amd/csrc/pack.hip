@@ -69,6 +69,30 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restri
   dst[idx] = qt_from_f32<T>(v);
 }
 
+// class-wise data-gradient operand of a stride-2 conv: dst[class][i][tap'][o]
+template <typename T>
+__global__ void pack_dgrad_s2_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int k) {
+  // taps per parity: k=3 -> {1} / {2,0};  k=1 -> {0} / {}
+  const int n0 = 1, n1 = k == 3 ? 2 : 0;
+  long long base = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    const int nh = ph ? n1 : n0, nw = pw ? n1 : n0;
+    const long long total = (long long)I * nh * nw * O;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+      const int o = (int)(idx % O);
+      const int t = (int)((idx / O) % (nh * nw));
+      const int i = (int)(idx / ((long long)O * nh * nw));
+      const int th = t / nw, tw = t - th * nw;
+      const int kh = k == 1 ? 0 : (ph ? (th == 0 ? 2 : 0) : 1);
+      const int kw = k == 1 ? 0 : (pw ? (tw == 0 ? 2 : 0) : 1);
+      dst[base + idx] = qt_from_f32<T>(w[(((long long)o * I + i) * k + kh) * k + kw]);
+    }
+    base += total;
+  }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ grad, int O, int I, int taps,
                                     int accumulate) {
   const long long total = (long long)O * I * taps;
@@ -124,6 +148,31 @@ extern "C" int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, 
   else
     hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw,
                        static_cast<bf16_t*>(w_fwd), static_cast<bf16_t*>(w_dgrad), O, I, kh * kw);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pack_dgrad_s2(int dtype, const float* w_oihw, void* dst, int O, int I, int k, long long* class_offset,
+                                int* class_kh, int* class_kw, void* stream) {
+  QT_CHECK_ARG(w_oihw && O > 0 && I > 0 && (k == 1 || k == 3), "qt_pack_dgrad_s2: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pack_dgrad_s2: bad dtype %d", dtype);
+  long long base = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int nh = (cls >> 1) ? (k == 3 ? 2 : 0) : 1, nw = (cls & 1) ? (k == 3 ? 2 : 0) : 1;
+    if (class_offset) class_offset[cls] = base;
+    if (class_kh) class_kh[cls] = nh;
+    if (class_kw) class_kw[cls] = nw;
+    base += (long long)I * nh * nw * O;
+  }
+  if (!dst) return QT_OK;  // layout query only
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long total = (long long)O * I * k * k;
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(pack_dgrad_s2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw,
+                       static_cast<float*>(dst), O, I, k);
+  else
+    hipLaunchKernelGGL(pack_dgrad_s2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw,
+                       static_cast<bf16_t*>(dst), O, I, k);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

@@ -40,6 +40,9 @@ struct ConvL {
   int bn;  // -1 if none
   size_t w_fwd, w_dgrad, dw;
   size_t y, gy;
+  // stride-2 data gradient as four parity-class gathers (qt_pack_dgrad_s2)
+  long long cls_off[4];
+  int cls_kh[4], cls_kw[4];
 };
 
 struct Block {
@@ -228,6 +231,9 @@ void layout_workspace(qt_plan* p) {
   for (size_t i = 0; i < p->convs.size(); ++i) {
     ConvL& c = p->convs[i];
     const size_t n = (i == 0) ? (size_t)64 * 8 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
+    if (i > 0 && c.stride == 2)
+      qt_pack_dgrad_s2(p->d.dtype, reinterpret_cast<const float*>(8), nullptr, c.cout, c.cin, c.k, c.cls_off, c.cls_kh,
+                       c.cls_kw, nullptr);
     c.w_fwd = ws.take(n * es);
     c.w_dgrad = ws.take(n * es);
     c.dw = ws.take(n * 4);
@@ -350,12 +356,12 @@ struct Exec {
   }
 
   void igemm(const qt_conv_desc& d, const void* src, const void* w, void* dst, const float* scale, const float* shift,
-             const void* res, const void* mask, float* stats, int relu) {
+             const void* res, const void* mask, float* stats, int relu, int kind = -1) {
     if (!ok()) return;
     qt_conv_desc dd = d;
     dd.relu = relu;
     qt_conv_io io = {src, w, dst, scale, shift, res, mask, stats};
-    const int slot = begin_timed(conv_flops(d), d.mode == QT_CONV_FWD ? 0 : 1);
+    const int slot = begin_timed(conv_flops(d), kind >= 0 ? kind : (d.mode == QT_CONV_FWD ? 0 : 1));
     run(qt_conv2d_igemm(&dd, &io, stream));
     end_timed(slot);
   }
@@ -410,8 +416,11 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
       if (i == 0) {
         e.run(qt_pack_stem_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), e.stem_taps(), stream));
       } else {
-        e.run(qt_pack_conv_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout,
-                                  c.cin, c.k, c.k, stream));
+        const bool s2 = c.stride == 2;
+        e.run(qt_pack_conv_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), (for_backward && !s2) ? e.at(c.w_dgrad) : nullptr,
+                                  c.cout, c.cin, c.k, c.k, stream));
+        if (for_backward && s2)
+          e.run(qt_pack_dgrad_s2(e.dt, e.tf(c.w), e.at(c.w_dgrad), c.cout, c.cin, c.k, nullptr, nullptr, nullptr, stream));
       }
     }
   }
@@ -560,6 +569,38 @@ struct Bwd : Exec {
     run(qt_bn_bwd_apply(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.coef),
                         at(c.gy), g_out, M, bn.C, stream));
   }
+  // data gradient of conv c: dst = conv_transpose(c.gy) (+resid) (* (mask > 0)).  A stride-2
+  // conv is run as four stride-1 gathers, one per parity class of the destination pixel, so no
+  // MFMA work is spent on taps that cannot reach a pixel (a dense gather would waste 3/4).
+  void dgrad(const ConvL& c, void* dst, const void* resid, const void* mask) {
+    if (c.stride == 1) {
+      igemm(conv_desc(c, QT_CONV_DGRAD), at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0);
+      return;
+    }
+    bool empty_class = false;
+    for (int cls = 0; cls < 4; ++cls) empty_class |= c.cls_kh[cls] * c.cls_kw[cls] == 0;
+    if (empty_class) {  // 1x1 stride 2: three of four pixels receive nothing from the conv
+      if (resid || mask) {
+        status = QT_ERR_UNSUPPORTED;
+        qt_set_error("dgrad: 1x1 stride-2 with residual/mask is not wired");
+        return;
+      }
+      run(zero(dst, (size_t)B * c.hin * c.hin * c.cin * p->esz, stream));
+    }
+    for (int cls = 0; cls < 4 && ok(); ++cls) {
+      if (c.cls_kh[cls] * c.cls_kw[cls] == 0) continue;
+      qt_conv_desc d;
+      memset(&d, 0, sizeof(d));
+      d.dtype = dt; d.mode = QT_CONV_FWD; d.batch = B;
+      d.in_h = d.in_w = c.hout; d.out_h = d.out_w = c.hin / 2;
+      d.k_per_tap = c.cout; d.n_out = c.cin;
+      d.kh = c.cls_kh[cls]; d.kw = c.cls_kw[cls]; d.stride = 1; d.pad = 0;
+      d.src_pix_stride = c.cout; d.src_row_stride = c.hout * c.cout; d.src_img_stride = (long long)c.hout * c.hout * c.cout;
+      d.dst_sub = 2; d.dst_h = d.dst_w = c.hin; d.dst_off_h = cls >> 1; d.dst_off_w = cls & 1;
+      igemm(d, at(c.gy), at<unsigned char>(c.w_dgrad) + (size_t)c.cls_off[cls] * p->esz, dst, nullptr, nullptr, resid,
+            mask, nullptr, 0, 1);
+    }
+  }
   // weight gradient of conv c: dy = c.gy, x = src
   void wgrad(const ConvL& c, const qt_conv_desc& fwd_desc, const void* src, bool stem) {
     if (!ok() || !gf(c.w)) return;
@@ -697,8 +738,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         const ConvL& cd = p->convs[blk.ds];
         e.bn_backward(cd, e.at(blk.gout), nullptr);
         e.wgrad(cd, e.conv_desc(cd, QT_CONV_FWD), e.at(x), false);
-        e.igemm(e.conv_desc(cd, QT_CONV_DGRAD), e.at(cd.gy), e.at(cd.w_dgrad), e.at(blk.gtmp), nullptr, nullptr,
-                nullptr, nullptr, nullptr, 0);
+        e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr);
         resid = e.at(blk.gtmp);
       }
       if (bi == 6 && !p->standard) {
@@ -709,8 +749,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       }
       void* gprev = bi == 0 ? e.at(p->g_p0) : e.at(p->blocks[bi - 1].gout);
       const void* mask = bi == 0 ? nullptr : e.at(x);
-      e.igemm(e.conv_desc(c1, QT_CONV_DGRAD), e.at(c1.gy), e.at(c1.w_dgrad), gprev, nullptr, nullptr, resid, mask,
-              nullptr, 0);
+      e.dgrad(c1, gprev, resid, mask);
     }
     // ---- stem ----
     const ConvL& c0 = p->convs[0];

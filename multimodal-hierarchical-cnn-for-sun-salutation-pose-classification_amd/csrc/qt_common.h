@@ -130,4 +130,21 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 }
 
 
+// exact unsigned division by a runtime constant (n < 2^31): q = (umulhi(n, mul) + n) >> shr
+struct FastDiv {
+  unsigned mul, shr;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
+  return (__umulhi(n, f.mul) + n) >> f.shr;  // exact for n < 2^31
+}
+
+
 static inline int qt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

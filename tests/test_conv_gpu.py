@@ -234,3 +234,51 @@ def test_quadrant_wgrad(dt):
                    strides=(14 * 14 * C, 14 * C, C))
     got = dw.cpu().view(N, 3, 3, C).permute(0, 3, 1, 2)
     assert rel_err(got, ref) <= 3e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 56, 3), (2, 128, 256, 28, 1), (3, 256, 512, 14, 3)])
+def test_stride2_dgrad_by_parity_classes(dt, cfg):
+    """Data gradient of a stride-2 conv as four stride-1 gathers with a strided destination."""
+    dev = _dev()
+    L = pkg("_lib")
+    B, Cin, Cout, H, k = cfg
+    p = 1 if k == 3 else 0
+    Ho = (H + 2 * p - k) // 2 + 1
+    g = torch.Generator().manual_seed(6)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cout * k * k)) ** 0.5).to(dt).float()
+    dy = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    other = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    act = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    ref = (torch.nn.grad.conv2d_input((B, Cin, H, H), w, dy, 2, p) + other) * (act > 0)
+
+    lib = L.lib()
+    offs, khs, kws = (ctypes.c_longlong * 4)(), (ctypes.c_int * 4)(), (ctypes.c_int * 4)()
+    wd = torch.empty(Cout * Cin * k * k, dtype=dt, device=dev)
+    wsrc = w.to(dev)
+    L.check(lib.qt_pack_dgrad_s2(L.qt_dtype(dt), L.ptr(wsrc), L.ptr(wd), Cout, Cin, k, offs, khs, kws, L.stream_ptr()),
+            "qt_pack_dgrad_s2")
+    dyd = nhwc(dy).to(dev, dt)
+    out = torch.zeros(B * H * H, Cin, dtype=dt, device=dev)
+    res = nhwc(other).to(dev, dt).view(-1, Cin)
+    msk = nhwc(act).to(dev, dt).view(-1, Cin)
+    esz = 2 if dt == torch.bfloat16 else 4
+    for cls in range(4):
+        if khs[cls] * kws[cls] == 0:
+            continue
+        d = L.ConvDesc()
+        d.dtype, d.mode, d.batch = L.qt_dtype(dt), L.QT_CONV_FWD, B
+        d.in_h = d.in_w = Ho
+        d.out_h = d.out_w = H // 2
+        d.k_per_tap, d.n_out = Cout, Cin
+        d.kh, d.kw, d.stride, d.pad = khs[cls], kws[cls], 1, 0
+        d.src_img_stride, d.src_row_stride, d.src_pix_stride = Ho * Ho * Cout, Ho * Cout, Cout
+        d.dst_sub, d.dst_h, d.dst_w, d.dst_off_h, d.dst_off_w = 2, H, H, cls >> 1, cls & 1
+        io = L.ConvIO(L.ptr(dyd), ctypes.c_void_p(wd.data_ptr() + offs[cls] * esz), L.ptr(out), None, None,
+                      L.ptr(res), L.ptr(msk), None)
+        L.check(lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()), "qt_conv2d_igemm")
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(B, H, H, Cin).permute(0, 3, 1, 2)
+    if k == 1:  # pixels no tap reaches were never written: only class (0,0) is defined
+        got, ref = got[:, :, ::2, ::2], ref[:, :, ::2, ::2]
+    assert rel_err(got, ref) <= TOL[dt]
