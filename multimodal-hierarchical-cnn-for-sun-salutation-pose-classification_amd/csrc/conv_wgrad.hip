@@ -28,7 +28,7 @@ struct WgradArgs {
   int OH, OW, IH, IW;
   int ntaps, KW, stride, pad;
   int quad;
-  int tilesN, tilesC, ksplit, pix_per_split;
+  int tilesN, tilesC, gtaps, ksplit, pix_per_split;
   int tap_stride;   // STEM: element distance between virtual taps (rows of the padded image)
   FastDiv div_ohw, div_ow;
 };
@@ -58,8 +58,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
 
-  int bid = blockIdx.x;
-  const int split = bid % p.ksplit; bid /= p.ksplit;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so XCD x runs block ids
+  // x, x+8, ...  Give each XCD whole pixel splits and run all (tap, tile) members of a split
+  // back to back on it: the 9 taps re-read the same dY / X rows from that XCD's L2.
+  // (only when the split count is a multiple of 8; few-split shapes keep the linear order.)
+  const int members = p.tilesN * p.tilesC * p.gtaps;
+  int split, bid;
+  if ((p.ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / members) * 8 + xcd;
+    bid = slot % members;
+  } else {
+    split = blockIdx.x % p.ksplit;
+    bid = blockIdx.x / p.ksplit;
+  }
   const int tc = bid % p.tilesC; bid /= p.tilesC;
   const int tn = bid % p.tilesN; bid /= p.tilesN;
   const int tap = bid;
@@ -260,10 +272,13 @@ int launch(WgradArgs a, hipStream_t stream) {
   const int max_split = qt_cdiv(a.M, KP * 4);
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
+  if (ksplit >= 6) ksplit = qt_cdiv(ksplit, 8) * 8;  // whole splits per XCD (see the kernel)
   int pps = qt_cdiv(a.M, ksplit);
   pps = qt_cdiv(pps, KP) * KP;
   a.ksplit = qt_cdiv(a.M, pps);
+  if (a.ksplit >= 6 && (a.ksplit & 7)) a.ksplit = qt_cdiv(a.ksplit, 8) * 8;  // empty tail splits exit at once
   a.pix_per_split = pps;
+  a.gtaps = gtaps;
   hipLaunchKernelGGL(kern, dim3(base_blocks * a.ksplit), dim3(256), LDS, stream, a);
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -290,7 +305,7 @@ extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void
   a.tap_stride = d->src_row_stride;
   a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
   a.div_ow = make_fastdiv((unsigned)d->out_w);
-  a.tilesN = a.tilesC = a.ksplit = a.pix_per_split = 0;
+  a.tilesN = a.tilesC = a.gtaps = a.ksplit = a.pix_per_split = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
   const bool stem = d->k_per_tap == 32 && d->kw == 1 && d->kh == 7 && d->n_out == 64;
