@@ -72,6 +72,10 @@ class PlanEngine:
         self.dtype = dtype
         self.max_batch = int(batch)
         self.num_classes = num_classes
+        if model_kind == QT_MODEL_STANDARD_RESNET:
+            self.fused_ld = 512
+        else:
+            self.fused_ld = {"fusion": 5376, "image_only": 5120, "numerical_only": 256}.get(mode, 5376)
         desc = PlanDesc(_lib.qt_dtype(dtype), self.max_batch, num_classes, model_kind, MODES.get(mode, 0),
                         numerical_dim, float(dropout_p), 1e-5, 0.1)
         handle = ctypes.c_void_p()
@@ -113,6 +117,12 @@ class PlanEngine:
         base = (self.ws_ptr.value - self.workspace.data_ptr()) + off.value
         n = int(torch.Size(shape).numel()) * (2 if self.dtype == torch.bfloat16 else 4)
         return self.workspace[base:base + n].view(self.dtype).view(shape)
+
+    def buffer_ld(self, name):
+        """Row length (elements) of the fused feature matrix / its gradient."""
+        if name in ("fused", "dfused"):
+            return self.fused_ld
+        raise QtError(f"no leading dimension known for {name}")
 
     # -- binding --------------------------------------------------------------
     def bind(self, tensors):
@@ -196,6 +206,7 @@ class PlanFunction(torch.autograd.Function):
         ctx.numerical = numerical
         ctx.param_index = owner._param_plan_index
         ctx.param_shapes = [tuple(p.shape) for p in params]
+        owner._fire_layer4_forward_hooks(engine, logits.shape[0])
         return logits
 
     @staticmethod
@@ -208,6 +219,7 @@ class PlanFunction(torch.autograd.Function):
         wanted = [(ctx.param_index[i], ctx.param_shapes[i]) for i, need in enumerate(needs)
                   if need and ctx.param_index[i] >= 0]
         grads = engine.backward(dlogits.contiguous().float(), ctx.numerical, wanted)
+        ctx.owner._fire_layer4_backward_hooks(engine, dlogits.shape[0])
         out, k = [], 0
         for i, need in enumerate(needs):
             if need and ctx.param_index[i] >= 0:

@@ -67,6 +67,40 @@ class _PlanModel(nn.Module):
                 -1 if n.startswith("base_cnn.fc.") else eng.index.get(n, -1) for n, _ in named]
         return sum(p._version for p in self._param_list)
 
+    # ---- Grad-CAM compatibility (reference: resnet/grad_cam_analysis.py:251-259,286,306-316;
+    # Quadtree_from scratch/grad_cam.py:72-83).  The reference registers a forward hook and a
+    # full backward hook on `model.base_cnn.layer4`.  The fused plan never calls that module, so
+    # the hooks are served from the plan's buffers with the tensors torch would have passed:
+    # output [B,512,7,7] f32 NCHW, grad_output[0] = d(loss)/d(layer4 output).
+    def _layer4_nchw(self, engine, batch, name):
+        t = engine.buffer(name, (engine.max_batch * 49, 512))[:batch * 49]
+        return t.float().view(batch, 7, 7, 512).permute(0, 3, 1, 2).contiguous()
+
+    def _fire_layer4_forward_hooks(self, engine, batch):
+        layer4 = self.base_cnn.layer4
+        if not layer4._forward_hooks or self._plan_mode() == "numerical_only":
+            return
+        out = self._layer4_nchw(engine, batch, "block7.out")
+        inp = self._layer4_nchw_in(engine, batch)
+        for hook in list(layer4._forward_hooks.values()):
+            hook(layer4, (inp,), out)
+
+    def _layer4_nchw_in(self, engine, batch):
+        t = engine.buffer("block5.out", (engine.max_batch * 196, 256))[:batch * 196]
+        return t.float().view(batch, 14, 14, 256).permute(0, 3, 1, 2).contiguous()
+
+    def _fire_layer4_backward_hooks(self, engine, batch):
+        layer4 = self.base_cnn.layer4
+        if not layer4._backward_hooks or self._plan_mode() == "numerical_only":
+            return
+        # layer4's output only feeds AdaptiveAvgPool2d(1,1): its gradient is dfused[:, :512] / 49
+        # broadcast over the 7x7 positions
+        ld = engine.buffer_ld("dfused")
+        d = engine.buffer("dfused", (engine.max_batch, ld))[:batch, :512].float() / 49.0
+        g = d.view(batch, 512, 1, 1).expand(batch, 512, 7, 7).contiguous()
+        for hook in list(layer4._backward_hooks.values()):
+            hook(layer4, (None,), (g,))
+
     def _run(self, image_input, numerical_input):
         ref = image_input if image_input is not None else numerical_input
         device = ref.device

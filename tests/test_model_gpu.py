@@ -150,3 +150,36 @@ def test_cpu_tensors_are_rejected_loudly():
     m = build("quadtree", torch.float32)
     with pytest.raises(pkg().QtError):
         m(torch.zeros(1, 3, 224, 224), torch.zeros(1, 47))
+
+
+def test_gradcam_hooks_on_layer4_match_oracle():
+    """The reference's Grad-CAM recipe (resnet/grad_cam_analysis.py:243-316): eval(), forward hook +
+    full backward hook on model.base_cnn.layer4, one-hot backward.  Frozen-backbone variant."""
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    m = build("quadtree", torch.float32, frozen=True).to(dev).eval()
+    h1 = m.base_cnn.layer4.register_forward_hook(m.save_activation_hook)
+    h2 = m.base_cnn.layer4.register_full_backward_hook(m.save_gradient_hook)
+    B = 2
+    x, f = synth.synth_images(B, salt=11), synth.synth_pose_features(B, salt=11)
+    xi = x.to(dev).requires_grad_(True)
+    logits = m(xi, f.to(dev))
+    one_hot = torch.zeros_like(logits)
+    one_hot[:, 3] = 1.0
+    logits.backward(gradient=one_hot, retain_graph=True)
+    torch.cuda.synchronize()
+    h1.remove()
+    h2.remove()
+    assert m.activations.shape == (B, 512, 7, 7) and m.gradients.shape == (B, 512, 7, 7)
+    # oracle: same quantities with torch autograd on CPU
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    taps = {}
+    ref = o.quadtree_forward(sd, x.requires_grad_(True), f, taps=taps)
+    taps["layer4"].retain_grad()
+    ref.backward(gradient=one_hot.cpu())
+    assert rel_err(m.activations.cpu(), taps["layer4"].detach()) <= 1e-4
+    assert rel_err(m.gradients.cpu(), taps["layer4"].grad) <= 1e-4
+    # the Grad-CAM map itself (pooled-gradient weighting, grad_cam_analysis.py:306-316)
+    cam = lambda a, g: torch.relu((g.mean((2, 3), keepdim=True) * a).sum(1))
+    assert rel_err(cam(m.activations.cpu(), m.gradients.cpu()), cam(taps["layer4"].detach(), taps["layer4"].grad)) <= 1e-3
