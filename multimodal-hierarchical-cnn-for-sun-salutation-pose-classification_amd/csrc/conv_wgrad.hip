@@ -31,6 +31,10 @@ struct WgradArgs {
   int tilesN, tilesC, gtaps, ksplit, pix_per_split;
   int tap_stride;   // STEM: element distance between virtual taps (rows of the padded image)
   FastDiv div_ohw, div_ow;
+  // pixel walk of the X loader (element offsets): one pixel / column wrap / row wrap / the
+  // jump over the KP - LB pixels other threads stage
+  long long step1, wrap_w, wrap_h, adv_off;
+  int adv_h, adv_w;
 };
 
 constexpr int KP = 64;  // pixels per K-step
@@ -108,41 +112,109 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   long long b_coff = b_chunk_off(b_chunk(rB), b_col_ok);
   const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
   const unsigned smem_base = lds_addr_of(smem);
+
+  // Pixel <-> LDS-row assignment.  The contraction index is the pixel, so the order of the
+  // pixels inside a K-step is free as long as both tiles agree.  It is chosen so that every
+  // thread stages LB CONSECUTIVE pixels of the X tile: LDS row rho = i*RPB + t  holds pixel
+  // t*LB + i  (t = the thread's row slot in a pass, i = pass).  The walk over consecutive
+  // pixels then needs no division and no multiplication: (oh, ow, offset) advance by one pixel
+  // with two wrap tests, and by the rest of the K-step with host-computed constants.
+  const int tB = rB;                                   // 0..RPB-1
+  int pixA[LA], rowoffA[LA];                           // dY tile rows follow the same assignment
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int rho = i * RPA + rA;
+    pixA[i] = (rho % RPB) * LB + rho / RPB;
+    rowoffA[i] = pixA[i] * p.N;
+  }
+  // state of the walk: first pixel of this thread in the current K-step
+  int st_m = pbeg + tB * LB, st_oh, st_ow;
+  long long st_off;
+  {
+    const unsigned mm = (unsigned)st_m;
+    const unsigned img = fdiv(mm, p.div_ohw);
+    const unsigned rem = mm - img * (unsigned)(p.OH * p.OW);
+    st_oh = (int)fdiv(rem, p.div_ow);
+    st_ow = (int)(rem - (unsigned)st_oh * (unsigned)p.OW);
+    st_off = (long long)img * p.x_img_stride + (long long)st_oh * p.stride * p.x_row_stride +
+             (long long)st_ow * p.stride * p.x_pix_stride;
+  }
+  const int dh0 = kh - p.pad, dw0 = kw - p.pad;
+  const long long tapoff = (long long)dh0 * p.x_row_stride + (long long)dw0 * p.x_pix_stride;
+  long long dy_off = (long long)pbeg * p.N + n0 + cA * EPC;
+
   auto dma_stage = [&](int ks, int buf) {
     const int pb = pbeg + ks * KP;
     const unsigned sa = smem_base + buf * STAGE + wave_u * 1024;
     const unsigned sb = sa + KP * RBA;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int m = pb + i * RPA + rA;
-      const T* g = (m < pend && a_col_ok) ? dy + (long long)m * p.N + n0 + cA * EPC : zero_src;
+      const T* g = (pb + pixA[i] < pend && a_col_ok) ? dy + (dy_off + rowoffA[i]) : zero_src;
       glds16(g, sa + i * (RPA * RBA));
     }
+    dy_off += (long long)KP * p.N;
+    if (p.quad) {
+      // quadrant images are not equally spaced in memory: general per-pixel decode
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int m = pb + tB * LB + i;
+        const T* g = zero_src;
+        if (RPB % 8 != 0) b_coff = b_chunk_off(b_chunk(i * RPB + rB), b_col_ok);
+        if (m < pend && b_col_ok) {
+          unsigned img = fdiv((unsigned)m, p.div_ohw);
+          unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
+          unsigned oh = fdiv(rem, p.div_ow);
+          unsigned ow = rem - oh * (unsigned)p.OW;
+          const int n = img >> 2, q = img & 3;
+          const long long base = (long long)n * p.x_img_stride + (long long)(q >> 1) * p.IH * p.x_row_stride +
+                                 (long long)(q & 1) * p.IW * p.x_pix_stride;
+          const int ih = (int)oh * p.stride + dh0, iw = (int)ow * p.stride + dw0;
+          if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+            g = x + base + (long long)ih * p.x_row_stride + (long long)iw * p.x_pix_stride + b_coff;
+        }
+        glds16(g, sb + i * (RPB * RBB));
+      }
+      return;
+    }
+    int oh = st_oh, ow = st_ow;
+    long long off = st_off;
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      const int m = pb + i * RPB + rB;
-      const T* g = zero_src;
       if (RPB % 8 != 0) b_coff = b_chunk_off(b_chunk(i * RPB + rB), b_col_ok);
-      if (m < pend && b_col_ok) {
-        unsigned img = fdiv((unsigned)m, p.div_ohw);
-        unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
-        unsigned oh = fdiv(rem, p.div_ow);
-        unsigned ow = rem - oh * (unsigned)p.OW;
-        long long base;
-        if (p.quad) {
-          const int n = img >> 2, q = img & 3;
-          base = (long long)n * p.x_img_stride + (long long)(q >> 1) * p.IH * p.x_row_stride +
-                 (long long)(q & 1) * p.IW * p.x_pix_stride;
-        } else {
-          base = (long long)img * p.x_img_stride;
-        }
-        const int ih = (int)oh * p.stride - p.pad + kh;
-        const int iw = (int)ow * p.stride - p.pad + kw;
-        if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
-          g = x + base + (long long)ih * p.x_row_stride + (long long)iw * p.x_pix_stride + b_coff;
-      }
+      const int ih = oh * p.stride + dh0, iw = ow * p.stride + dw0;
+      const bool ok = st_m + i < pend && b_col_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      const T* g = ok ? x + (off + tapoff + b_coff) : zero_src;
       glds16(g, sb + i * (RPB * RBB));
+      // next pixel
+      ++ow;
+      off += p.step1;
+      if (ow == p.OW) {
+        ow = 0;
+        ++oh;
+        off += p.wrap_w;
+        if (oh == p.OH) {
+          oh = 0;
+          off += p.wrap_h;
+        }
+      }
     }
+    // the remaining KP - LB pixels of the K-step in one jump
+    st_m += KP;
+    ow += p.adv_w;
+    off += p.adv_off;
+    if (ow >= p.OW) {
+      ow -= p.OW;
+      ++oh;
+      off += p.wrap_w;
+    }
+    oh += p.adv_h;
+    if (oh >= p.OH) {
+      oh -= p.OH;
+      off += p.wrap_h;
+    }
+    st_oh = oh;
+    st_ow = ow;
+    st_off = off;
   };
 
   f32x4 acc[TMW][TNW];
@@ -279,6 +351,19 @@ int launch(WgradArgs a, hipStream_t stream) {
   if (a.ksplit >= 6 && (a.ksplit & 7)) a.ksplit = qt_cdiv(a.ksplit, 8) * 8;  // empty tail splits exit at once
   a.pix_per_split = pps;
   a.gtaps = gtaps;
+  {
+    constexpr int CPRBh = (STEM ? 256 : BNW) * ES / 16, LBh = KP / (256 / CPRBh);
+    const long long srs = (long long)a.stride * a.x_row_stride, sps = (long long)a.stride * a.x_pix_stride;
+    a.step1 = sps;
+    a.wrap_w = srs - (long long)a.OW * sps;
+    a.wrap_h = a.x_img_stride - (long long)a.OH * srs;
+    const int jump = KP - LBh;  // pixels
+    const int ohw = a.OH * a.OW;
+    const int di = jump / ohw, r1 = jump % ohw;
+    a.adv_h = r1 / a.OW;
+    a.adv_w = r1 % a.OW;
+    a.adv_off = (long long)di * a.x_img_stride + (long long)a.adv_h * srs + (long long)a.adv_w * sps;
+  }
   hipLaunchKernelGGL(kern, dim3(base_blocks * a.ksplit), dim3(256), LDS, stream, a);
   QT_CHECK_LAUNCH();
   return QT_OK;
