@@ -548,7 +548,7 @@ __global__ void col_sum_kernel(const T* __restrict__ x, long long rows, int cols
 
 // Long row counts are first folded 256:1 into the spare rows behind `rows`.
 static int fold_partial(float*& partial, int& rows, int C, hipStream_t s) {
-  if (rows <= 128) return QT_OK;
+  if (rows <= 1024) return QT_OK;  // the 1024-thread finalize kernels cover this directly
   const int S = qt_cdiv(rows, kFold);
   hipLaunchKernelGGL(stats_stage1_kernel, dim3(qt_cdiv(C, 64), S), dim3(256), 0, s, partial, rows, C);
   QT_CHECK_LAUNCH();
@@ -557,7 +557,7 @@ static int fold_partial(float*& partial, int& rows, int C, hipStream_t s) {
   return QT_OK;
 }
 
-extern "C" int qt_stats_capacity_rows(int rows) { return rows <= 128 ? rows : rows + qt_cdiv(rows, kFold); }
+extern "C" int qt_stats_capacity_rows(int rows) { return rows <= 1024 ? rows : rows + qt_cdiv(rows, kFold); }
 
 extern "C" int qt_bn_finalize(float* partial, int rows, int C, long long count, const float* gamma,
                               const float* beta, float* running_mean, float* running_var,

@@ -80,6 +80,12 @@ struct qt_plan {
   struct Timed { hipEvent_t a, b; double flops; int kind; };
   bool profiling = false;
   std::vector<Timed> timed;
+  // weight gradients run on a plan-owned side stream, concurrently with the BatchNorm /
+  // data-gradient chain of the next layer (they only share read-only inputs); joined at the
+  // end of every backward phase.  QTCNN_SIDE_STREAM=0 keeps everything on the caller's stream.
+  bool use_side = true;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // state of the last forward
   int last_batch = 0, last_training = 0;
   unsigned long long last_seed = 0;
@@ -375,18 +381,18 @@ struct Exec {
     const double k = stem ? 147.0 : (double)d.kh * d.kw * d.k_per_tap;
     return 2.0 * imgs * fwd_pixels * k * d.n_out;
   }
-  int begin_timed(double flops, int kind) {
+  int begin_timed(double flops, int kind, void* on = nullptr) {
     if (!p->profiling) return -1;
     qt_plan::Timed t;
     if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
     t.flops = flops;
     t.kind = kind;
-    (void)hipEventRecord(t.a, static_cast<hipStream_t>(stream));
+    (void)hipEventRecord(t.a, static_cast<hipStream_t>(on ? on : stream));
     p->timed.push_back(t);
     return (int)p->timed.size() - 1;
   }
-  void end_timed(int slot) {
-    if (slot >= 0) (void)hipEventRecord(p->timed[slot].b, static_cast<hipStream_t>(stream));
+  void end_timed(int slot, void* on = nullptr) {
+    if (slot >= 0) (void)hipEventRecord(p->timed[slot].b, static_cast<hipStream_t>(on ? on : stream));
   }
 
   long long rows_of(const ConvL& c) const { return (long long)B * c.hout * c.hout; }
@@ -601,25 +607,61 @@ struct Bwd : Exec {
             mask, nullptr, 0, 1);
     }
   }
+  // ---- side stream for the weight gradients ----
+  void* wstream = nullptr;  // == stream when the side stream is off
+  bool forked = false;
+  void hip(hipError_t e, const char* what) {
+    if (e != hipSuccess && status == QT_OK) {
+      qt_set_error("%s: %s", what, hipGetErrorString(e));
+      status = QT_ERR_LAUNCH;
+    }
+  }
+  void setup_side() {
+    wstream = stream;
+    if (!p->use_side) return;
+    if (!p->side) {
+      hip(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking), "hipStreamCreate");
+      hip(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
+      hip(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (ok()) wstream = p->side;
+  }
+  // everything enqueued on `stream` so far happens before later side-stream work
+  void fork() {
+    if (wstream == stream || !ok()) return;
+    hip(hipEventRecord(p->ev_fork, static_cast<hipStream_t>(stream)), "hipEventRecord");
+    hip(hipStreamWaitEvent(p->side, p->ev_fork, 0), "hipStreamWaitEvent");
+    forked = true;
+  }
+  // side-stream work happens before anything enqueued on `stream` afterwards
+  void join() {
+    if (!forked || !ok()) return;
+    hip(hipEventRecord(p->ev_join, p->side), "hipEventRecord");
+    hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join, 0), "hipStreamWaitEvent");
+    forked = false;
+  }
+
   // weight gradient of conv c: dy = c.gy, x = src
   void wgrad(const ConvL& c, const qt_conv_desc& fwd_desc, const void* src, bool stem) {
     if (!ok() || !gf(c.w)) return;
+    fork();
+    void* ws_ = wstream;
     const size_t n = stem ? (size_t)64 * 7 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
     if (!stem && c.k == 1) {  // [O][1][I] is already OIHW
-      run(zero(gf(c.w), n * 4, stream));
-      const int slot = begin_timed(conv_flops(fwd_desc), 2);
-      run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, gf(c.w), stream));
-      end_timed(slot);
+      run(zero(gf(c.w), n * 4, ws_));
+      const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);
+      run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, gf(c.w), ws_));
+      end_timed(slot, ws_);
       return;
     }
-    run(zero(at(c.dw), n * 4, stream));
-    const int slot = begin_timed(conv_flops(fwd_desc), 2);
-    run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, at<float>(c.dw), stream));
-    end_timed(slot);
+    run(zero(at(c.dw), n * 4, ws_));
+    const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);
+    run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, at<float>(c.dw), ws_));
+    end_timed(slot, ws_);
     if (stem)
-      run(qt_unpack_stem_wgrad(at<float>(c.dw), gf(c.w), 0, stream));
+      run(qt_unpack_stem_wgrad(at<float>(c.dw), gf(c.w), 0, ws_));
     else
-      run(qt_unpack_conv_wgrad(at<float>(c.dw), gf(c.w), c.cout, c.cin, c.k, c.k, 0, stream));
+      run(qt_unpack_conv_wgrad(at<float>(c.dw), gf(c.w), c.cout, c.cin, c.k, c.k, 0, ws_));
   }
 };
 
@@ -628,6 +670,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   Bwd e;
   e.p = p; e.ws = static_cast<unsigned char*>(workspace); e.T = T; e.stream = stream; e.B = p->last_batch;
   e.dt = p->d.dtype; e.G = G;
+  e.setup_side();
   const int dt = e.dt;
   const int B = e.B;
   const bool tr = p->last_training != 0;
@@ -667,10 +710,11 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, stream));
     const qt_conv_desc lf = e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD);
     if (e.gf(p->cls0.w)) {
-      e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, stream));
-      const int slot = e.begin_timed(e.conv_flops(lf), 2);
-      e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), stream));
-      e.end_timed(slot);
+      e.fork();
+      e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, e.wstream));
+      const int slot = e.begin_timed(e.conv_flops(lf), 2, e.wstream);
+      e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), e.wstream));
+      e.end_timed(slot, e.wstream);
     }
     const bool need_dfused = p->has_numerical || (p->has_image && (!p->standard || backbone_grads));
     if (need_dfused)
@@ -713,6 +757,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       e.wgrad(cq, e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), false);
     }
   }
+
+  if (!(phases & QT_BWD_BACKBONE)) e.join();  // a phase-wise caller reduces the head bucket next
 
   if ((phases & QT_BWD_BACKBONE) && backbone_grads) {
     // gradient of layer4's output through avgpool (+ ReLU mask of the block output)
@@ -759,6 +805,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     e.bn_backward(c0, e.at(c0.gy), nullptr);
     e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
   }
+  e.join();
   return e.status;
 }
 
@@ -779,13 +826,20 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
   qt_plan* p = new qt_plan();
   p->d = *desc;
   p->esz = desc->dtype == QT_F32 ? 4 : 2;
+  if (const char* v = getenv("QTCNN_SIDE_STREAM")) p->use_side = atoi(v) != 0;
   build_graph(p);
   layout_workspace(p);
   *out = p;
   return QT_OK;
 }
 
-extern "C" void qt_plan_destroy(qt_plan* p) { delete p; }
+extern "C" void qt_plan_destroy(qt_plan* p) {
+  if (!p) return;
+  if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  delete p;
+}
 extern "C" int qt_plan_num_tensors(const qt_plan* p) { return p ? (int)p->tensors.size() : QT_ERR_INVALID_ARG; }
 extern "C" const char* qt_plan_tensor_name(const qt_plan* p, int i) {
   return (p && i >= 0 && i < (int)p->tensors.size()) ? p->tensors[i].name.c_str() : nullptr;
