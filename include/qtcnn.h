@@ -84,6 +84,16 @@ typedef struct qt_conv_io {
   const void* residual;  /* [M][n_out] or NULL */
   const void* relu_mask; /* [M][n_out] or NULL: dst = mask > 0 ? dst : 0 */
   float* stats_partial;  /* or NULL */
+  /* Optional (data-gradient launches): up to two BatchNorms consume the value g written to
+   * dst; the epilogue then also emits, per 128-row tile, sum g and sum g*(y-mean)*invstd for
+   * each of them ([qt_conv2d_stats_rows][2][n_out] f32), which is what qt_bn_bwd_finalize
+   * takes -- the separate qt_bn_bwd_reduce pass over g and y is not needed. */
+  struct {
+    const void* y;       /* BatchNorm input saved by the forward pass, [M][n_out] */
+    const float* mean;   /* [n_out] */
+    const float* invstd; /* [n_out] */
+    float* partial;
+  } bwd_bn[2];
 } qt_conv_io;
 
 int qt_conv2d_stats_rows(const qt_conv_desc* desc);

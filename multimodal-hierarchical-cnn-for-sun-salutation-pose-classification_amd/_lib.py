@@ -41,6 +41,11 @@ class ConvIO(ctypes.Structure):
         ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
         ("residual", ctypes.c_void_p), ("relu_mask", ctypes.c_void_p),
         ("stats_partial", ctypes.c_void_p),
+        # bwd_bn[2]: {y, mean, invstd, partial}
+        ("bn0_y", ctypes.c_void_p), ("bn0_mean", ctypes.c_void_p), ("bn0_invstd", ctypes.c_void_p),
+        ("bn0_partial", ctypes.c_void_p),
+        ("bn1_y", ctypes.c_void_p), ("bn1_mean", ctypes.c_void_p), ("bn1_invstd", ctypes.c_void_p),
+        ("bn1_partial", ctypes.c_void_p),
     ]
 
 

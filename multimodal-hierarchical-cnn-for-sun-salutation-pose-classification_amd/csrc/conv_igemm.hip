@@ -29,6 +29,12 @@ struct ConvArgs {
   const void* residual;    // [M][N] same dtype, nullable
   const void* relu_mask;   // [M][N] same dtype: result *= (mask > 0), nullable
   float* stats_partial;    // [gridM][2][N] per-tile sum / sum of squares, nullable
+  // BatchNorm-backward partial sums of the value written to dst (g): sum g and sum g*xhat with
+  // xhat = (bn_y - mean) * invstd, for up to two BatchNorms that consume g
+  const void* bn_y[2];
+  const float* bn_mean[2];
+  const float* bn_invstd[2];
+  float* bn_partial[2];     // [gridM][2][N] each
   long long src_img_stride;
   int src_row_stride, src_pix_stride;
   int M, N;
@@ -301,9 +307,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     sc[e] = (p.scale && n_ok) ? p.scale[nbase + e] : 1.f;
     sh[e] = (p.shift && n_ok) ? p.shift[nbase + e] : 0.f;
   }
-  float s1[8], s2[8];
+  float s1[8], s2[8], s3[8];  // forward: sum v, sum v^2;  backward: sum g, sum g*xhat0, sum g*xhat1
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
+  const bool bwd_stats = p.bn_y[0] != nullptr;
+  float mu0[8], is0[8], mu1[8], is1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu0[e] = (bwd_stats && n_ok) ? p.bn_mean[0][nbase + e] : 0.f;
+    is0[e] = (bwd_stats && n_ok) ? p.bn_invstd[0][nbase + e] : 0.f;
+    mu1[e] = (p.bn_y[1] && n_ok) ? p.bn_mean[1][nbase + e] : 0.f;
+    is1[e] = (p.bn_y[1] && n_ok) ? p.bn_invstd[1][nbase + e] : 0.f;
+  }
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
@@ -324,12 +339,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         drow = ((long long)img * p.dst_h + oh * p.dst_sub + p.dst_oh) * p.dst_w + ow * p.dst_sub + p.dst_ow;
       }
       const long long off = drow * p.N + nbase;
+      if (!bwd_stats) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s1[e] += v[e];
-        s2[e] += v[e] * v[e];
-        v[e] = v[e] * sc[e] + sh[e];
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += v[e];
+          s2[e] += v[e] * v[e];
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
       if (res) {
         float rv[8];
         QtVec8<T>::load(res + off, rv);
@@ -347,28 +365,49 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
       }
       QtVec8<T>::store(dst + off, v);
+      if (bwd_stats) {
+        float yv[8];
+        QtVec8<T>::load(static_cast<const T*>(p.bn_y[0]) + off, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += v[e];
+          s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
+        }
+        if (p.bn_y[1]) {
+          QtVec8<T>::load(static_cast<const T*>(p.bn_y[1]) + off, yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
+        }
+      }
     }
   }
 
-  if (p.stats_partial) {
+  if (p.stats_partial || bwd_stats) {
     // reduce the per-thread sums over the threads that share a channel group
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [RPP][BN][2]
+    float* red = reinterpret_cast<float*>(smem);  // [RPP][BN][3]
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      red[(r0 * BN + cg * 8 + e) * 2 + 0] = s1[e];
-      red[(r0 * BN + cg * 8 + e) * 2 + 1] = s2[e];
+      red[(r0 * BN + cg * 8 + e) * 3 + 0] = s1[e];
+      red[(r0 * BN + cg * 8 + e) * 3 + 1] = s2[e];
+      red[(r0 * BN + cg * 8 + e) * 3 + 2] = s3[e];
     }
     __syncthreads();
     if (tid < BN) {
-      float a = 0.f, b = 0.f;
+      float a = 0.f, b = 0.f, c = 0.f;
       for (int r = 0; r < RPP; ++r) {
-        a += red[(r * BN + tid) * 2 + 0];
-        b += red[(r * BN + tid) * 2 + 1];
+        a += red[(r * BN + tid) * 3 + 0];
+        b += red[(r * BN + tid) * 3 + 1];
+        c += red[(r * BN + tid) * 3 + 2];
       }
       if (n0 + tid < p.N) {
-        p.stats_partial[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-        p.stats_partial[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
+        float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
+        o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
+        o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
+        if (bwd_stats && p.bn_y[1]) {
+          p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
+          p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
+        }
       }
     }
   }
@@ -461,6 +500,13 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.scale = io->scale; a.shift = io->shift;
   a.residual = io->residual; a.relu_mask = io->relu_mask;
   a.stats_partial = io->stats_partial;
+  for (int k = 0; k < 2; ++k) {
+    a.bn_y[k] = io->bwd_bn[k].y; a.bn_mean[k] = io->bwd_bn[k].mean; a.bn_invstd[k] = io->bwd_bn[k].invstd;
+    a.bn_partial[k] = io->bwd_bn[k].partial;
+    QT_CHECK_ARG(!a.bn_y[k] || (a.bn_mean[k] && a.bn_invstd[k] && a.bn_partial[k] && !io->stats_partial),
+                 "qt_conv2d_igemm: incomplete bwd_bn[%d]", k);
+  }
+  QT_CHECK_ARG(!(a.bn_y[1] && !a.bn_y[0]), "qt_conv2d_igemm: bwd_bn[1] without bwd_bn[0]");
   a.src_img_stride = d->src_img_stride;
   a.src_row_stride = d->src_row_stride;
   a.src_pix_stride = d->src_pix_stride;

@@ -75,6 +75,7 @@ struct qt_plan {
   size_t xpad = 0, p0 = 0, argmax = 0, g_p0 = 0;
   size_t q = 0, dq = 0, fused = 0, dfused = 0, h1 = 0, dh1 = 0, hidden = 0, dhidden = 0;
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
+  size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;  // BatchNorm-backward partials emitted by dgrad epilogues
   // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
   // the launch stream around every igemm / wgrad launch while enabled
   struct Timed { hipEvent_t a, b; double flops; int kind; };
@@ -225,6 +226,11 @@ void layout_workspace(qt_plan* p) {
     size_t bytes = (size_t)rows * 2 * 64 * 4;
     const size_t bwd = (size_t)qt_stats_capacity_rows(2048) * 2 * 512 * 4;
     p->stats = ws.take(bytes > bwd ? bytes : bwd);
+    // dgrad-epilogue partials: one row per 128-pixel tile (+ the fold rows); layer1 is the largest
+    const size_t ep = (size_t)qt_stats_capacity_rows(qt_cdiv((long long)B * 56 * 56, 128) + 8) * 2 * 64 * 4;
+    p->stats_bn2 = ws.take(ep);
+    p->stats_ds = ws.take(ep);
+    p->stats_bn1 = ws.take(ep);
   }
   for (auto& b : p->bns) {
     b.mean = ws.take(b.C * 4);
@@ -361,12 +367,23 @@ struct Exec {
     return d;
   }
 
+  struct BnLink {  // a BatchNorm that consumes the gradient a dgrad launch writes
+    const void* y = nullptr;
+    const float* mean = nullptr;
+    const float* invstd = nullptr;
+    float* partial = nullptr;
+  };
   void igemm(const qt_conv_desc& d, const void* src, const void* w, void* dst, const float* scale, const float* shift,
-             const void* res, const void* mask, float* stats, int relu, int kind = -1) {
+             const void* res, const void* mask, float* stats, int relu, int kind = -1, const BnLink* links = nullptr,
+             int nlinks = 0) {
     if (!ok()) return;
     qt_conv_desc dd = d;
     dd.relu = relu;
     qt_conv_io io = {src, w, dst, scale, shift, res, mask, stats};
+    for (int k = 0; k < nlinks && k < 2; ++k) {
+      io.bwd_bn[k].y = links[k].y; io.bwd_bn[k].mean = links[k].mean;
+      io.bwd_bn[k].invstd = links[k].invstd; io.bwd_bn[k].partial = links[k].partial;
+    }
     const int slot = begin_timed(conv_flops(d), kind >= 0 ? kind : (d.mode == QT_CONV_FWD ? 0 : 1));
     run(qt_conv2d_igemm(&dd, &io, stream));
     end_timed(slot);
@@ -562,14 +579,17 @@ struct Bwd : Exec {
   float* gf(int idx) const { return idx < 0 ? nullptr : G[idx]; }
 
   // BatchNorm backward for conv c given g (in gy or external): dy -> c.gy
-  void bn_backward(const ConvL& c, const void* g, void* g_out) {
+  void bn_backward(const ConvL& c, const void* g, void* g_out, float* pre_partial = nullptr, int pre_rows = 0) {
     if (!ok()) return;
     const BnL& bn = p->bns[c.bn];
     const long long M = rows_of(c);
-    float* part = at<float>(p->stats);
-    run(qt_bn_bwd_reduce(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), part, M, bn.C, stream));
-    if (!ok()) return;
-    const int rows = qt_bn_bwd_partial_rows(M, bn.C);
+    float* part = pre_partial ? pre_partial : at<float>(p->stats);
+    int rows = pre_rows;
+    if (!pre_partial) {
+      run(qt_bn_bwd_reduce(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), part, M, bn.C, stream));
+      if (!ok()) return;
+      rows = qt_bn_bwd_partial_rows(M, bn.C);
+    }
     run(qt_bn_bwd_finalize(part, rows, bn.C, M, tf(bn.gamma), at<float>(bn.invstd), gf(bn.gamma), gf(bn.beta), 0,
                            at<float>(bn.coef), stream));
     run(qt_bn_bwd_apply(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.coef),
@@ -578,21 +598,25 @@ struct Bwd : Exec {
   // data gradient of conv c: dst = conv_transpose(c.gy) (+resid) (* (mask > 0)).  A stride-2
   // conv is run as four stride-1 gathers, one per parity class of the destination pixel, so no
   // MFMA work is spent on taps that cannot reach a pixel (a dense gather would waste 3/4).
-  void dgrad(const ConvL& c, void* dst, const void* resid, const void* mask) {
+  // returns the number of partial rows each link received
+  int dgrad(const ConvL& c, void* dst, const void* resid, const void* mask, const BnLink* links = nullptr,
+            int nlinks = 0) {
     if (c.stride == 1) {
-      igemm(conv_desc(c, QT_CONV_DGRAD), at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0);
-      return;
+      const qt_conv_desc d = conv_desc(c, QT_CONV_DGRAD);
+      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, -1, links, nlinks);
+      return qt_conv2d_stats_rows(&d);
     }
     bool empty_class = false;
     for (int cls = 0; cls < 4; ++cls) empty_class |= c.cls_kh[cls] * c.cls_kw[cls] == 0;
     if (empty_class) {  // 1x1 stride 2: three of four pixels receive nothing from the conv
-      if (resid || mask) {
+      if (resid || mask || nlinks) {
         status = QT_ERR_UNSUPPORTED;
-        qt_set_error("dgrad: 1x1 stride-2 with residual/mask is not wired");
-        return;
+        qt_set_error("dgrad: 1x1 stride-2 with residual/mask/links is not wired");
+        return 0;
       }
       run(zero(dst, (size_t)B * c.hin * c.hin * c.cin * p->esz, stream));
     }
+    int rows = 0;
     for (int cls = 0; cls < 4 && ok(); ++cls) {
       if (c.cls_kh[cls] * c.cls_kw[cls] == 0) continue;
       qt_conv_desc d;
@@ -603,9 +627,16 @@ struct Bwd : Exec {
       d.kh = c.cls_kh[cls]; d.kw = c.cls_kw[cls]; d.stride = 1; d.pad = 0;
       d.src_pix_stride = c.cout; d.src_row_stride = c.hout * c.cout; d.src_img_stride = (long long)c.hout * c.hout * c.cout;
       d.dst_sub = 2; d.dst_h = d.dst_w = c.hin; d.dst_off_h = cls >> 1; d.dst_off_w = cls & 1;
+      BnLink l2[2];
+      for (int k = 0; k < nlinks && k < 2; ++k) {
+        l2[k] = links[k];
+        l2[k].partial = links[k].partial + (size_t)rows * 2 * c.cin;  // each class appends its tile rows
+      }
       igemm(d, at(c.gy), at<unsigned char>(c.w_dgrad) + (size_t)c.cls_off[cls] * p->esz, dst, nullptr, nullptr, resid,
-            mask, nullptr, 0, 1);
+            mask, nullptr, 0, 1, l2, nlinks);
+      rows += qt_conv2d_stats_rows(&d);
     }
+    return rows;
   }
   // ---- side stream for the weight gradients ----
   void* wstream = nullptr;  // == stream when the side stream is off
@@ -764,25 +795,29 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // gradient of layer4's output through avgpool (+ ReLU mask of the block output)
     e.run(qt_avgpool_bwd(dt, e.at(p->dfused), e.at(p->blocks[7].out), e.at(p->blocks[7].gout), B, 49, 512, p->fused_ld,
                          0, stream));
+    int rows_bn2 = 0;  // partial rows of bn2 / downsample-BN of the block being entered (0 = none yet)
     for (int bi = 7; bi >= 0; --bi) {
       const Block& blk = p->blocks[bi];
       const ConvL& c1 = p->convs[blk.conv1];
       const ConvL& c2 = p->convs[blk.conv2];
       const size_t x = bi == 0 ? p->p0 : p->blocks[bi - 1].out;
       const qt_conv_desc f1 = e.conv_desc(c1, QT_CONV_FWD), f2 = e.conv_desc(c2, QT_CONV_FWD);
-      // bn2 / conv2
-      e.bn_backward(c2, e.at(blk.gout), nullptr);
+      // bn2 / conv2: the partial sums were emitted by the dgrad that wrote blk.gout
+      e.bn_backward(c2, e.at(blk.gout), nullptr, rows_bn2 ? e.at<float>(p->stats_bn2) : nullptr, rows_bn2);
       e.wgrad(c2, f2, e.at(blk.a1), false);
-      e.igemm(e.conv_desc(c2, QT_CONV_DGRAD), e.at(c2.gy), e.at(c2.w_dgrad), e.at(c1.gy), nullptr, nullptr, nullptr,
-              e.at(blk.a1), nullptr, 0);
-      // bn1 / conv1
-      e.bn_backward(c1, e.at(c1.gy), nullptr);
+      {
+        const BnL& b1 = p->bns[c1.bn];
+        Exec::BnLink l = {e.at(c1.y), e.at<float>(b1.mean), e.at<float>(b1.invstd), e.at<float>(p->stats_bn1)};
+        const int r1 = e.dgrad(c2, e.at(c1.gy), nullptr, e.at(blk.a1), &l, 1);
+        // bn1 / conv1
+        e.bn_backward(c1, e.at(c1.gy), nullptr, e.at<float>(p->stats_bn1), r1);
+      }
       e.wgrad(c1, f1, e.at(x), false);
       // gradient w.r.t. the block input = conv1 dgrad + identity path (+ quadrant head for layer3's output)
       const void* resid = e.at(blk.gout);
       if (blk.ds >= 0) {
         const ConvL& cd = p->convs[blk.ds];
-        e.bn_backward(cd, e.at(blk.gout), nullptr);
+        e.bn_backward(cd, e.at(blk.gout), nullptr, rows_bn2 ? e.at<float>(p->stats_ds) : nullptr, rows_bn2);
         e.wgrad(cd, e.conv_desc(cd, QT_CONV_FWD), e.at(x), false);
         e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr);
         resid = e.at(blk.gtmp);
@@ -795,7 +830,21 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       }
       void* gprev = bi == 0 ? e.at(p->g_p0) : e.at(p->blocks[bi - 1].gout);
       const void* mask = bi == 0 ? nullptr : e.at(x);
-      e.dgrad(c1, gprev, resid, mask);
+      Exec::BnLink links[2];
+      int nlinks = 0;
+      if (bi > 0) {  // gprev feeds bn2 (and the downsample BN) of the previous block
+        const Block& pb = p->blocks[bi - 1];
+        const ConvL& pc2 = p->convs[pb.conv2];
+        const BnL& pb2 = p->bns[pc2.bn];
+        links[nlinks++] = {e.at(pc2.y), e.at<float>(pb2.mean), e.at<float>(pb2.invstd), e.at<float>(p->stats_bn2)};
+        if (pb.ds >= 0) {
+          const ConvL& pcd = p->convs[pb.ds];
+          const BnL& pbd = p->bns[pcd.bn];
+          links[nlinks++] = {e.at(pcd.y), e.at<float>(pbd.mean), e.at<float>(pbd.invstd), e.at<float>(p->stats_ds)};
+        }
+      }
+      rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks);
+      if (bi == 0) rows_bn2 = 0;
     }
     // ---- stem ----
     const ConvL& c0 = p->convs[0];
