@@ -96,6 +96,9 @@ typedef struct qt_conv_io {
   } bwd_bn[2];
 } qt_conv_io;
 
+/* Experimental: route 3x3 stride-1 convs of 56x56 / 28x28 maps through the LDS-resident-patch
+ * kernel (csrc/conv_patch.hip) instead of the generic implicit GEMM.  Default off. */
+void qt_set_patch_conv(int enabled);
 int qt_conv2d_stats_rows(const qt_conv_desc* desc);
 int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream);
 

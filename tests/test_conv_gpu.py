@@ -61,7 +61,10 @@ def run_conv(L, dt, x_nhwc, w_krsc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw, 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [
     # B, Cin, Cout, H, k, stride, pad
-    (2, 64, 64, 56, 3, 1, 1),
+    (2, 64, 64, 56, 3, 1, 1),    # patch kernel (conv_patch.hip), BN=64
+    (3, 128, 128, 28, 3, 1, 1),  # patch kernel, BN=128, two channel chunks
+    (1, 64, 128, 56, 3, 1, 1),   # patch kernel, widest LDS footprint
+    (5, 128, 64, 28, 3, 1, 1),   # patch kernel, ragged last tile
     (3, 64, 128, 56, 3, 2, 1),
     (2, 64, 128, 56, 1, 2, 0),
     (1, 256, 512, 14, 3, 2, 1),
@@ -101,7 +104,8 @@ def test_conv_fwd_epilogue(dt, cfg):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [
-    (2, 64, 64, 56, 3, 1, 1),
+    (2, 64, 64, 56, 3, 1, 1),    # patch kernel
+    (3, 128, 128, 28, 3, 1, 1),  # patch kernel
     (2, 64, 128, 56, 3, 2, 1),
     (2, 64, 128, 56, 1, 2, 0),
     (1, 256, 512, 14, 3, 2, 1),
@@ -160,6 +164,23 @@ def test_quadrant_conv_fwd_and_dgrad(dt):
                     strides=(49 * N, 7 * N, N))
     got = y.float().cpu().view(B, 14, 14, C).permute(0, 3, 1, 2)
     assert rel_err(got, dbase) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patch_kernel_matches_generic_path(dt):
+    """The experimental LDS-resident-patch kernel (conv_patch.hip) behind the same entry point."""
+    _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    lib.qt_set_patch_conv(1)
+    try:
+        for cfg in [(2, 64, 64, 56, 3, 1, 1), (3, 128, 128, 28, 3, 1, 1), (1, 64, 128, 56, 3, 1, 1),
+                    (5, 128, 64, 28, 3, 1, 1)]:
+            test_conv_fwd_epilogue(dt, cfg)
+        for cfg in [(2, 64, 64, 56, 3, 1, 1), (3, 128, 128, 28, 3, 1, 1)]:
+            test_conv_dgrad(dt, cfg)
+    finally:
+        lib.qt_set_patch_conv(0)
 
 
 def test_conv_rejects_bad_args():
