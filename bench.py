@@ -192,9 +192,17 @@ def main():
         if nig:
             ach = (fl[0] + fl[1]) / ((ms[0] + ms[1]) * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
+            traffic, traffic_src = None, None
+            try:  # HBM bytes per launch from the committed PMC summary (rocprofv3 cannot run inside bench.py)
+                import glob
+                tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
+                fam = json.load(open(tf))["families"]["conv_igemm_kernel"]
+                traffic, traffic_src = fam["hbm_bytes_per_launch"], os.path.relpath(tf, ROOT)
+            except Exception:
+                pass
             roofline = {"kernel": "conv_igemm_kernel (implicit-GEMM conv, fwd + dgrad launches)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None,
+                        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(1e3 * (ms[0] + ms[1]) / nig, 2),
                         "gflop_per_launch": round((fl[0] + fl[1]) / nig / 1e9, 3),
                         "mfma_ms_per_step": round(sum(ms) / args.profile_steps, 3),

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<name>/{trace,fetch,write} (scripts/collect_profiles.sh) into the committed
+summaries under profiles/: per-kernel duration table and per-kernel-family HBM traffic.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KiB and reads
+exactly 1/2 of the bytes of wide coalesced streams -> bytes = FETCH_SIZE * 1024 * 2;
+WRITE_SIZE * 1024 is exact for 16-byte-per-lane stores and float atomics."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+name = sys.argv[1] if len(sys.argv) > 1 else "profile"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", name)
+
+
+def family(kernel):
+    for key in ("conv_igemm_kernel", "conv_wgrad_kernel", "conv_patch_kernel", "bn_bwd_apply", "bn_bwd_reduce",
+                "bn_act", "stem_pool_bwd", "stem_pool", "multi_tensor_apply"):
+        if key in kernel:
+            return key
+    return "other"
+
+
+def pmc(sub, counter):
+    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == counter:
+            a = agg[family(r["Kernel_Name"])]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return agg
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(stats)))
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w") as out:
+    out.write(open(stats).read())
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+summary = {}
+for fam in sorted(set(fetch) | set(write)):
+    n = max(fetch[fam][1], write[fam][1], 1)
+    rd = fetch[fam][0] * 1024 * 2 / max(fetch[fam][1], 1)
+    wr = write[fam][0] * 1024 / max(write[fam][1], 1)
+    summary[fam] = {"launches_profiled": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                    "hbm_bytes_per_launch": round(rd + wr)}
+dur = collections.defaultdict(lambda: [0.0, 0])
+for r in rows:
+    d = dur[family(r["Name"])]
+    d[0] += float(r["TotalDurationNs"])
+    d[1] += int(r["Calls"])
+for fam, (ns, calls) in dur.items():
+    summary.setdefault(fam, {})["avg_us"] = round(ns / calls / 1e3, 2)
+    summary[fam]["calls"] = calls
+json.dump({"command": "bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 0 (B=256, bf16, 1 GPU)",
+           "corrections": "read = FETCH_SIZE*1024*2 (gfx950 half-count of wide coalesced reads), write = WRITE_SIZE*1024",
+           "families": summary}, open(os.path.join(root, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
