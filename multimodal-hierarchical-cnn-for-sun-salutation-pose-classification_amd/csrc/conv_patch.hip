@@ -54,6 +54,124 @@ constexpr int kRowBytes = 128;
 constexpr int BM = 256;
 constexpr int NT = 512;
 
+// Rows of the staged f32 tile -> dense NHWC rows with the fused epilogue; `mt` = row of the
+// per-tile partial-sum tables.
+template <typename T, int BN, int NTH>
+__device__ __forceinline__ void patch_epilogue(const PatchArgs& p, unsigned char* smem, long long q0, int mt, int n0,
+                                               int tid) {
+  constexpr int ROWB = BN * 4;
+  constexpr int TPR = BN / 8;
+  constexpr int RPP = NTH / TPR;
+  constexpr int NPASS = BM / RPP;
+  const int cg = tid % TPR, r0 = tid / TPR;
+  const int nbase = n0 + cg * 8;
+  const bool n_ok = nbase < p.N;
+  float sc[8], sh[8], mu0[8], is0[8], mu1[8], is1[8];
+  const bool bwd_stats = p.bn_y[0] != nullptr;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = (p.scale && n_ok) ? p.scale[nbase + e] : 1.f;
+    sh[e] = (p.shift && n_ok) ? p.shift[nbase + e] : 0.f;
+    mu0[e] = (bwd_stats && n_ok) ? p.bn_mean[0][nbase + e] : 0.f;
+    is0[e] = (bwd_stats && n_ok) ? p.bn_invstd[0][nbase + e] : 0.f;
+    mu1[e] = (p.bn_y[1] && n_ok) ? p.bn_mean[1][nbase + e] : 0.f;
+    is1[e] = (p.bn_y[1] && n_ok) ? p.bn_invstd[1][nbase + e] : 0.f;
+  }
+  float s1[8], s2[8], s3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
+  T* __restrict__ dst = static_cast<T*>(p.dst);
+  const T* __restrict__ res = static_cast<const T*>(p.residual);
+  const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int r = r0 + ps * RPP;
+    const long long q = q0 + r;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg) ^ (r & 7)) << 4));
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg + 1) ^ (r & 7)) << 4));
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (q < p.Q && n_ok) {
+      const unsigned uq = (unsigned)q;
+      const unsigned img = fdiv(uq, p.div_pp);
+      const unsigned rem = uq - img * (unsigned)p.PP;
+      const unsigned hp = fdiv(rem, p.div_pw);
+      const unsigned wp = rem - hp * (unsigned)p.PW;
+      if (hp >= 1 && hp <= (unsigned)p.H && wp >= 1 && wp <= (unsigned)p.W) {
+        const long long off = ((((long long)img * p.H + (hp - 1)) * p.W + (wp - 1))) * p.N + nbase;
+        if (!bwd_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += v[e];
+            s2[e] += v[e] * v[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res) {
+          float rv[8];
+          QtVec8<T>::load(res + off, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (msk) {
+          float mv[8];
+          QtVec8<T>::load(msk + off, mv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+        }
+        QtVec8<T>::store(dst + off, v);
+        if (bwd_stats) {
+          float yv[8];
+          QtVec8<T>::load(static_cast<const T*>(p.bn_y[0]) + off, yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += v[e];
+            s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
+          }
+          if (p.bn_y[1]) {
+            QtVec8<T>::load(static_cast<const T*>(p.bn_y[1]) + off, yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
+          }
+        }
+      }
+    }
+  }
+
+  if (p.stats_partial || bwd_stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [RPP][BN][3]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(r0 * BN + cg * 8 + e) * 3 + 0] = s1[e];
+      red[(r0 * BN + cg * 8 + e) * 3 + 1] = s2[e];
+      red[(r0 * BN + cg * 8 + e) * 3 + 2] = s3[e];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float a = 0.f, b = 0.f, c = 0.f;
+      for (int r = 0; r < RPP; ++r) {
+        a += red[(r * BN + tid) * 3 + 0];
+        b += red[(r * BN + tid) * 3 + 1];
+        c += red[(r * BN + tid) * 3 + 2];
+      }
+      if (n0 + tid < p.N) {
+        float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
+        o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
+        o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
+        if (bwd_stats && p.bn_y[1]) {
+          p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
+          p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int BN>
 __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
   constexpr int BK = kRowBytes / (int)sizeof(T);
@@ -210,116 +328,7 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
     }
   __syncthreads();
 
-  constexpr int TPR = BN / 8;
-  constexpr int RPP = NT / TPR;
-  constexpr int NPASS = BM / RPP;
-  const int cg = tid % TPR, r0 = tid / TPR;
-  const int nbase = n0 + cg * 8;
-  const bool n_ok = nbase < p.N;
-  float sc[8], sh[8], mu0[8], is0[8], mu1[8], is1[8];
-  const bool bwd_stats = p.bn_y[0] != nullptr;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = (p.scale && n_ok) ? p.scale[nbase + e] : 1.f;
-    sh[e] = (p.shift && n_ok) ? p.shift[nbase + e] : 0.f;
-    mu0[e] = (bwd_stats && n_ok) ? p.bn_mean[0][nbase + e] : 0.f;
-    is0[e] = (bwd_stats && n_ok) ? p.bn_invstd[0][nbase + e] : 0.f;
-    mu1[e] = (p.bn_y[1] && n_ok) ? p.bn_mean[1][nbase + e] : 0.f;
-    is1[e] = (p.bn_y[1] && n_ok) ? p.bn_invstd[1][nbase + e] : 0.f;
-  }
-  float s1[8], s2[8], s3[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
-  T* __restrict__ dst = static_cast<T*>(p.dst);
-  const T* __restrict__ res = static_cast<const T*>(p.residual);
-  const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int r = r0 + ps * RPP;
-    const long long q = q0 + r;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg) ^ (r & 7)) << 4));
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg + 1) ^ (r & 7)) << 4));
-    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    if (q < p.Q && n_ok) {
-      const unsigned uq = (unsigned)q;
-      const unsigned img = fdiv(uq, p.div_pp);
-      const unsigned rem = uq - img * (unsigned)p.PP;
-      const unsigned hp = fdiv(rem, p.div_pw);
-      const unsigned wp = rem - hp * (unsigned)p.PW;
-      if (hp >= 1 && hp <= (unsigned)p.H && wp >= 1 && wp <= (unsigned)p.W) {
-        const long long off = ((((long long)img * p.H + (hp - 1)) * p.W + (wp - 1))) * p.N + nbase;
-        if (!bwd_stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * v[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-        if (res) {
-          float rv[8];
-          QtVec8<T>::load(res + off, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (msk) {
-          float mv[8];
-          QtVec8<T>::load(msk + off, mv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-        }
-        QtVec8<T>::store(dst + off, v);
-        if (bwd_stats) {
-          float yv[8];
-          QtVec8<T>::load(static_cast<const T*>(p.bn_y[0]) + off, yv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
-          }
-          if (p.bn_y[1]) {
-            QtVec8<T>::load(static_cast<const T*>(p.bn_y[1]) + off, yv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
-          }
-        }
-      }
-    }
-  }
-
-  if (p.stats_partial || bwd_stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [RPP][BN][3]
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[(r0 * BN + cg * 8 + e) * 3 + 0] = s1[e];
-      red[(r0 * BN + cg * 8 + e) * 3 + 1] = s2[e];
-      red[(r0 * BN + cg * 8 + e) * 3 + 2] = s3[e];
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float a = 0.f, b = 0.f, c = 0.f;
-      for (int r = 0; r < RPP; ++r) {
-        a += red[(r * BN + tid) * 3 + 0];
-        b += red[(r * BN + tid) * 3 + 1];
-        c += red[(r * BN + tid) * 3 + 2];
-      }
-      if (n0 + tid < p.N) {
-        float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
-        o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-        o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
-        if (bwd_stats && p.bn_y[1]) {
-          p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-          p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
-        }
-      }
-    }
-  }
+  patch_epilogue<T, BN, NT>(p, smem, q0, mt, n0, tid);
 }
 
 template <typename T, int BN>
@@ -362,7 +371,9 @@ int launch_patch(PatchArgs a, hipStream_t stream) {
 // Off by default: measured on MI355X (B=256, bf16) it only ties the generic kernel
 // (layer1 127 vs 119 us, layer2 109 vs 100 us): with one 8-wave workgroup per CU the load,
 // MFMA and epilogue phases of a tile do not overlap, while the generic kernel runs two
-// workgroups per CU.  QTCNN_PATCH_CONV=1 or qt_set_patch_conv(1) turns it on.
+// workgroups per CU.  A persistent filter-in-registers variant for the 64->64 layer (4 waves,
+// 288 weight VGPRs, double-buffered patch) was also measured: 200 us, slower still; it is in
+// the git history (commit "persistent layer1 kernel"), not in the tree.  QTCNN_PATCH_CONV=1 or qt_set_patch_conv(1) turns it on.
 static int g_patch_enabled = -1;
 extern "C" void qt_set_patch_conv(int enabled) { g_patch_enabled = enabled ? 1 : 0; }
 
