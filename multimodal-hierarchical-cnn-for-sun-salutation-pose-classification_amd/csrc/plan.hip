@@ -75,7 +75,9 @@ struct qt_plan {
   size_t xpad = 0, p0 = 0, argmax = 0, g_p0 = 0;
   size_t q = 0, dq = 0, fused = 0, dfused = 0, h1 = 0, dh1 = 0, hidden = 0, dhidden = 0;
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
-  size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;  // BatchNorm-backward partials emitted by dgrad epilogues
+  size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;
+  size_t dw_begin = 0, dw_end = 0;
+  bool dw_dirty = true;  // weight-gradient scratch holds sums of an earlier backward  // BatchNorm-backward partials emitted by dgrad epilogues
   // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
   // the launch stream around every igemm / wgrad launch while enabled
   struct Timed { hipEvent_t a, b; double flops; int kind; };
@@ -248,8 +250,15 @@ void layout_workspace(qt_plan* p) {
                        c.cls_kw, nullptr);
     c.w_fwd = ws.take(n * es);
     c.w_dgrad = ws.take(n * es);
+  }
+  // f32 [O][kh][kw][I] weight-gradient scratch of all convs, contiguous: zeroed by ONE memset per backward
+  p->dw_begin = ws.off;
+  for (size_t i = 0; i < p->convs.size(); ++i) {
+    ConvL& c = p->convs[i];
+    const size_t n = (i == 0) ? (size_t)64 * 8 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
     c.dw = ws.take(n * 4);
   }
+  p->dw_end = ws.off;
   for (LinL* l : {&p->cls0}) {
     l->w_fwd = ws.take((size_t)l->in * l->out * es);
     l->w_dgrad = ws.take((size_t)l->in * l->out * es);
@@ -685,8 +694,7 @@ struct Bwd : Exec {
       end_timed(slot, ws_);
       return;
     }
-    run(zero(at(c.dw), n * 4, ws_));
-    const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);
+    const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);  // c.dw was zeroed at the start of this backward
     run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, at<float>(c.dw), ws_));
     end_timed(slot, ws_);
     if (stem)
@@ -702,6 +710,11 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   e.p = p; e.ws = static_cast<unsigned char*>(workspace); e.T = T; e.stream = stream; e.B = p->last_batch;
   e.dt = p->d.dtype; e.G = G;
   e.setup_side();
+  if ((phases & QT_BWD_HEAD) || p->dw_dirty) {  // once per backward, before any weight-gradient launch
+    e.run(zero(e.at(p->dw_begin), p->dw_end - p->dw_begin, stream));
+    p->dw_dirty = false;
+  }
+  if (phases & QT_BWD_BACKBONE) p->dw_dirty = true;
   const int dt = e.dt;
   const int B = e.B;
   const bool tr = p->last_training != 0;
