@@ -173,6 +173,16 @@ int qt_stem_pool(int dtype, const void* y, const float* scale, const float* shif
                  unsigned char* argmax, int batch, void* stream);
 int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
                      const float* shift, void* g, int batch, void* stream);
+/* The same gradient fused with bn1's backward, without materialising it: _reduce emits
+ * qt_stem_bn_bwd_rows(batch) rows of partial sums for qt_bn_bwd_finalize, _apply writes
+ * d(loss)/d(conv1 output) directly. */
+int qt_stem_bn_bwd_rows(int batch);
+int qt_stem_bn_bwd_reduce(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          float* partial, int batch, void* stream);
+int qt_stem_bn_bwd_apply(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* coef, void* dy,
+                         int batch, void* stream);
 /* AdaptiveAvgPool2d(1,1)+flatten into columns [col0, col0+C) of the fused feature
  * matrix (Quadtree_from scratch/models.py:242,289-294) and its backward fused with the
  * ReLU mask of the pooled map. */

@@ -325,15 +325,34 @@ __global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restric
 }
 
 // g[n][h][w][c] = (y*scale+shift > 0) * sum over the <=4 pooled cells whose argmax is (h,w)
-template <typename T>
-__global__ void stem_pool_bwd_kernel(const T* __restrict__ dpooled, const unsigned char* __restrict__ argmax,
-                                     const T* __restrict__ y, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, T* __restrict__ g, int batch) {
+// MODE 0: store g.   MODE 1: BatchNorm-backward partial sums of g (nothing stored).
+// MODE 2: store dy = a*(g - b - xhat*c) directly.  Modes 1+2 never materialise g (411 MB at B=256).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void stem_pool_bwd_kernel(
+    const T* __restrict__ dpooled, const unsigned char* __restrict__ argmax, const T* __restrict__ y,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ coef, float* __restrict__ partial,
+    T* __restrict__ out, int batch) {
   constexpr int H = 112, W = 112, C = 64, PH = 56, PW = 56;
   const long long total = (long long)batch * H * W * (C / 8);
+  // gridDim.x * blockDim.x is a multiple of 8, so a thread keeps its channel group
+  const int c0 = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) % (C / 8)) * 8;
+  float sc[8], sh[8], mu[8], is[8], ca[8], cb[8], cc[8], s1[8], s2[8];
+  load8f(scale + c0, sc);
+  load8f(shift + c0, sh);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = mu[e] = is[e] = ca[e] = cb[e] = cc[e] = 0.f;
+  if (MODE >= 1) {
+    load8f(mean + c0, mu);
+    load8f(invstd + c0, is);
+  }
+  if (MODE == 2) {
+    load8f(coef + c0, ca);
+    load8f(coef + C + c0, cb);
+    load8f(coef + 2 * C + c0, cc);
+  }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % (C / 8)) * 8;
     const int w = (int)((i / (C / 8)) % W);
     const int h = (int)((i / ((C / 8) * W)) % H);
     const int n = (int)(i / ((long long)(C / 8) * W * H));
@@ -362,13 +381,43 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dpooled, const unsign
       }
     }
     const long long off = (((long long)n * H + h) * W + w) * C + c0;
-    float v[8], sc[8], sh[8];
+    float v[8];
     QtVec8<T>::load(y + off, v);
-    load8f(scale + c0, sc);
-    load8f(shift + c0, sh);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = (v[e] * sc[e] + sh[e] > 0.f) ? acc[e] : 0.f;
-    QtVec8<T>::store(g + off, acc);
+    if (MODE == 0) {
+      QtVec8<T>::store(out + off, acc);
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += acc[e];
+        s2[e] += acc[e] * (v[e] - mu[e]) * is[e];
+      }
+    } else {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = ca[e] * (acc[e] - cb[e] - (v[e] - mu[e]) * is[e] * cc[e]);
+      QtVec8<T>::store(out + off, o);
+    }
+  }
+  if (MODE == 1) {
+    __shared__ float red[32][64][2];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // blockDim.x == 256: 8 channel groups x 32 lanes
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[rl][cg * 8 + e][0] = s1[e];
+      red[rl][cg * 8 + e][1] = s2[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < 32; ++r) {
+        a += red[r][threadIdx.x][0];
+        b += red[r][threadIdx.x][1];
+      }
+      partial[((long long)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+      partial[((long long)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+    }
   }
 }
 
@@ -678,6 +727,21 @@ extern "C" int qt_stem_pool(int dtype, const void* y, const float* scale, const 
   return QT_OK;
 }
 
+template <typename T>
+static void launch_stem_bwd(int mode, int grid, hipStream_t s, const void* dpooled, const unsigned char* argmax,
+                            const void* y, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, const float* coef, float* partial, void* out, int batch) {
+  if (mode == 0)
+    hipLaunchKernelGGL((stem_pool_bwd_kernel<T, 0>), dim3(grid), dim3(256), 0, s, (const T*)dpooled, argmax, (const T*)y,
+                       scale, shift, mean, invstd, coef, partial, (T*)out, batch);
+  else if (mode == 1)
+    hipLaunchKernelGGL((stem_pool_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)dpooled, argmax, (const T*)y,
+                       scale, shift, mean, invstd, coef, partial, (T*)out, batch);
+  else
+    hipLaunchKernelGGL((stem_pool_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, s, (const T*)dpooled, argmax, (const T*)y,
+                       scale, shift, mean, invstd, coef, partial, (T*)out, batch);
+}
+
 extern "C" int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
                                 const float* scale, const float* shift, void* g, int batch, void* stream) {
   QT_DT_OK(dtype, "qt_stem_pool_bwd");
@@ -685,11 +749,47 @@ extern "C" int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned c
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for((long long)batch * 112 * 112 * 8);
   if (dtype == QT_F32)
-    hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dpooled, argmax,
-                       (const float*)y, scale, shift, (float*)g, batch);
+    launch_stem_bwd<float>(0, grid, s, dpooled, argmax, y, scale, shift, nullptr, nullptr, nullptr, nullptr, g, batch);
   else
-    hipLaunchKernelGGL(stem_pool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dpooled, argmax,
-                       (const bf16_t*)y, scale, shift, (bf16_t*)g, batch);
+    launch_stem_bwd<bf16_t>(0, grid, s, dpooled, argmax, y, scale, shift, nullptr, nullptr, nullptr, nullptr, g, batch);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+static int stem_bwd_rows(int batch) {
+  const long long blocks = ((long long)batch * 112 * 112 * 8 + 255) / 256;
+  return (int)(blocks > 2048 ? 2048 : blocks);
+}
+extern "C" int qt_stem_bn_bwd_rows(int batch) { return batch > 0 ? stem_bwd_rows(batch) : QT_ERR_INVALID_ARG; }
+
+extern "C" int qt_stem_bn_bwd_reduce(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     float* partial, int batch, void* stream) {
+  QT_DT_OK(dtype, "qt_stem_bn_bwd_reduce");
+  QT_CHECK_ARG(dpooled && argmax && y && scale && shift && mean && invstd && partial && batch > 0,
+               "qt_stem_bn_bwd_reduce: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = stem_bwd_rows(batch);
+  if (dtype == QT_F32)
+    launch_stem_bwd<float>(1, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, nullptr, partial, nullptr, batch);
+  else
+    launch_stem_bwd<bf16_t>(1, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, nullptr, partial, nullptr, batch);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_stem_bn_bwd_apply(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    const float* coef, void* dy, int batch, void* stream) {
+  QT_DT_OK(dtype, "qt_stem_bn_bwd_apply");
+  QT_CHECK_ARG(dpooled && argmax && y && scale && shift && mean && invstd && coef && dy && batch > 0,
+               "qt_stem_bn_bwd_apply: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)batch * 112 * 112 * 8);
+  if (dtype == QT_F32)
+    launch_stem_bwd<float>(2, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, coef, nullptr, dy, batch);
+  else
+    launch_stem_bwd<bf16_t>(2, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, coef, nullptr, dy, batch);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
