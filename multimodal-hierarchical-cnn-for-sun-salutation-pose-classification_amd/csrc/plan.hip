@@ -862,19 +862,12 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // ---- stem ----
     const ConvL& c0 = p->convs[0];
     const BnL& bn0 = p->bns[c0.bn];
-    {
-      // max-pool backward + ReLU mask + bn1 backward without materialising the 112x112 gradient
-      float* part = e.at<float>(p->stats);
-      e.run(qt_stem_bn_bwd_reduce(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
-                                  e.at<float>(bn0.shift), e.at<float>(bn0.mean), e.at<float>(bn0.invstd), part, B,
-                                  stream));
-      e.run(qt_bn_bwd_finalize(part, qt_stem_bn_bwd_rows(B), bn0.C, (long long)B * 112 * 112, e.tf(bn0.gamma),
-                               e.at<float>(bn0.invstd), e.gf(bn0.gamma), e.gf(bn0.beta), 0, e.at<float>(bn0.coef),
-                               stream));
-      e.run(qt_stem_bn_bwd_apply(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
-                                 e.at<float>(bn0.shift), e.at<float>(bn0.mean), e.at<float>(bn0.invstd),
-                                 e.at<float>(bn0.coef), e.at(c0.gy), B, stream));
-    }
+    // max-pool backward + ReLU mask, then bn1 backward.  (The fused qt_stem_bn_bwd_reduce/_apply
+    // pair, which never materialises this gradient, measured SLOWER on MI355X -- 2 x 333 us vs
+    // 260 + 87 + 120 us: the 4-cell argmax gather is ALU-heavy and would run twice.)
+    e.run(qt_stem_pool_bwd(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
+                           e.at<float>(bn0.shift), e.at(c0.gy), B, stream));
+    e.bn_backward(c0, e.at(c0.gy), nullptr);
     e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
   }
   e.join();
