@@ -183,3 +183,74 @@ def test_gradcam_hooks_on_layer4_match_oracle():
     # the Grad-CAM map itself (pooled-gradient weighting, grad_cam_analysis.py:306-316)
     cam = lambda a, g: torch.relu((g.mean((2, 3), keepdim=True) * a).sum(1))
     assert rel_err(cam(m.activations.cpu(), m.gradients.cpu()), cam(taps["layer4"].detach(), taps["layer4"].grad)) <= 1e-3
+
+
+def test_three_optimizer_steps_follow_the_oracle_trajectory():
+    """The reference's hot loop (Quadtree_train.py:62-66) for three steps, ragged batch of 6,
+    f32 build, dropout 0: losses must track the CPU oracle step by step (checks weight
+    re-packing after optimizer.step, running-stat updates, gradient hand-over to the optimizer).
+    SGD+momentum instead of the reference's Adam: Adam divides by sqrt(v), so parameters whose
+    gradient is at rounding level move by ~lr in a rounding-determined direction and the two
+    trajectories separate chaotically (measured 3e-4 after one step, 3e-3 after two)."""
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    B = 6
+    m = build("quadtree", torch.float32, dropout=0.0)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    opt = torch.optim.SGD(m.parameters(), lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    keys = o.trainable_keys(sd0, False)
+    sd = o.unique_params(sd0, keys)
+    opt_ref = torch.optim.SGD([sd[k] for k in keys], lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    got, ref = [], []
+    for step in range(3):
+        x = synth.synth_images(B, salt=20 + step)
+        f = synth.synth_pose_features(B, salt=20 + step)
+        y = synth.synth_labels(B, 12, salt=20 + step)
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(x.to(dev), f.to(dev)), y.to(dev))
+        loss.backward()
+        opt.step()
+        got.append(loss.item())
+        opt_ref.zero_grad()
+        lr = torch.nn.functional.cross_entropy(o.quadtree_forward(sd, x, f, train=True, dropout_p=0.0), y)
+        lr.backward()
+        opt_ref.step()
+        ref.append(lr.item())
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 3e-3 * max(1.0, abs(b)), (got, ref)
+    # eval after training uses the updated running statistics
+    m.eval()
+    x, f = synth.synth_images(2, salt=30), synth.synth_pose_features(2, salt=30)
+    with torch.no_grad():
+        e1 = m(x.to(dev), f.to(dev)).cpu()
+        e2 = o.quadtree_forward(sd, x, f)
+    assert rel_err(e1, e2) <= 5e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batch_growth_and_dropout_statistics(dt):
+    """The engine is rebuilt when the batch outgrows the plan; dropout keeps about half of the
+    hidden units in train() and is the identity in eval()."""
+    dev = _dev()
+    m = build("quadtree", dt, dropout=0.5).to(dev)
+    m.eval()
+    with torch.no_grad():
+        a = m(torch.randn(3, 3, 224, 224, device=dev), torch.randn(3, 47, device=dev))
+        b = m(torch.randn(9, 3, 224, 224, device=dev), torch.randn(9, 47, device=dev))
+    assert a.shape == (3, 12) and b.shape == (9, 12) and m._engine.max_batch >= 9
+    m.train()
+    x, f = torch.randn(8, 3, 224, 224, device=dev), torch.randn(8, 47, device=dev)
+    torch.manual_seed(1)
+    l1 = m(x, f)
+    hid = m._engine.buffer("hidden", (m._engine.max_batch, 2688))[:8].float()
+    frac_zero = float((hid == 0).float().mean())
+    assert 0.55 <= frac_zero <= 0.95  # ReLU zeros plus ~half of the rest dropped
+    torch.manual_seed(2)
+    l2 = m(x, f)
+    assert not torch.allclose(l1, l2)  # different dropout masks
+    torch.manual_seed(1)
+    l3 = m(x, f)
+    # same seed -> same mask (running stats moved a little, so compare loosely)
+    assert rel_err(l3.detach().cpu(), l1.detach().cpu()) < rel_err(l2.detach().cpu(), l1.detach().cpu())
