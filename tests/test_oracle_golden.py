@@ -70,3 +70,16 @@ def test_oracle_train_step(case, frozen, golden_train):
         if k.startswith(f"{case}/buf/") and k.endswith("/shape"):
             n = k[len(f"{case}/buf/"):-len("/shape")]
             check_summary(sd[n], golden_train, f"{case}/buf/{n}", 1e-5)
+
+
+def test_numpy_float64_restatement_agrees_with_reference(golden_eval):
+    """The torch-independent float64 restatement (oracle/numpy_ops.py) reproduces the reference's
+    own logits: operator definitions, BatchNorm constants, pooling semantics and concat order
+    are therefore pinned without going through ATen."""
+    import oracle.numpy_ops as nops
+    synth = pkg("synth")
+    x, f = synth.synth_images(2, salt=0), synth.synth_pose_features(2, salt=0)
+    logits = nops.quadtree_forward_eval(_sd(), x, f)
+    gold = golden_eval["qs_quadtree_eval/logits"].astype(np.float64)
+    # the reference ran in fp32: allow fp32 rounding through 20 layers
+    assert float(np.abs(logits - gold).max() / np.abs(gold).max()) <= 2e-5
