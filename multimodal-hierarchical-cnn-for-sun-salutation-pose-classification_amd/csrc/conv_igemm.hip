@@ -444,6 +444,8 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 // Measured (B=256, bf16): the 256-pixel tile only wins for K-loops of >= 36 steps; the
 // per-CU L2->LDS rate (~70 GB/s) bounds both shapes, and the short-K layers are dominated
 // by the per-tile prologue / epilogue, where two resident workgroups overlap better.
+// Also measured for N = 64: a 256x64 tile with four 64x64 wave tiles (fewer LDS reads per MFMA,
+// two workgroups per CU) runs 130 us against 117 us for the 128x64 tile (three per CU).
 inline int tile_m(long long M, int N, int ksteps) { return (M >= 256 * 256 && ksteps >= 36 && N > 64) ? 256 : 128; }
 
 template <typename T, bool DGRAD>
