@@ -96,9 +96,11 @@ typedef struct qt_conv_io {
   } bwd_bn[2];
 } qt_conv_io;
 
-/* Experimental: route 3x3 stride-1 convs of 56x56 / 28x28 maps through the LDS-resident-patch
- * kernel (csrc/conv_patch.hip) instead of the generic implicit GEMM.  Default off. */
-void qt_set_patch_conv(int enabled);
+/* 3x3 stride-1 convs with the input patch resident in LDS (csrc/conv_patch.hip) instead of the
+ * generic implicit GEMM: 0 never, 1 every eligible shape (56x56x64 and 28x28x128 inputs; the
+ * one-tile-per-workgroup kernel is experimental), 2 (default) only the persistent sliding-ring
+ * kernel for the 56x56 64->64 bf16 layers. */
+void qt_set_patch_conv(int mode);
 int qt_conv2d_stats_rows(const qt_conv_desc* desc);
 int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream);
 

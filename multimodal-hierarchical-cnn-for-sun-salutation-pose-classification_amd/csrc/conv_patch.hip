@@ -172,8 +172,13 @@ __device__ __forceinline__ void patch_epilogue(const PatchArgs& p, unsigned char
   }
 }
 
-template <typename T, int BN>
+// Geometry is compile time (map width WW, data-gradient flip, channel chunks, patch buffers): every
+// LDS fragment address is then a per-lane base plus an immediate, which removes the ~7 VALU
+// instructions per MFMA that a runtime row shift costs (measured with SQ_INSTS_VALU).
+template <typename T, int BN, int WW, bool FLIP, int NCHUNKS, int PBUFS>
 __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
+  constexpr int PW = WW + 2;
+  constexpr int PR = (BM + 2 * PW + 2 + 63) / 64 * 64;
   constexpr int BK = kRowBytes / (int)sizeof(T);
   constexpr int TM = 4;            // 64 positions per wave
   constexpr int TN = BN / 32;      // BN/2 channels per wave
@@ -191,10 +196,10 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
   const int mt = bid / p.gridN, nt = bid - mt * p.gridN;
   const long long q0 = (long long)mt * BM;
   const int n0 = nt * BN;
-  const int npass = p.PR >> 6;
-  const int PATCH_BYTES = p.PR * kRowBytes;
+  constexpr int npass = PR >> 6;
+  constexpr int PATCH_BYTES = PR * kRowBytes;
   const unsigned smem_base = lds_addr_of(smem);
-  const unsigned wring = smem_base + p.pbufs * PATCH_BYTES;   // weight ring behind the patch buffer(s)
+  const unsigned wring = smem_base + PBUFS * PATCH_BYTES;   // weight ring behind the patch buffer(s)
   const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
 
   // ---- patch rows staged by this thread: pointer to the pixel's channel 0 (+ this lane's chunk) ----
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
   for (int i = 0; i < MAXPASS; ++i) {
     prow[i] = nullptr;
     if (i < npass) {
-      const long long q = q0 - p.PW - 1 + (i * 64 + rbase);
+      const long long q = q0 - PW - 1 + (i * 64 + rbase);
       if (q >= 0 && q < p.Q) {
         const unsigned uq = (unsigned)q;
         const unsigned img = fdiv(uq, p.div_pp);
@@ -224,11 +229,11 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
     wrow[i] = n < p.N ? wgt + (long long)n * 9 * p.C + chunk * (16 / (int)sizeof(T)) : nullptr;
   }
 
-  const int nchunks = p.C / BK;
-  const int ngroups = nchunks * 3;   // a group = the three taps of one filter row of one chunk
+  constexpr int nchunks = NCHUNKS;
+  constexpr int ngroups = nchunks * 3;   // a group = the three taps of one filter row of one chunk
   constexpr int DG = 3 * DW;         // weight DMA instructions per wave per group
   constexpr int GSTAGE = 3 * WSTAGE;
-  const int pbufs = p.pbufs;         // 2: next chunk's patch is prefetched; 1: staged at the chunk seam
+  constexpr int pbufs = PBUFS;       // 2: next chunk's patch is prefetched; 1: staged at the chunk seam
   auto dma_patch = [&](int c) {
     const unsigned pb = smem_base + (pbufs == 2 ? (c & 1) : 0) * PATCH_BYTES + wave * (8 * kRowBytes);
 #pragma unroll
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
   dma_group(0);
   if (ngroups > 1) dma_group(1);
   if (ngroups > 2) dma_group(2);
+#pragma unroll
   for (int g = 0; g < ngroups; ++g) {
     const int c = g / 3, kh = g - c * 3;
     if (pbufs == 1 && kh == 0 && c > 0) {
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
     const unsigned char* sg = smem + pbufs * PATCH_BYTES + (g % 3) * GSTAGE;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      const int shift = p.flip ? (2 - kh) * p.PW + (2 - kw) : kh * p.PW + kw;
+      const int shift = FLIP ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
       const unsigned char* sw = sg + kw * WSTAGE;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -331,33 +337,27 @@ __global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
   patch_epilogue<T, BN, NT>(p, smem, q0, mt, n0, tid);
 }
 
-template <typename T, int BN>
+template <typename T, int BN, int WW, bool FLIP, int NCHUNKS, int PBUFS>
 int launch_patch(PatchArgs a, hipStream_t stream) {
-  int lds_loop = 2 * a.PR * kRowBytes + 9 * BN * kRowBytes;
-  a.pbufs = 2;
-  if (lds_loop > 160 * 1024 || a.C * (int)sizeof(T) <= kRowBytes) {  // one chunk, or no room: single buffer
-    a.pbufs = 1;
-    lds_loop = a.PR * kRowBytes + 9 * BN * kRowBytes;
-  }
-  const int lds_epi = BM * BN * 4;
-  const int red = (NT / (BN / 8)) * BN * 3 * 4;
-  int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  if (red > lds) lds = red;
-  if (lds > 160 * 1024) {
-    qt_set_error("conv_patch: %d B of LDS needed", lds);
-    return QT_ERR_UNSUPPORTED;
-  }
-  auto kern = conv_patch_kernel<T, BN>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
+  constexpr int PR = (BM + 2 * (WW + 2) + 2 + 63) / 64 * 64;
+  constexpr int lds_loop = PBUFS * PR * kRowBytes + 9 * BN * kRowBytes;
+  constexpr int lds_epi = BM * BN * 4;
+  constexpr int red = (NT / (BN / 8)) * BN * 3 * 4;
+  constexpr int lds = lds_loop > lds_epi ? (lds_loop > red ? lds_loop : red) : (lds_epi > red ? lds_epi : red);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv_patch_kernel<T, BN, WW, FLIP, NCHUNKS, PBUFS>;
+  static bool attr_done = false;
+  if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       qt_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
       return QT_ERR_LAUNCH;
     }
-    attr_lds = 160 * 1024;
+    attr_done = true;
   }
+  a.PR = PR;
+  a.pbufs = PBUFS;
   a.gridM = qt_cdiv(a.Q, BM);
   a.gridN = qt_cdiv(a.N, BN);
   hipLaunchKernelGGL(kern, dim3(a.gridM * a.gridN), dim3(NT), lds, stream, a);
@@ -365,35 +365,313 @@ int launch_patch(PatchArgs a, hipStream_t stream) {
   return QT_OK;
 }
 
+template <typename T, int WW, int NCHUNKS, int PBUFS>
+int launch_patch_flip(const PatchArgs& a, hipStream_t stream) {
+  return a.flip ? launch_patch<T, 64, WW, true, NCHUNKS, PBUFS>(a, stream)
+                : launch_patch<T, 64, WW, false, NCHUNKS, PBUFS>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant for ResNet layer1 (56x56 map, 64 -> 64 channels, bf16; forward and data
+// gradient).  One 8-wave workgroup per CU walks a CONTIGUOUS range of 256-position tiles:
+//   * the whole 3x3x64x64 filter stays in LDS (72 KB), loaded once per workgroup;
+//   * the input patch is a sliding window in a 640-row LDS ring (80 KB): consecutive tiles share
+//     their halo, so a tile fetches only its 256 new positions (32 KB), and the fetch of tile k+1
+//     is issued at the start of tile k (it lands behind 144 MFMAs per wave);
+//   * no LDS staging in the epilogue: a lane owns 4 consecutive channels of a position and
+//     stores them (8 bytes) itself; BatchNorm partial sums accumulate in registers over all tiles
+//     of the workgroup and are reduced once (one partial row per workgroup);
+//   * one barrier per tile.
+// Per tile and CU: 32 KB from L2 for 37.7 MFLOP (1150 FLOP/B) -- the kernel is no longer bound by
+// the L2->LDS path, and workgroup dispatch gaps / exposed prologues (what holds the one-tile-per-
+// workgroup kernel above back) disappear.
+// ---------------------------------------------------------------------------------------------
+constexpr int L1_PW = 58, L1_RING = 640, L1_WBYTES = 9 * 64 * kRowBytes, L1_RBYTES = L1_RING * kRowBytes;
+constexpr int L1_RED = L1_WBYTES + L1_RBYTES;           // [8 waves][2 i][4 fk][4 r][3] floats
+constexpr int L1_LDS = L1_RED + 8 * 2 * 4 * 4 * 3 * 4;
+
+template <bool FLIP>
+__global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const T* __restrict__ src = static_cast<const T*>(p.src);
+  const T* __restrict__ wgt = static_cast<const T*>(p.wgt);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int frow = lane & 15, fk = lane >> 4;
+  const int rbase = tid >> 3, chunk = (tid & 7) ^ (rbase & 7);
+  const unsigned smem_base = lds_addr_of(smem);
+  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
+
+  // contiguous tile range of this workgroup
+  const int ntiles = p.gridM, G = gridDim.x, b = blockIdx.x;
+  const int t0 = (int)((long long)b * ntiles / G), t1 = (int)((long long)(b + 1) * ntiles / G);
+  const int nt = t1 - t0;
+  if (nt <= 0) return;
+  const long long qstart = (long long)t0 * BM - (L1_PW + 1);   // padded position of ring index u = 0
+
+  // ring pass: 64 consecutive window indices [ub, ub+64), ub a multiple of 64
+  auto dma_ring = [&](int ub) {
+    const long long q = qstart + ub + rbase;
+    const T* g = zero_src;
+    if (q >= 0 && q < p.Q) {
+      const unsigned uq = (unsigned)q;
+      const unsigned img = fdiv(uq, p.div_pp);
+      const unsigned rem = uq - img * (unsigned)p.PP;
+      const unsigned hp = fdiv(rem, p.div_pw);
+      const unsigned wp = rem - hp * (unsigned)L1_PW;
+      if (hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u)
+        g = src + (((long long)img * 56 + (hp - 1)) * 56 + (wp - 1)) * 64 + chunk * 8;
+    }
+    const int rrow = __builtin_amdgcn_readfirstlane(ub % L1_RING);
+    glds16(g, smem_base + L1_WBYTES + (rrow + wave * 8) * kRowBytes);
+  };
+
+  // ---- prologue: filter (LDS row t*64 + n) and the first window ----
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    glds16(wgt + ((long long)rbase * 9 + t) * 64 + chunk * 8, smem_base + (t * 64 + wave * 8) * kRowBytes);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_ring(i * 64);
+
+  // per-lane epilogue constants: channels n = wn*32 + i*16 + fk*4 + r
+  float sc[2][4], sh[2][4], mu0[2][4], is0[2][4], mu1[2][4], is1[2][4];
+  const bool bwd_stats = p.bn_y[0] != nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wn * 32 + i * 16 + fk * 4 + r;
+      sc[i][r] = p.scale ? p.scale[n] : 1.f;
+      sh[i][r] = p.shift ? p.shift[n] : 0.f;
+      mu0[i][r] = bwd_stats ? p.bn_mean[0][n] : 0.f;
+      is0[i][r] = bwd_stats ? p.bn_invstd[0][n] : 0.f;
+      mu1[i][r] = p.bn_y[1] ? p.bn_mean[1][n] : 0.f;
+      is1[i][r] = p.bn_y[1] ? p.bn_invstd[1][n] : 0.f;
+    }
+  float s1[2][4], s2[2][4], s3[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = s3[i][r] = 0.f;
+  T* __restrict__ dst = static_cast<T*>(p.dst);
+  const T* __restrict__ res = static_cast<const T*>(p.residual);
+  const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  const unsigned char* ring = smem + L1_WBYTES;
+
+  int base = 0;  // (256*k) mod 640
+  for (int k = 0; k < nt; ++k) {
+    // this tile's window has landed; every wave is done reading the rows the next fetch replaces
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (k + 1 < nt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_ring(256 * k + 384 + i * 64);
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane_row = base + wm * 64 + frow;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      constexpr int kPW = L1_PW;
+      const int kh = t / 3, kw = t % 3;
+      const int shift = FLIP ? (2 - kh) * kPW + (2 - kw) : kh * kPW + kw;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 fw[2], fa[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = t * 64 + wn * 32 + i * 16 + frow;
+          fw[i] = *reinterpret_cast<const uint4*>(smem + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int rr = lane_row + j * 16 + shift;
+          rr = rr >= L1_RING ? rr - L1_RING : rr;
+          fa[j] = *reinterpret_cast<const uint4*>(ring + rr * kRowBytes + (((kk * 4 + fk) ^ (rr & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) QtMma<T>::run(acc[i][j], fw[i], fa[j]);
+      }
+    }
+    base += BM;
+    if (base >= L1_RING) base -= L1_RING;
+
+    // ---- epilogue straight from the accumulators ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long q = (long long)(t0 + k) * BM + wm * 64 + j * 16 + frow;
+      if (q >= p.Q) continue;
+      const unsigned uq = (unsigned)q;
+      const unsigned img = fdiv(uq, p.div_pp);
+      const unsigned rem = uq - img * (unsigned)p.PP;
+      const unsigned hp = fdiv(rem, p.div_pw);
+      const unsigned wp = rem - hp * (unsigned)L1_PW;
+      if (!(hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u)) continue;
+      const long long row = ((long long)img * 56 + (hp - 1)) * 56 + (wp - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long long off = row * 64 + wn * 32 + i * 16 + fk * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (!bwd_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[i][r] += v[r];
+            s2[i][r] += v[r] * v[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[i][r] + sh[i][r];
+        if (res) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + off);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (msk) {
+          const bf16x4 mv = *reinterpret_cast<const bf16x4*>(msk + off);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (float)mv[r] > 0.f ? v[r] : 0.f;
+        }
+        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(dst + off) = o;
+        if (bwd_stats) {
+          const bf16x4 yv = *reinterpret_cast<const bf16x4*>(static_cast<const T*>(p.bn_y[0]) + off);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[i][r] += v[r];
+            s2[i][r] += v[r] * ((float)yv[r] - mu0[i][r]) * is0[i][r];
+          }
+          if (p.bn_y[1]) {
+            const bf16x4 y2 = *reinterpret_cast<const bf16x4*>(static_cast<const T*>(p.bn_y[1]) + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s3[i][r] += v[r] * ((float)y2[r] - mu1[i][r]) * is1[i][r];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- BatchNorm partial sums: one row per workgroup ----
+  if (p.stats_partial || bwd_stats) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {  // over the 16 positions (lanes with equal fk)
+          s1[i][r] += __shfl_xor(s1[i][r], m, 64);
+          s2[i][r] += __shfl_xor(s2[i][r], m, 64);
+          s3[i][r] += __shfl_xor(s3[i][r], m, 64);
+        }
+      }
+    float* red = reinterpret_cast<float*>(smem + L1_RED);  // [wave][i][fk][r][3]
+    if (frow == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* d = red + ((((wave * 2 + i) * 4 + fk) * 4 + r) * 3);
+          d[0] = s1[i][r];
+          d[1] = s2[i][r];
+          d[2] = s3[i][r];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int n = tid, wn_ = n >> 5, i = (n >> 4) & 1, fk_ = (n >> 2) & 3, r = n & 3;
+      float a = 0.f, bb = 0.f, c = 0.f;
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const float* d = red + (((((wn_ * 4 + w4) * 2 + i) * 4 + fk_) * 4 + r) * 3);
+        a += d[0];
+        bb += d[1];
+        c += d[2];
+      }
+      float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
+      o0[((long long)b * 2 + 0) * 64 + n] = a;
+      o0[((long long)b * 2 + 1) * 64 + n] = bb;
+      if (bwd_stats && p.bn_y[1]) {
+        p.bn_partial[1][((long long)b * 2 + 0) * 64 + n] = a;
+        p.bn_partial[1][((long long)b * 2 + 1) * 64 + n] = c;
+      }
+    }
+  }
+}
+
+inline int l1_ring_grid(long long Q) {
+  const int ntiles = qt_cdiv(Q, BM);
+  return ntiles < 256 ? ntiles : 256;
+}
+
+template <bool FLIP>
+int launch_l1_ring(PatchArgs a, hipStream_t stream) {
+  auto kern = conv_l1_ring_kernel<FLIP>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS);
+    if (e != hipSuccess) {
+      qt_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return QT_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  a.gridM = qt_cdiv(a.Q, BM);
+  a.gridN = 1;
+  hipLaunchKernelGGL(kern, dim3(l1_ring_grid(a.Q)), dim3(NT), L1_LDS, stream, a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
 }  // namespace
 
 // Shapes this kernel takes over from the generic implicit GEMM (see qt_conv2d_igemm).
-// Off by default: measured on MI355X (B=256, bf16) it only ties the generic kernel
+// Mostly off by default (mode 2 = ring kernel only): measured on MI355X (B=256, bf16) it only ties the generic kernel
 // (layer1 127 vs 119 us, layer2 109 vs 100 us): with one 8-wave workgroup per CU the load,
 // MFMA and epilogue phases of a tile do not overlap, while the generic kernel runs two
 // workgroups per CU.  A persistent filter-in-registers variant for the 64->64 layer (4 waves,
 // 288 weight VGPRs, double-buffered patch) was also measured: 200 us, slower still; it is in
 // the git history (commit "persistent layer1 kernel"), not in the tree.  QTCNN_PATCH_CONV=1 or qt_set_patch_conv(1) turns it on.
 static int g_patch_enabled = -1;
-extern "C" void qt_set_patch_conv(int enabled) { g_patch_enabled = enabled ? 1 : 0; }
+extern "C" void qt_set_patch_conv(int mode) { g_patch_enabled = mode < 0 ? 2 : (mode > 2 ? 2 : mode); }
+
+static bool l1_ring_shape(const qt_conv_desc* d);
 
 bool qt_patch_eligible(const qt_conv_desc* d) {
   if (g_patch_enabled < 0) {
     const char* v = getenv("QTCNN_PATCH_CONV");
-    g_patch_enabled = v ? atoi(v) != 0 : 0;
+    g_patch_enabled = v ? atoi(v) : 2;
   }
+  // 0: never; 1: every eligible shape (experimental one-tile-per-workgroup kernel included);
+  // 2 (default): only the shape served by the persistent ring kernel, which is a measured win
   if (!g_patch_enabled) return false;
+  if (g_patch_enabled == 2 && !l1_ring_shape(d)) return false;
   const int bk = d->dtype == QT_F32 ? 32 : 64;
   return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && !d->quad && !d->dst_sub &&
-         d->in_h == d->out_h && d->in_w == d->out_w && d->in_h == d->in_w && (d->in_w == 56 || d->in_w == 28) &&
+         d->in_h == d->out_h && d->in_w == d->out_w && d->in_h == d->in_w &&
+         ((d->in_w == 56 && d->k_per_tap == 64) || (d->in_w == 28 && d->k_per_tap == 128)) &&
          d->k_per_tap % bk == 0 && d->n_out % 64 == 0 && d->src_pix_stride == d->k_per_tap &&
          d->src_row_stride == d->in_w * d->k_per_tap &&
          d->src_img_stride == (long long)d->in_h * d->in_w * d->k_per_tap &&
          (long long)d->batch * (d->in_h + 2) * (d->in_w + 2) < (1ll << 31);
 }
 
+static bool l1_ring_shape(const qt_conv_desc* d) {
+  return d->dtype == QT_BF16 && d->in_w == 56 && d->k_per_tap == 64 && d->n_out == 64;
+}
+
 int qt_patch_stats_rows(const qt_conv_desc* d) {
-  return qt_cdiv((long long)d->batch * (d->in_h + 2) * (d->in_w + 2), BM);
+  const long long Q = (long long)d->batch * (d->in_h + 2) * (d->in_w + 2);
+  if (l1_ring_shape(d)) return l1_ring_grid(Q);  // the persistent kernel emits one row per workgroup
+  return qt_cdiv(Q, BM);
 }
 
 int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
@@ -410,11 +688,14 @@ int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   a.Q = (long long)a.B * a.PP;
   a.flip = d->mode == QT_CONV_DGRAD;
   a.relu = d->relu;
-  a.PR = (BM + 2 * a.PW + 2 + 63) / 64 * 64;
   a.div_pp = make_fastdiv((unsigned)a.PP);
   a.div_pw = make_fastdiv((unsigned)a.PW);
   a.gridM = a.gridN = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // 64-channel tiles: all nine taps of a chunk fit the LDS ring, three taps per barrier
-  return d->dtype == QT_BF16 ? launch_patch<bf16_t, 64>(a, s) : launch_patch<float, 64>(a, s);
+  if (l1_ring_shape(d)) return a.flip ? launch_l1_ring<true>(a, s) : launch_l1_ring<false>(a, s);
+  // 64-channel tiles: all nine taps of a chunk fit the LDS ring, three taps per barrier.
+  // bf16: one 64-channel chunk per 128 bytes; f32: 32 channels per chunk.
+  if (d->dtype == QT_BF16)
+    return a.W == 56 ? launch_patch_flip<bf16_t, 56, 1, 1>(a, s) : launch_patch_flip<bf16_t, 28, 2, 2>(a, s);
+  return a.W == 56 ? launch_patch_flip<float, 56, 2, 1>(a, s) : launch_patch_flip<float, 28, 4, 2>(a, s);
 }
