@@ -308,6 +308,52 @@ struct Exec {
   int B;
   int dt;
   int status = QT_OK;
+  size_t stats_off = (size_t)-1;  // BatchNorm partial-sum scratch in use ((size_t)-1: p->stats)
+
+  // ---- plan-owned side stream: independent branches run next to the caller's stream ----
+  void* wstream = nullptr;  // == stream when the side stream is off
+  bool forked = false;
+  void hip(hipError_t e, const char* what) {
+    if (e != hipSuccess && status == QT_OK) {
+      qt_set_error("%s: %s", what, hipGetErrorString(e));
+      status = QT_ERR_LAUNCH;
+    }
+  }
+  void setup_side() {
+    wstream = stream;
+    if (!p->use_side) return;
+    if (!p->side) {
+      hip(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking), "hipStreamCreate");
+      hip(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
+      hip(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (ok()) wstream = p->side;
+  }
+  // everything enqueued on `stream` so far happens before later side-stream work
+  void fork() {
+    if (!wstream || wstream == stream || !ok()) return;
+    hip(hipEventRecord(p->ev_fork, static_cast<hipStream_t>(stream)), "hipEventRecord");
+    hip(hipStreamWaitEvent(p->side, p->ev_fork, 0), "hipStreamWaitEvent");
+    forked = true;
+  }
+  // side-stream work happens before anything enqueued on `stream` afterwards
+  void join() {
+    if (wstream == stream || !wstream || !forked || !ok()) return;
+    hip(hipEventRecord(p->ev_join, p->side), "hipEventRecord");
+    hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join, 0), "hipStreamWaitEvent");
+    forked = false;
+  }
+
+  // run `body` with every launch going to the side stream (after fork()), with its own stats scratch
+  template <typename F> void on_side(size_t scratch, F&& body) {
+    void* main_stream = stream;
+    const size_t main_stats = stats_off;
+    stream = wstream ? wstream : stream;
+    stats_off = scratch;
+    body();
+    stream = main_stream;
+    stats_off = main_stats;
+  }
 
   template <typename X = void> X* at(size_t off) const { return reinterpret_cast<X*>(ws + off); }
   float* tf(int idx) const { return idx < 0 ? nullptr : static_cast<float*>(T[idx]); }
@@ -427,10 +473,11 @@ struct Exec {
   void conv_bn_stats(const ConvL& c, const qt_conv_desc& d, const void* src, bool training) {
     BnL& bn = p->bns[c.bn];
     if (training) {
-      igemm(d, src, at(c.w_fwd), at(c.y), nullptr, nullptr, nullptr, nullptr, at<float>(p->stats), 0);
+      float* part = at<float>(stats_off == (size_t)-1 ? p->stats : stats_off);
+      igemm(d, src, at(c.w_fwd), at(c.y), nullptr, nullptr, nullptr, nullptr, part, 0);
       if (!ok()) return;
       const int rows = qt_conv2d_stats_rows(&d);
-      run(qt_bn_finalize(at<float>(p->stats), rows, bn.C, rows_of(c), tf(bn.gamma), tf(bn.beta), tf(bn.rmean),
+      run(qt_bn_finalize(part, rows, bn.C, rows_of(c), tf(bn.gamma), tf(bn.beta), tf(bn.rmean),
                          tf(bn.rvar), static_cast<long long*>(T[bn.nbt]), p->d.bn_momentum, p->d.bn_eps,
                          at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.scale), at<float>(bn.shift), stream));
     } else {
@@ -464,9 +511,33 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
 int forward(qt_plan* p, void* workspace, void* const* T, const float* image, const float* numerical, float* logits,
             int batch, int training, unsigned long long seed, void* stream) {
   Exec e{p, static_cast<unsigned char*>(workspace), T, stream, batch, p->d.dtype};
+  e.setup_side();
   const int dt = e.dt;
   const bool tr = training != 0;
   hipStream_t hs = static_cast<hipStream_t>(stream);
+  // The quadrant head (needs layer3's output) and the numerical MLP (needs nothing) are independent
+  // of layer4: they run on the side stream and are joined before the classifier.
+  auto quad_branch = [&]() {
+    const ConvL& cq = p->convs[p->quad_conv];
+    e.igemm(e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), e.at(cq.w_fwd), e.at(p->q), nullptr, e.tf(cq.bias),
+            nullptr, nullptr, nullptr, 1);
+    e.run(qt_quad_pool(dt, e.at(p->q), e.at(p->fused), batch, p->fused_ld, 512, e.stream));
+  };
+  auto mlp_branch = [&]() {
+    qt_gemm_small_desc g;
+    memset(&g, 0, sizeof(g));
+    g.M = batch; g.N = p->mlp0.out; g.K = p->mlp0.in;
+    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+    g.a_row_stride = p->mlp0.in; g.a_k_stride = 1; g.b_row_stride = p->mlp0.in; g.b_k_stride = 1;
+    g.c_row_stride = p->mlp0.out; g.relu = 1;
+    e.run(qt_gemm_small(&g, numerical, e.tf(p->mlp0.w), e.tf(p->mlp0.b), e.at(p->h1), e.stream));
+    if (tr && p->d.dropout_p > 0.f)
+      e.run(qt_dropout(QT_F32, e.at(p->h1), batch, p->mlp0.out, p->mlp0.out, seed, p->d.dropout_p, e.stream));
+    g.N = p->mlp1.out; g.K = p->mlp1.in;
+    g.a_row_stride = p->mlp1.in; g.b_row_stride = p->mlp1.in; g.c_dtype = dt; g.c_row_stride = p->fused_ld; g.relu = 0;
+    e.run(qt_gemm_small(&g, e.at(p->h1), e.tf(p->mlp1.w), e.tf(p->mlp1.b),
+                        e.at<unsigned char>(p->fused) + (size_t)p->mlp_col0 * p->esz, e.stream));
+  };
   if (p->has_image) {
     // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
     e.run(qt_pack_stem_input(dt, image, e.at(p->xpad), batch, stream));
@@ -492,6 +563,18 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
       const BnL& b2 = p->bns[c2.bn];
       const qt_conv_desc d1 = e.conv_desc(c1, QT_CONV_FWD), d2 = e.conv_desc(c2, QT_CONV_FWD);
       const long long M = e.rows_of(c2);
+      if (blk.ds >= 0) {
+        const ConvL& cd = p->convs[blk.ds];
+        const BnL& bd = p->bns[cd.bn];
+        const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
+        e.fork();
+        e.on_side(p->stats_ds, [&] {
+          e.conv_bn_stats(cd, dd, e.at(x), tr);
+          if (!tr)
+            e.igemm(dd, e.at(x), e.at(cd.w_fwd), e.at(cd.y), e.at<float>(bd.scale), e.at<float>(bd.shift), nullptr,
+                    nullptr, nullptr, 0);
+        });
+      }
       e.conv_bn_stats(c1, d1, e.at(x), tr);
       if (tr) {
         e.run(qt_bn_act(dt, e.at(c1.y), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr, nullptr, nullptr, 1,
@@ -500,22 +583,25 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         e.igemm(d1, e.at(x), e.at(c1.w_fwd), e.at(blk.a1), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr,
                 nullptr, nullptr, 1);
       }
-      e.conv_bn_stats(c2, d2, e.at(blk.a1), tr);
       if (blk.ds >= 0) {
+        // the 1x1 downsample branch only needs the block input: it runs on the side stream next
+        // to conv1 -> BN -> conv2 and is joined before the residual add
         const ConvL& cd = p->convs[blk.ds];
         const BnL& bd = p->bns[cd.bn];
         const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
-        e.conv_bn_stats(cd, dd, e.at(x), tr);
+        // (fork happened before conv1, see below)
+        e.conv_bn_stats(c2, d2, e.at(blk.a1), tr);
+        e.join();
         if (tr) {
           e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(cd.y),
                           e.at<float>(bd.scale), e.at<float>(bd.shift), 1, e.at(blk.out), M, c2.cout, stream));
         } else {
-          e.igemm(dd, e.at(x), e.at(cd.w_fwd), e.at(cd.y), e.at<float>(bd.scale), e.at<float>(bd.shift), nullptr,
-                  nullptr, nullptr, 0);
           e.igemm(d2, e.at(blk.a1), e.at(c2.w_fwd), e.at(blk.out), e.at<float>(b2.scale), e.at<float>(b2.shift),
                   e.at(cd.y), nullptr, nullptr, 1);
         }
+        (void)dd;
       } else {
+        e.conv_bn_stats(c2, d2, e.at(blk.a1), tr);
         if (tr) {
           e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(x), nullptr, nullptr, 1,
                           e.at(blk.out), M, c2.cout, stream));
@@ -525,32 +611,19 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         }
       }
       x = blk.out;
+      if (&blk == &p->blocks[5] && !p->standard) {  // layer3 is done: start the side branches
+        e.fork();
+        e.on_side(p->stats_ds, [&] {
+          quad_branch();
+          if (p->has_numerical) mlp_branch();
+        });
+      }
     }
     // ---- global branch: avgpool(layer4) -> fused[:, 0:512] ----
     e.run(qt_avgpool(dt, e.at(p->blocks[7].out), e.at(p->fused), batch, 49, 512, p->fused_ld, 0, stream));
-    // ---- quadrant branch on layer3's output ----
-    if (!p->standard) {
-      const ConvL& cq = p->convs[p->quad_conv];
-      e.igemm(e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), e.at(cq.w_fwd), e.at(p->q), nullptr, e.tf(cq.bias),
-              nullptr, nullptr, nullptr, 1);
-      e.run(qt_quad_pool(dt, e.at(p->q), e.at(p->fused), batch, p->fused_ld, 512, stream));
-    }
   }
-  if (p->has_numerical) {
-    qt_gemm_small_desc g;
-    memset(&g, 0, sizeof(g));
-    g.M = batch; g.N = p->mlp0.out; g.K = p->mlp0.in;
-    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
-    g.a_row_stride = p->mlp0.in; g.a_k_stride = 1; g.b_row_stride = p->mlp0.in; g.b_k_stride = 1;
-    g.c_row_stride = p->mlp0.out; g.relu = 1;
-    e.run(qt_gemm_small(&g, numerical, e.tf(p->mlp0.w), e.tf(p->mlp0.b), e.at(p->h1), stream));
-    if (tr && p->d.dropout_p > 0.f)
-      e.run(qt_dropout(QT_F32, e.at(p->h1), batch, p->mlp0.out, p->mlp0.out, seed, p->d.dropout_p, stream));
-    g.N = p->mlp1.out; g.K = p->mlp1.in;
-    g.a_row_stride = p->mlp1.in; g.b_row_stride = p->mlp1.in; g.c_dtype = dt; g.c_row_stride = p->fused_ld; g.relu = 0;
-    e.run(qt_gemm_small(&g, e.at(p->h1), e.tf(p->mlp1.w), e.tf(p->mlp1.b),
-                        e.at<unsigned char>(p->fused) + (size_t)p->mlp_col0 * p->esz, stream));
-  }
+  if (p->has_numerical && !p->has_image) mlp_branch();  // numerical_only: nothing to overlap with
+  e.join();  // quadrant + MLP columns of the fused matrix are complete
   // ---- classifier: Linear -> ReLU -> Dropout -> Linear ----
   e.igemm(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD), e.at(p->fused), e.at(p->cls0.w_fwd), e.at(p->hidden),
           nullptr, e.tf(p->cls0.b), nullptr, nullptr, nullptr, 1);
@@ -647,40 +720,6 @@ struct Bwd : Exec {
     }
     return rows;
   }
-  // ---- side stream for the weight gradients ----
-  void* wstream = nullptr;  // == stream when the side stream is off
-  bool forked = false;
-  void hip(hipError_t e, const char* what) {
-    if (e != hipSuccess && status == QT_OK) {
-      qt_set_error("%s: %s", what, hipGetErrorString(e));
-      status = QT_ERR_LAUNCH;
-    }
-  }
-  void setup_side() {
-    wstream = stream;
-    if (!p->use_side) return;
-    if (!p->side) {
-      hip(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking), "hipStreamCreate");
-      hip(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
-      hip(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming), "hipEventCreate");
-    }
-    if (ok()) wstream = p->side;
-  }
-  // everything enqueued on `stream` so far happens before later side-stream work
-  void fork() {
-    if (wstream == stream || !ok()) return;
-    hip(hipEventRecord(p->ev_fork, static_cast<hipStream_t>(stream)), "hipEventRecord");
-    hip(hipStreamWaitEvent(p->side, p->ev_fork, 0), "hipStreamWaitEvent");
-    forked = true;
-  }
-  // side-stream work happens before anything enqueued on `stream` afterwards
-  void join() {
-    if (!forked || !ok()) return;
-    hip(hipEventRecord(p->ev_join, p->side), "hipEventRecord");
-    hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join, 0), "hipStreamWaitEvent");
-    forked = false;
-  }
-
   // weight gradient of conv c: dy = c.gy, x = src
   void wgrad(const ConvL& c, const qt_conv_desc& fwd_desc, const void* src, bool stem) {
     if (!ok() || !gf(c.w)) return;
