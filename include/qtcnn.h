@@ -236,13 +236,15 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *   qt_plan_backward     : loss.backward() of Quadtree_train.py:65 given dlogits;
  *                          grads[i] (f32, same layout as tensors[i]) is written
  *                          (not accumulated) when non-NULL; QT_BWD_HEAD = classifier,
- *                          numerical MLP and quadrant head, QT_BWD_BACKBONE = ResNet
- *                          stages and stem (lets the caller start the gradient
- *                          all-reduce of the head while the backbone runs).
+ *                          numerical MLP and quadrant head, QT_BWD_LAYER4 = layer4,
+ *                          QT_BWD_REST = layers 3..1 and the stem (lets the caller start the
+ *                          gradient all-reduce of a bucket while the next phase runs).
  * ------------------------------------------------------------------------ */
 enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1 };
 enum { QT_MODE_FUSION = 0, QT_MODE_IMAGE_ONLY = 1, QT_MODE_NUMERICAL_ONLY = 2 };
-enum { QT_BWD_HEAD = 1, QT_BWD_BACKBONE = 2, QT_BWD_ALL = 3 };
+/* QT_BWD_BACKBONE = QT_BWD_LAYER4 | QT_BWD_REST; call order HEAD, LAYER4, REST (or any union of
+ * consecutive phases in one call). */
+enum { QT_BWD_HEAD = 1, QT_BWD_LAYER4 = 2, QT_BWD_REST = 4, QT_BWD_BACKBONE = 6, QT_BWD_ALL = 7 };
 
 typedef struct qt_plan_desc {
   int dtype;
@@ -273,6 +275,11 @@ int qt_plan_find_buffer(const qt_plan* plan, const char* name, size_t* offset);
  * and launch counts per kind {0 igemm forward, 1 igemm dgrad, 2 wgrad}. */
 int qt_plan_profile_begin(qt_plan* plan);
 int qt_plan_profile_end(qt_plan* plan, double* flops3, double* ms3, int* launches3);
+/* Weight gradients run on a plan-owned side stream; a partial qt_plan_backward phase returns
+ * without joining it.  Before consuming that phase's gradients on another stream (the
+ * all-reduce stream), make it wait for the side stream with qt_plan_side_fence (and for the
+ * caller's stream as usual).  The last phase joins the side stream into the caller's stream. */
+int qt_plan_side_fence(qt_plan* plan, void* waiting_stream);
 int qt_plan_init_workspace(qt_plan* plan, void* workspace, void* stream);
 int qt_plan_pack_weights(qt_plan* plan, void* workspace, void* const* tensors, int for_backward, void* stream);
 int qt_plan_forward(qt_plan* plan, void* workspace, void* const* tensors, const float* image, const float* numerical,

@@ -7,7 +7,11 @@ every product entry point raises.
 import ctypes
 import os
 
-import torch  # noqa: F401  (loads the process-wide HIP runtime first)
+# Side stream + RCCL streams need more than ROCm's default 4 hardware queues to really overlap
+# (see bench.py); only effective if the HIP runtime has not been initialised yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: F401,E402  (loads the process-wide HIP runtime first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqtcnn_hip.so")

@@ -77,7 +77,8 @@ struct qt_plan {
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
   size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;
   size_t dw_begin = 0, dw_end = 0;
-  bool dw_dirty = true;  // weight-gradient scratch holds sums of an earlier backward  // BatchNorm-backward partials emitted by dgrad epilogues
+  bool dw_dirty = true;  // weight-gradient scratch holds sums of an earlier backward
+  int bwd_rows_bn2 = 0;  // carried from the layer4 phase to the rest-of-backbone phase  // BatchNorm-backward partials emitted by dgrad epilogues
   // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
   // the launch stream around every igemm / wgrad launch while enabled
   struct Timed { hipEvent_t a, b; double flops; int kind; };
@@ -753,7 +754,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     e.run(zero(e.at(p->dw_begin), p->dw_end - p->dw_begin, stream));
     p->dw_dirty = false;
   }
-  if (phases & QT_BWD_BACKBONE) p->dw_dirty = true;
+  if (phases & QT_BWD_REST) p->dw_dirty = true;
   const int dt = e.dt;
   const int B = e.B;
   const bool tr = p->last_training != 0;
@@ -841,14 +842,24 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     }
   }
 
-  if (!(phases & QT_BWD_BACKBONE)) e.join();  // a phase-wise caller reduces the head bucket next
+  // (no join after a partial phase: the caller orders its consumer behind the side stream with
+  //  qt_plan_side_fence, so the main chain never stalls on the weight-gradient stream)
 
+  // The backbone can be run in two calls -- QT_BWD_LAYER4 (blocks 7, 6: 8.4 M of the 11.2 M backbone
+  // parameters) then QT_BWD_REST -- so that a data-parallel caller can start reducing layer4's
+  // gradients while layers 3..1 and the stem are still running.
   if ((phases & QT_BWD_BACKBONE) && backbone_grads) {
-    // gradient of layer4's output through avgpool (+ ReLU mask of the block output)
-    e.run(qt_avgpool_bwd(dt, e.at(p->dfused), e.at(p->blocks[7].out), e.at(p->blocks[7].gout), B, 49, 512, p->fused_ld,
-                         0, stream));
+    const bool do_l4 = (phases & QT_BWD_LAYER4) != 0, do_rest = (phases & QT_BWD_REST) != 0;
     int rows_bn2 = 0;  // partial rows of bn2 / downsample-BN of the block being entered (0 = none yet)
-    for (int bi = 7; bi >= 0; --bi) {
+    if (do_l4) {
+      // gradient of layer4's output through avgpool (+ ReLU mask of the block output)
+      e.run(qt_avgpool_bwd(dt, e.at(p->dfused), e.at(p->blocks[7].out), e.at(p->blocks[7].gout), B, 49, 512,
+                           p->fused_ld, 0, stream));
+    } else {
+      rows_bn2 = p->bwd_rows_bn2;
+    }
+    const int bi_hi = do_l4 ? 7 : 5, bi_lo = do_rest ? 0 : 6;
+    for (int bi = bi_hi; bi >= bi_lo; --bi) {
       const Block& blk = p->blocks[bi];
       const ConvL& c1 = p->convs[blk.conv1];
       const ConvL& c2 = p->convs[blk.conv2];
@@ -898,6 +909,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks);
       if (bi == 0) rows_bn2 = 0;
     }
+    p->bwd_rows_bn2 = rows_bn2;
+    if (do_rest) {
     // ---- stem ----
     const ConvL& c0 = p->convs[0];
     const BnL& bn0 = p->bns[c0.bn];
@@ -908,8 +921,13 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
                            e.at<float>(bn0.shift), e.at(c0.gy), B, stream));
     e.bn_backward(c0, e.at(c0.gy), nullptr);
     e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
+    }
   }
-  e.join();
+  // the last phase (or a head-only model) joins: afterwards the caller's stream sees every gradient
+  if ((phases & QT_BWD_REST) || !backbone_grads) {
+    e.forked = e.forked || (p->side != nullptr && e.wstream == p->side);
+    e.join();
+  }
   return e.status;
 }
 
@@ -1020,6 +1038,22 @@ extern "C" int qt_plan_profile_end(qt_plan* p, double* flops, double* ms, int* l
   }
   p->timed.clear();
   return st;
+}
+
+// Make `waiting_stream` wait for everything enqueued so far on the plan's side stream (the
+// weight gradients of the phases already issued).  No-op when the side stream is not in use.
+extern "C" int qt_plan_side_fence(qt_plan* p, void* waiting_stream) {
+  QT_CHECK_ARG(p, "qt_plan_side_fence: null plan");
+  if (!p->side || !p->use_side) return QT_OK;
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventRecord(ev, p->side) != hipSuccess ||
+      hipStreamWaitEvent(static_cast<hipStream_t>(waiting_stream), ev, 0) != hipSuccess) {
+    qt_set_error("qt_plan_side_fence: HIP error");
+    return QT_ERR_LAUNCH;
+  }
+  (void)hipEventDestroy(ev);  // destruction is deferred until the event has completed
+  return QT_OK;
 }
 
 extern "C" int qt_plan_init_workspace(qt_plan* p, void* workspace, void* stream) {

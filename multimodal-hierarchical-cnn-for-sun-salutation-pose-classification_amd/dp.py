@@ -4,11 +4,12 @@ gradient all-reduce (RCCL over xGMI; `nccl` backend of torch.distributed) per
 step.  The reference has no distributed code at all; message
 sizes and overlap plan are in SURVEY.md 8(e).
 
-The plan's backward hands over its flat f32 gradient buffer in two buckets, in
+The plan's backward hands over its flat f32 gradient buffer in three buckets, in
 the order they become final:
-  phase 1 (head)      classifier + numerical MLP + quadrant conv  (~57 % of the bytes,
-                      ready before any backbone kernel has run)
-  phase 2 (backbone)  ResNet-18 stages + stem
+  head      classifier + numerical MLP + quadrant conv  (59 MB, 57 % of the bytes,
+            ready before any backbone kernel has run)
+  layer4    33.6 MB, ready after the first two residual blocks of backward
+  rest      layers 3..1 + stem, 11 MB: the only bucket whose reduction is not hidden
 Each bucket is averaged across ranks on a dedicated communication stream while
 the compute stream continues with the backbone backward; the compute stream
 waits for the communication stream once, at the end of backward.  BatchNorm
@@ -35,20 +36,23 @@ class GradBucketReducer:
         self.world = dist.get_world_size(process_group)
         self.comm_stream = None
         self.bytes_reduced = 0
+        self.force = False  # exercise the collective even with one rank (rehearsal)
         self._avg_ok = dist.get_backend(process_group) == "nccl"
 
-    def __call__(self, bucket, phase):
+    def __call__(self, bucket, phase, side_fence=None):
         if bucket is None:
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
             return
         self.bytes_reduced += bucket.numel() * bucket.element_size()
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if bucket.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=bucket.device)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if side_fence is not None:   # the bucket's weight gradients come from the plan's side stream
+                side_fence(self.comm_stream)
             bucket.record_stream(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
                 if self.average and self._avg_ok:
@@ -80,6 +84,8 @@ def attach_data_parallel(model, process_group=None, broadcast=True):
     if broadcast:
         broadcast_state(model, 0, process_group)
     model._grad_sync = GradBucketReducer(process_group)
+    import os
+    model._grad_sync.force = os.environ.get("QTCNN_FORCE_DIST") == "1"  # "2": phases only, no collective
     if getattr(model, "_engine", None) is not None:
         model._engine.grad_sync = model._grad_sync
     return model

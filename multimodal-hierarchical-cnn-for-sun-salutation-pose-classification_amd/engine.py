@@ -15,7 +15,7 @@ from ._lib import QtError
 
 QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET = 0, 1
 MODES = {"fusion": 0, "image_only": 1, "numerical_only": 2}
-QT_BWD_HEAD, QT_BWD_BACKBONE = 1, 2
+QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_REST, QT_BWD_ALL = 1, 2, 4, 7
 
 
 class PlanDesc(ctypes.Structure):
@@ -56,6 +56,7 @@ def _bind_api(L):
                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p]
     L.qt_plan_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.qt_plan_side_fence.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.qt_plan_find_buffer.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
     L._plan_bound = True
 
@@ -118,6 +119,11 @@ class PlanEngine:
         n = int(torch.Size(shape).numel()) * (2 if self.dtype == torch.bfloat16 else 4)
         return self.workspace[base:base + n].view(self.dtype).view(shape)
 
+    def side_fence(self, torch_stream):
+        """Make `torch_stream` wait for the plan's weight-gradient stream (see qt_plan_side_fence)."""
+        _lib.check(self.L.qt_plan_side_fence(self.handle, ctypes.c_void_p(torch_stream.cuda_stream)),
+                   "qt_plan_side_fence")
+
     def buffer_ld(self, name):
         """Row length (elements) of the fused feature matrix / its gradient."""
         if name in ("fused", "dfused"):
@@ -161,16 +167,23 @@ class PlanEngine:
     def backward(self, dlogits, numerical, wanted):
         """wanted: list of (plan tensor index, shape) in the order gradients are
         returned.  Gradients are views of one flat f32 buffer laid out
-        [head | backbone] so a data-parallel caller can all-reduce two buckets."""
-        head = [w for w in wanted if not self.names[w[0]].startswith("base_cnn.")]
-        body = [w for w in wanted if self.names[w[0]].startswith("base_cnn.")]
+        [head | layer4 | rest of the backbone]: the order in which backward finishes them, so a
+        data-parallel caller all-reduces three buckets, each while the next phase runs."""
+        def bucket_of(idx):
+            name = self.names[idx]
+            if not name.startswith("base_cnn."):
+                return 0
+            return 1 if name.startswith("base_cnn.layer4.") else 2
+        order = sorted(wanted, key=lambda w: bucket_of(w[0]))  # stable: keeps parameter order inside a bucket
         sizes = {idx: int(torch.Size(shape).numel()) for idx, shape in wanted}
         # keep every view 16-byte aligned
-        offs, total = {}, 0
-        for idx, _ in head + body:
+        offs, total, ends = {}, 0, [0, 0, 0]
+        for idx, _ in order:
             offs[idx] = total
             total += (sizes[idx] + 3) // 4 * 4
-        head_elems = sum((sizes[i] + 3) // 4 * 4 for i, _ in head)
+            ends[bucket_of(idx)] = total
+        ends[1] = max(ends[1], ends[0])
+        ends[2] = max(ends[2], ends[1])
         flat = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
         grad_ptrs = (ctypes.c_void_p * len(self.names))()
         views = {}
@@ -178,16 +191,22 @@ class PlanEngine:
             v = flat[offs[idx]:offs[idx] + sizes[idx]].view(shape)
             views[idx] = v
             grad_ptrs[idx] = v.data_ptr()
-        for phase in (QT_BWD_HEAD, QT_BWD_BACKBONE):
+
+        def run(phase):
             _lib.check(self.L.qt_plan_backward(self.handle, self.ws_ptr, self._tensor_ptrs, grad_ptrs,
                                                _lib.ptr(numerical), _lib.ptr(dlogits), phase, _lib.stream_ptr()),
                        "qt_plan_backward")
-            if self.grad_sync is not None:
-                bucket = flat[:head_elems] if phase == QT_BWD_HEAD else flat[head_elems:total]
-                if bucket.numel():
-                    self.grad_sync(bucket, phase)
-        if self.grad_sync is not None:
-            self.grad_sync(None, 0)  # join
+
+        if self.grad_sync is None:
+            run(QT_BWD_ALL)
+        else:
+            begin = 0
+            for b, phase in enumerate((QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_REST)):
+                run(phase)
+                if ends[b] > begin:
+                    self.grad_sync(flat[begin:ends[b]], phase, self.side_fence)
+                begin = ends[b]
+            self.grad_sync(None, 0, None)  # join
         return [views[idx] for idx, _ in wanted]
 
 
