@@ -110,6 +110,10 @@ int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream
  * (Quadtree_from scratch/Quadtree_train.py:65).  `dw` must be zeroed (or hold the
  * running sum) by the caller: partial tiles are added with f32 atomics. */
 int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* stream);
+/* bf16 3x3 / stride 1 / pad 1 weight gradients of images at least `min_width` wide take the
+ * streaming kernel (csrc/conv_wgrad_patch.hip: one workgroup accumulates all nine taps of a
+ * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default. */
+void qt_set_wgrad_patch_min_width(int min_width);
 
 /* ------------------------------------------------------------------------
  * Layout packing (HBM-bound).

@@ -371,6 +371,10 @@ int launch(WgradArgs a, hipStream_t stream) {
 
 }  // namespace
 
+// conv_wgrad_patch.hip: streaming kernel for 3x3 / stride 1 / pad 1 (bf16)
+bool qt_wgrad_patch_eligible(const qt_conv_desc* d);
+int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream);
+
 extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
   QT_CHECK_ARG(d && dy && x && dw, "qt_conv2d_wgrad: null argument");
   QT_CHECK_ARG(d->dtype == QT_F32 || d->dtype == QT_BF16, "qt_conv2d_wgrad: bad dtype %d", d->dtype);
@@ -392,6 +396,7 @@ extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void
   a.div_ow = make_fastdiv((unsigned)d->out_w);
   a.tilesN = a.tilesC = a.gtaps = a.ksplit = a.pix_per_split = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (qt_wgrad_patch_eligible(d)) return qt_wgrad_patch_launch(d, dy, x, dw, stream);
   // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
   const bool stem = d->k_per_tap == 32 && d->kw == 1 && d->kh == 7 && d->n_out == 64;
   if (d->dtype == QT_BF16) {

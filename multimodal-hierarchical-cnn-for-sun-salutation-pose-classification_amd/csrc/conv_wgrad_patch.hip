@@ -1,0 +1,275 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution as a streaming "patch" kernel (bf16).
+//
+// Replaces the conv2d backward-weight ATen calls of loss.backward()
+// (/root/reference/Quadtree_from scratch/Quadtree_train.py:65) for the BasicBlock convolutions of the
+// backbone (/root/reference/Quadtree_from scratch/models.py:222-229 -> torchvision resnet18 layer1..3).
+//
+//   dW[o][kh][kw][i] = sum_g dY[g][o] * X[g + (kh-1)*PW + (kw-1)][i]
+//
+// g runs over ZERO-PADDED positions (PW = W+2 columns, PH = H+2 rows per image, images back to
+// back), so a filter tap is a constant shift of the position index and all nine taps read the SAME
+// rows of X.  The generic kernel (conv_wgrad.hip) makes one workgroup per (tap, tile) and therefore
+// fetches dY and X nine times (32 FLOP per byte staged for 64x64 tiles); here one workgroup owns a
+// 64(o) x 64(i) x 9(taps) accumulator (144 VGPRs per lane over 4 waves) and streams its range of
+// positions once: 288 FLOP per staged byte.
+//
+//   * X rows live in an LDS ring of NX 32-row chunks (row = position, 128 B = 64 channels), dY rows in
+//     a ring of ND chunks; both are filled by LDS-DMA (global_load_lds_dwordx4, halo / out-of-image
+//     positions come from the zero page), D chunks ahead of the MFMAs, one barrier per chunk.
+//   * pixel-major MFMA fragments come from ds_read_b64_tr_b16; the 32-byte-block XOR swizzle of
+//     conv_wgrad.hip sits on the DMA source side.  A tap only moves the row a lane reads.
+//   * the range of positions is split over workgroups (one per CU); partial filters are added
+//     with f32 atomics into the zeroed gradient, as in the generic kernel.
+#include <stdlib.h>
+
+#include "qt_common.h"
+
+namespace {
+
+struct WPArgs {
+  const bf16_t* dy;
+  const bf16_t* x;
+  float* dw;
+  long long x_is, dy_is;  // image strides (elements)
+  int x_rs, x_ps, dy_rs, dy_ps;
+  int N, KC, H, W, PW, PH, B, PP;
+  int total;              // B * PP padded positions
+  int pps, nsplit, tiles, tilesC;
+  int halo;               // rows of X kept on each side of a chunk: ceil32(PW + 1)
+  int adv_h, adv_w;       // 32 positions = adv_h padded rows + adv_w columns
+  FastDiv div_pp, div_pw;
+};
+
+// walks padded positions 32 at a time and keeps the element offset of the (unpadded) source pixel
+struct PosWalk {
+  int img, ph, pw;
+  long long off;
+  __device__ __forceinline__ void init(int g, const WPArgs& p, long long is, int rs, int ps, int coff) {
+    const unsigned gg = (unsigned)(g + p.PP);  // callers keep g >= -PP
+    const unsigned q = fdiv(gg, p.div_pp);
+    const unsigned rem = gg - q * (unsigned)p.PP;
+    img = (int)q - 1;
+    ph = (int)fdiv(rem, p.div_pw);
+    pw = (int)rem - ph * p.PW;
+    off = (long long)img * is + (long long)(ph - 1) * rs + (long long)(pw - 1) * ps + coff;
+  }
+  __device__ __forceinline__ bool valid(const WPArgs& p) const {
+    return (unsigned)img < (unsigned)p.B && (unsigned)(ph - 1) < (unsigned)p.H && (unsigned)(pw - 1) < (unsigned)p.W;
+  }
+  __device__ __forceinline__ void advance(const WPArgs& p, long long adv_off, long long wrap_w, long long wrap_h) {
+    pw += p.adv_w;
+    ph += p.adv_h;
+    off += adv_off;
+    if (pw >= p.PW) {
+      pw -= p.PW;
+      ++ph;
+      off += wrap_w;
+    }
+    if (ph >= p.PH) {
+      ph -= p.PH;
+      ++img;
+      off += wrap_h;
+    }
+  }
+};
+
+__device__ __forceinline__ QT_LDS_AS s16x4* lds_tr_ptr(unsigned lds_byte) {
+  return (QT_LDS_AS s16x4*)(size_t)lds_byte;
+}
+
+constexpr int WP_CH = 32;          // positions per chunk (one MFMA K-step)
+constexpr int WP_CHB = WP_CH * 128;  // bytes of a chunk: 32 rows x 64 bf16
+
+template <int D, int NX, int ND>
+__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
+  static_assert((NX & (NX - 1)) == 0 && (ND & (ND - 1)) == 0, "rings are powers of two");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr unsigned XRING = NX * WP_CHB;  // X ring at LDS byte 0 (power of two: wrap = AND)
+  const unsigned smem_base = lds_addr_of(smem);
+  if (smem_base != 0) return;  // no static LDS in this kernel; addresses below are absolute
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // whole position ranges per XCD; the tiles of one range run back to back on it (they share
+  // the dY / X slices in that XCD's L2)
+  int split, tile;
+  if ((p.nsplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / p.tiles) * 8 + xcd;
+    tile = slot % p.tiles;
+  } else {
+    split = blockIdx.x % p.nsplit;
+    tile = blockIdx.x / p.nsplit;
+  }
+  const int tc = tile % p.tilesC, tn = tile / p.tilesC;
+  const int n0 = tn * 64, c0 = tc * 64;
+  const int p0 = split * p.pps;
+  if (p0 >= p.total) return;
+  const int pend = min(p.total, p0 + p.pps);
+  const int nsteps = (pend - p0 + WP_CH - 1) / WP_CH;
+  const int L = p.halo >> 4;  // X chunks ahead of the dY chunk: 2 * halo / 32
+
+  // ---- DMA side: thread = (row of the chunk, 16-byte LDS slot); swizzle on the source ----
+  const int drow = tid >> 3, dslot = tid & 7;
+  const int dkey = (drow >> 1) & 3;
+  const int dchunk = (((dslot >> 1) ^ dkey) << 1) | (dslot & 1);
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(qt_zero_page);
+  PosWalk wx, wy;
+  wx.init(p0 - p.halo + drow, p, p.x_is, p.x_rs, p.x_ps, c0 + dchunk * 8);
+  wy.init(p0 - 2 * p.halo + drow, p, p.dy_is, p.dy_rs, p.dy_ps, n0 + dchunk * 8);
+  const long long x_adv = (long long)p.adv_h * p.x_rs + (long long)p.adv_w * p.x_ps;
+  const long long x_ww = (long long)p.x_rs - (long long)p.PW * p.x_ps;
+  const long long x_wh = p.x_is - (long long)p.PH * p.x_rs;
+  const long long y_adv = (long long)p.adv_h * p.dy_rs + (long long)p.adv_w * p.dy_ps;
+  const long long y_ww = (long long)p.dy_rs - (long long)p.PW * p.dy_ps;
+  const long long y_wh = p.dy_is - (long long)p.PH * p.dy_rs;
+  int unit = 0;  // next unit to issue: X chunk `unit`, dY chunk `unit - L`
+  auto issue = [&]() {
+    const bf16_t* gx = wx.valid(p) ? p.x + wx.off : zero_src;
+    glds16(gx, (unsigned)((unit & (NX - 1)) * WP_CHB + wave * 1024));
+    const bf16_t* gy = (unit >= L && wy.valid(p)) ? p.dy + wy.off : zero_src;
+    glds16(gy, XRING + (unsigned)(((unit - L) & (ND - 1)) * WP_CHB + wave * 1024));
+    wx.advance(p, x_adv, x_ww, x_wh);
+    wy.advance(p, y_adv, y_ww, y_wh);
+    ++unit;
+  };
+
+  // ---- MFMA side ----
+  const int li = lane & 15, lg = lane >> 4;
+  const int q = li >> 2, pp = li & 3;
+  const int lrow = 4 * lg + q;  // second transposing read: lrow + 16 (same swizzle key)
+  // dY fragment addresses inside a stage (hi half = +2048 B)
+  unsigned a_rel[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_rel[i] = XRING + lrow * 128 + ((i ^ ((lrow >> 1) & 3)) << 5) + pp * 8;
+  // X fragment addresses per tap (absolute LDS bytes, advanced by one chunk per step)
+  unsigned b_lo[9], b_hi[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int s = (t / 3 - 1) * p.PW + (t % 3 - 1);
+    const int r = p.halo + s + lrow;  // >= 0: halo >= PW + 1
+    const unsigned k = (unsigned)(r >> 1) & 3u;
+    const unsigned col = (((unsigned)wave ^ k) << 5) + pp * 8;
+    b_lo[t] = (((unsigned)r * 128u) & (XRING - 1)) + col;
+    b_hi[t] = (((unsigned)(r + 16) * 128u) & (XRING - 1)) + col;
+  }
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int u = 0; u < L + D; ++u) issue();
+
+  for (int c = 0; c < nsteps; ++c) {
+    issue();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * D) : "memory");
+    const unsigned sbase = (unsigned)((c & (ND - 1)) * WP_CHB);
+    uint4 fa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(a_rel[i] + sbase));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(a_rel[i] + sbase + 2048));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(b_lo[t]));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(b_hi[t]));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      const uint4 fb = make_uint4(l2.x, l2.y, h2.x, h2.y);
+      b_lo[t] = (b_lo[t] + WP_CHB) & (XRING - 1);
+      b_hi[t] = (b_hi[t] + WP_CHB) & (XRING - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                            __builtin_bit_cast(bf16x8, fb), acc[i][t], 0, 0, 0);
+    }
+  }
+  // the look-ahead units are still in flight: they must land before this workgroup's LDS is reused
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- accumulate: lane holds o = 16*i + 4*lg + r, input channel 16*wave + li of every tap ----
+  const int cc = c0 + wave * 16 + li;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + i * 16 + lg * 4 + r;
+      float* row = p.dw + (long long)n * 9 * p.KC + cc;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(row + t * p.KC, acc[i][t][r]);
+    }
+}
+
+int g_wgrad_patch_min_w = -1;  // smallest image width routed here; 0 = off
+
+int min_w() {
+  if (g_wgrad_patch_min_w < 0) {
+    const char* e = getenv("QTCNN_WGRAD_PATCH_MIN_W");
+    g_wgrad_patch_min_w = e ? atoi(e) : 14;
+  }
+  return g_wgrad_patch_min_w;
+}
+
+constexpr int kD = 4, kNX = 16, kND = 8;
+
+}  // namespace
+
+// Smallest image width whose 3x3 stride-1 weight gradients take the streaming kernel
+// (0 = never; default 14 = every eligible layer, env QTCNN_WGRAD_PATCH_MIN_W).
+extern "C" void qt_set_wgrad_patch_min_width(int w) { g_wgrad_patch_min_w = w < 0 ? 14 : w; }
+
+bool qt_wgrad_patch_eligible(const qt_conv_desc* d) {
+  const int mw = min_w();
+  if (mw <= 0 || d->dtype != QT_BF16) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->quad) return false;
+  if (d->in_h != d->out_h || d->in_w != d->out_w) return false;
+  if (d->n_out % 64 || d->k_per_tap % 64) return false;
+  if (d->out_w < mw || d->out_w < 14 || d->out_h < 14 || d->out_w > 120) return false;
+  if ((long long)d->batch * (d->out_h + 2) * (d->out_w + 2) >= (1ll << 30)) return false;
+  return true;
+}
+
+int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+  WPArgs a;
+  a.dy = static_cast<const bf16_t*>(dy);
+  a.x = static_cast<const bf16_t*>(x);
+  a.dw = dw;
+  a.N = d->n_out; a.KC = d->k_per_tap; a.H = d->out_h; a.W = d->out_w; a.B = d->batch;
+  a.PW = a.W + 2; a.PH = a.H + 2; a.PP = a.PW * a.PH;
+  a.x_is = d->src_img_stride; a.x_rs = d->src_row_stride; a.x_ps = d->src_pix_stride;
+  a.dy_ps = a.N; a.dy_rs = a.W * a.N; a.dy_is = (long long)a.H * a.dy_rs;
+  a.total = a.B * a.PP;
+  a.halo = (a.PW + 1 + 31) / 32 * 32;
+  QT_CHECK_ARG(2 * a.halo <= a.PP && a.halo / 16 + kD + 2 <= kNX, "qt_conv2d_wgrad: image %dx%d does not fit the streaming kernel", a.H, a.W);
+  a.adv_h = WP_CH / a.PW; a.adv_w = WP_CH % a.PW;
+  a.div_pp = make_fastdiv((unsigned)a.PP);
+  a.div_pw = make_fastdiv((unsigned)a.PW);
+  a.tilesC = a.KC / 64;
+  a.tiles = (a.N / 64) * a.tilesC;
+  int nsplit = 256 / a.tiles;
+  if (nsplit < 1) nsplit = 1;
+  int pps = qt_cdiv(a.total, nsplit);
+  pps = qt_cdiv(pps, WP_CH) * WP_CH;
+  a.pps = pps;
+  a.nsplit = qt_cdiv(a.total, pps);
+  if (a.nsplit >= 6 && (a.nsplit & 7)) a.nsplit = qt_cdiv(a.nsplit, 8) * 8;  // empty tail ranges exit at once
+  constexpr int LDS = (kNX + kND) * WP_CHB;
+  auto kern = conv_wgrad_patch_kernel<kD, kNX, kND>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return QT_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(256), LDS, static_cast<hipStream_t>(stream), a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

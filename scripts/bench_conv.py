@@ -65,3 +65,14 @@ if __name__ == "__main__":
             bench(kind, B, 7, 512, 512, 3, 1, 1)
             bench(kind, B, 56, 64, 128, 3, 2, 1)
             bench(kind, B, 56, 64, 128, 1, 2, 0)
+    if which == "wgrad":
+        for mw in (0, 14):   # 0: generic kernel, 14: streaming kernel wherever eligible
+            L.lib().qt_set_wgrad_patch_min_width(mw)
+            print("qt_set_wgrad_patch_min_width", mw, flush=True)
+            bench("wgrad", B, 56, 64, 64, 3, 1, 1)
+            bench("wgrad", B, 28, 128, 128, 3, 1, 1)
+            bench("wgrad", B, 14, 256, 256, 3, 1, 1)
+    if which == "wgrad1":   # streaming kernel only (QTCNN_WP_* env experiments)
+        L.lib().qt_set_wgrad_patch_min_width(14)
+        bench("wgrad", B, 56, 64, 64, 3, 1, 1)
+        bench("wgrad", B, 28, 128, 128, 3, 1, 1)

@@ -241,6 +241,59 @@ def test_conv_wgrad(dt, cfg):
     assert rel_err(got, ref) <= 3e-5  # f32 accumulation of exactly representable products
 
 
+@pytest.mark.parametrize("cfg", [
+    (3, 64, 64, 56),      # layer1
+    (5, 128, 128, 28),    # layer2: four channel tiles share a range of positions
+    (9, 64, 128, 28),     # ragged batch, rectangular channel tiles
+    (2, 256, 256, 14),    # layer3: 16 tiles, 30 % padding overhead
+    (300, 64, 64, 14),    # more ranges than workgroups' worth of images: ranges cut through images
+])
+def test_conv_wgrad_streaming_kernel(cfg):
+    """3x3 / stride 1 weight gradient with all nine taps accumulated by one workgroup
+    (csrc/conv_wgrad_patch.hip) against torch.nn.grad.conv2d_weight and against the generic kernel."""
+    dev = _dev()
+    L = pkg("_lib")
+    dt = torch.bfloat16
+    B, Cin, Cout, H = cfg
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    dy = torch.randn(B, Cout, H, H, generator=g).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, 1, 1)
+    xd, dyd = nhwc(x).to(dev, dt), nhwc(dy).to(dev, dt)
+    try:
+        L.lib().qt_set_wgrad_patch_min_width(14)
+        dw = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1)
+        L.lib().qt_set_wgrad_patch_min_width(0)
+        dw_generic = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1)
+    finally:
+        L.lib().qt_set_wgrad_patch_min_width(-1)
+    got = dw.cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= 3e-5
+    assert rel_err(dw.cpu(), dw_generic.cpu()) <= 3e-5
+
+
+def test_conv_wgrad_streaming_kernel_channel_slice():
+    """X is a 64-channel slice of a wider NHWC tensor (explicit strides), as the plan's views are."""
+    dev = _dev()
+    L = pkg("_lib")
+    dt = torch.bfloat16
+    B, Cw, C, N, H = 2, 192, 64, 64, 56
+    g = torch.Generator().manual_seed(15)
+    wide = torch.randn(B, H, H, Cw, generator=g).to(dt)
+    dy = torch.randn(B, N, H, H, generator=g).to(dt).float()
+    xs = wide[..., 64:128].float().permute(0, 3, 1, 2).contiguous()
+    ref = torch.nn.grad.conv2d_weight(xs, (N, C, 3, 3), dy, 1, 1)
+    wd = wide.to(dev)
+    try:
+        L.lib().qt_set_wgrad_patch_min_width(14)
+        dw = run_wgrad(L, dt, nhwc(dy).to(dev, dt), wd.view(-1)[64:], B, (H, H), (H, H), C, N, 3, 3, 1, 1,
+                       strides=(H * H * Cw, H * Cw, Cw))
+    finally:
+        L.lib().qt_set_wgrad_patch_min_width(-1)
+    got = dw.cpu().view(N, 3, 3, C).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= 3e-5
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_quadrant_wgrad(dt):
     dev = _dev()
