@@ -110,6 +110,13 @@ int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream
  * (Quadtree_from scratch/Quadtree_train.py:65).  `dw` must be zeroed (or hold the
  * running sum) by the caller: partial tiles are added with f32 atomics. */
 int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* stream);
+/* Same, with a caller-owned scratch buffer of qt_conv2d_wgrad_workspace_bytes(desc) bytes (0: this
+ * shape does not use one).  With it the streaming kernel writes one partial filter per range of
+ * positions with plain stores and a second kernel adds them to `dw` in a fixed order: no atomics,
+ * bit-reproducible.  A NULL or too small workspace falls back to the atomic accumulation. */
+size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* desc);
+int qt_conv2d_wgrad_ws(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* workspace,
+                       size_t workspace_bytes, void* stream);
 /* bf16 3x3 / stride 1 / pad 1 weight gradients of images at least `min_width` wide take the
  * streaming kernel (csrc/conv_wgrad_patch.hip: one workgroup accumulates all nine taps of a
  * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default. */

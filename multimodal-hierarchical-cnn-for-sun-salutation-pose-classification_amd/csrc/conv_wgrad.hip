@@ -373,10 +373,22 @@ int launch(WgradArgs a, hipStream_t stream) {
 
 // conv_wgrad_patch.hip: streaming kernel for 3x3 / stride 1 / pad 1 (bf16)
 bool qt_wgrad_patch_eligible(const qt_conv_desc* d);
-int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream);
+size_t qt_wgrad_patch_workspace_bytes(const qt_conv_desc* d);
+int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+extern "C" size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* d) {
+  return d ? qt_wgrad_patch_workspace_bytes(d) : 0;
+}
 
 extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+  return qt_conv2d_wgrad_ws(d, dy, x, dw, nullptr, 0, stream);
+}
+
+extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   QT_CHECK_ARG(d && dy && x && dw, "qt_conv2d_wgrad: null argument");
+  QT_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "qt_conv2d_wgrad_ws: misaligned workspace");
   QT_CHECK_ARG(d->dtype == QT_F32 || d->dtype == QT_BF16, "qt_conv2d_wgrad: bad dtype %d", d->dtype);
   QT_CHECK_ARG(d->mode == QT_CONV_FWD, "qt_conv2d_wgrad: describe the FORWARD convolution (mode QT_CONV_FWD)");
   QT_CHECK_ARG(d->n_out > 0 && d->n_out % 8 == 0 && d->k_per_tap > 0 && d->k_per_tap % 8 == 0,
@@ -396,7 +408,7 @@ extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void
   a.div_ow = make_fastdiv((unsigned)d->out_w);
   a.tilesN = a.tilesC = a.gtaps = a.ksplit = a.pix_per_split = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (qt_wgrad_patch_eligible(d)) return qt_wgrad_patch_launch(d, dy, x, dw, stream);
+  if (qt_wgrad_patch_eligible(d)) return qt_wgrad_patch_launch(d, dy, x, dw, workspace, workspace_bytes, stream);
   // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
   const bool stem = d->k_per_tap == 32 && d->kw == 1 && d->kh == 7 && d->n_out == 64;
   if (d->dtype == QT_BF16) {

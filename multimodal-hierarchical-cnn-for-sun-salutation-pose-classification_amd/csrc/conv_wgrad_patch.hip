@@ -30,6 +30,7 @@ struct WPArgs {
   const bf16_t* dy;
   const bf16_t* x;
   float* dw;
+  float* part;            // [nsplit][N][9][KC] partial filters (plain stores) or NULL: atomics into dw
   long long x_is, dy_is;  // image strides (elements)
   int x_rs, x_ps, dy_rs, dy_ps;
   int N, KC, H, W, PW, PH, B, PP;
@@ -77,19 +78,26 @@ __device__ __forceinline__ QT_LDS_AS s16x4* lds_tr_ptr(unsigned lds_byte) {
   return (QT_LDS_AS s16x4*)(size_t)lds_byte;
 }
 
-constexpr int WP_CH = 32;          // positions per chunk (one MFMA K-step)
-constexpr int WP_CHB = WP_CH * 128;  // bytes of a chunk: 32 rows x 64 bf16
+constexpr int WP_CH = 32;  // positions per MFMA K-step
 
-template <int D, int NX, int ND>
-__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
+// G = wave groups per workgroup (4 waves each).  A macro-chunk is 32*G consecutive positions: all
+// waves stage it together, group g contracts rows [32g, 32g+32) of it, so with G = 2 every SIMD
+// holds two waves that cover each other's LDS reads and address arithmetic.  The groups' partial
+// filters are summed through LDS before they leave the workgroup.
+template <int G, int D, int NX, int ND>
+__global__ __launch_bounds__(256 * G) void conv_wgrad_patch_kernel(WPArgs p) {
   static_assert((NX & (NX - 1)) == 0 && (ND & (ND - 1)) == 0, "rings are powers of two");
+  static_assert(G == 1 || G == 2, "one or two wave groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr unsigned XRING = NX * WP_CHB;  // X ring at LDS byte 0 (power of two: wrap = AND)
+  constexpr int MCR = WP_CH * G;              // rows of a macro-chunk
+  constexpr int MCB = MCR * 128;              // its bytes (64 bf16 channels per row)
+  constexpr unsigned XRING = NX * MCB;        // X ring at LDS byte 0 (power of two: wrap = AND)
   const unsigned smem_base = lds_addr_of(smem);
   if (smem_base != 0) return;  // no static LDS in this kernel; addresses below are absolute
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = wave >> 2, wq = wave & 3;
 
   // whole position ranges per XCD; the tiles of one range run back to back on it (they share
   // the dY / X slices in that XCD's L2)
@@ -107,10 +115,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
   const int p0 = split * p.pps;
   if (p0 >= p.total) return;
   const int pend = min(p.total, p0 + p.pps);
-  const int nsteps = (pend - p0 + WP_CH - 1) / WP_CH;
-  const int L = p.halo >> 4;  // X chunks ahead of the dY chunk: 2 * halo / 32
+  const int nsteps = (pend - p0 + MCR - 1) / MCR;
+  const int L = (2 * p.halo) / MCR;  // X macro-chunks ahead of the dY macro-chunk
 
-  // ---- DMA side: thread = (row of the chunk, 16-byte LDS slot); swizzle on the source ----
+  // ---- DMA side: thread = (row of the macro-chunk, 16-byte LDS slot); swizzle on the source ----
   const int drow = tid >> 3, dslot = tid & 7;
   const int dkey = (drow >> 1) & 3;
   const int dchunk = (((dslot >> 1) ^ dkey) << 1) | (dslot & 1);
@@ -124,12 +132,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
   const long long y_adv = (long long)p.adv_h * p.dy_rs + (long long)p.adv_w * p.dy_ps;
   const long long y_ww = (long long)p.dy_rs - (long long)p.PW * p.dy_ps;
   const long long y_wh = p.dy_is - (long long)p.PH * p.dy_rs;
-  int unit = 0;  // next unit to issue: X chunk `unit`, dY chunk `unit - L`
+  int unit = 0;  // next unit to issue: X macro-chunk `unit`, dY macro-chunk `unit - L`
   auto issue = [&]() {
     const bf16_t* gx = wx.valid(p) ? p.x + wx.off : zero_src;
-    glds16(gx, (unsigned)((unit & (NX - 1)) * WP_CHB + wave * 1024));
+    glds16(gx, (unsigned)((unit & (NX - 1)) * MCB + wave * 1024));
     const bf16_t* gy = (unit >= L && wy.valid(p)) ? p.dy + wy.off : zero_src;
-    glds16(gy, XRING + (unsigned)(((unit - L) & (ND - 1)) * WP_CHB + wave * 1024));
+    glds16(gy, XRING + (unsigned)(((unit - L) & (ND - 1)) * MCB + wave * 1024));
     wx.advance(p, x_adv, x_ww, x_wh);
     wy.advance(p, y_adv, y_ww, y_wh);
     ++unit;
@@ -138,19 +146,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
   // ---- MFMA side ----
   const int li = lane & 15, lg = lane >> 4;
   const int q = li >> 2, pp = li & 3;
-  const int lrow = 4 * lg + q;  // second transposing read: lrow + 16 (same swizzle key)
+  const int lrow = WP_CH * group + 4 * lg + q;  // second transposing read: lrow + 16 (same swizzle key)
   // dY fragment addresses inside a stage (hi half = +2048 B)
   unsigned a_rel[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) a_rel[i] = XRING + lrow * 128 + ((i ^ ((lrow >> 1) & 3)) << 5) + pp * 8;
-  // X fragment addresses per tap (absolute LDS bytes, advanced by one chunk per step)
+  // X fragment addresses per tap (absolute LDS bytes, advanced by one macro-chunk per step)
   unsigned b_lo[9], b_hi[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int s = (t / 3 - 1) * p.PW + (t % 3 - 1);
     const int r = p.halo + s + lrow;  // >= 0: halo >= PW + 1
     const unsigned k = (unsigned)(r >> 1) & 3u;
-    const unsigned col = (((unsigned)wave ^ k) << 5) + pp * 8;
+    const unsigned col = (((unsigned)wq ^ k) << 5) + pp * 8;
     b_lo[t] = (((unsigned)r * 128u) & (XRING - 1)) + col;
     b_hi[t] = (((unsigned)(r + 16) * 128u) & (XRING - 1)) + col;
   }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
   for (int c = 0; c < nsteps; ++c) {
     issue();
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * D) : "memory");
-    const unsigned sbase = (unsigned)((c & (ND - 1)) * WP_CHB);
+    const unsigned sbase = (unsigned)((c & (ND - 1)) * MCB);
     uint4 fa[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
       s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(b_hi[t]));
       uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
       const uint4 fb = make_uint4(l2.x, l2.y, h2.x, h2.y);
-      b_lo[t] = (b_lo[t] + WP_CHB) & (XRING - 1);
-      b_hi[t] = (b_hi[t] + WP_CHB) & (XRING - 1);
+      b_lo[t] = (b_lo[t] + MCB) & (XRING - 1);
+      b_hi[t] = (b_hi[t] + MCB) & (XRING - 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
@@ -192,17 +200,108 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WPArgs p) {
   // the look-ahead units are still in flight: they must land before this workgroup's LDS is reused
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- accumulate: lane holds o = 16*i + 4*lg + r, input channel 16*wave + li of every tap ----
-  const int cc = c0 + wave * 16 + li;
+  // ---- two groups: group 1 hands o-blocks 0,1 to group 0 and takes o-blocks 2,3 from it ----
+  if constexpr (G == 2) {
+    f32x4* xch = reinterpret_cast<f32x4*>(smem) + (wq * 18) * 64 + lane;  // [wq][18][lane] x 16 B
+    __syncthreads();  // every wave is done reading the rings
+    if (group == 1) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xch[(i * 9 + t) * 64] = acc[i][t];
+    }
+    __syncthreads();
+    if (group == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] += xch[(i * 9 + t) * 64];
+    }
+    __syncthreads();
+    if (group == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xch[(i * 9 + t) * 64] = acc[2 + i][t];
+    }
+    __syncthreads();
+    if (group == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[2 + i][t] += xch[(i * 9 + t) * 64];
+    }
+  }
+
+  // ---- accumulate: lane holds o = 16*i + 4*lg + r, input channel 16*wq + li of every tap ----
+  const int cc = c0 + wq * 16 + li;
+  auto flush = [&](int i, const f32x4 (&a)[9]) {
+    if (p.part) {  // deterministic path: this range's partial filter, summed by wgrad_partial_sum_kernel
+      float* base = p.part + (long long)split * p.N * 9 * p.KC;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + i * 16 + lg * 4 + r;
+        float* row = base + (long long)n * 9 * p.KC + cc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) row[t * p.KC] = a[t][r];
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + i * 16 + lg * 4 + r;
       float* row = p.dw + (long long)n * 9 * p.KC + cc;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(row + t * p.KC, acc[i][t][r]);
+      for (int t = 0; t < 9; ++t) atomicAdd(row + t * p.KC, a[t][r]);
     }
+  };
+  if constexpr (G == 2) {
+    if (group == 0) {
+      flush(0, acc[0]);
+      flush(1, acc[1]);
+    } else {
+      flush(2, acc[2]);
+      flush(3, acc[3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) flush(i, acc[i]);
+  }
+}
+
+// dw[j] += sum over ranges of part[range][j].  A block sums JQ = 256/SG float4 columns; thread
+// group g adds its contiguous share of the ranges in ascending order and the groups are added in
+// ascending order, so the result does not depend on timing.  SG is chosen so that a thread has
+// few (<= 8) dependent loads: the launch overlaps HBM-heavy kernels and must not be a latency chain.
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_partial_sum_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                int nq, int nsplit, long long stride_q) {
+  constexpr int JQ = 256 / SG;
+  __shared__ float4 red[SG][JQ];
+  const int col = threadIdx.x % JQ, sg = threadIdx.x / JQ;
+  const int jq = blockIdx.x * JQ + col;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (jq < nq) {
+    const float4* src = reinterpret_cast<const float4*>(part) + jq;
+    const int per = (nsplit + SG - 1) / SG;
+    const int beg = sg * per, end = min(nsplit, beg + per);
+#pragma unroll 8
+    for (int k = beg; k < end; ++k) {
+      const float4 v = src[(long long)k * stride_q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[sg][col] = s;
+  __syncthreads();
+  if (sg == 0 && jq < nq) {
+    float4 o = reinterpret_cast<float4*>(dw)[jq];
+#pragma unroll
+    for (int g = 0; g < SG; ++g) {
+      const float4 v = red[g][col];
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[jq] = o;
+  }
 }
 
 int g_wgrad_patch_min_w = -1;  // smallest image width routed here; 0 = off
@@ -215,7 +314,58 @@ int min_w() {
   return g_wgrad_patch_min_w;
 }
 
-constexpr int kD = 4, kNX = 16, kND = 8;
+// ranges of positions the grid is cut into for `total` positions and `tiles` channel tiles
+void split_ranges(int total, int tiles, int mcr, int* pps_out, int* nsplit_out) {
+  int nsplit = 256 / tiles;
+  if (nsplit < 1) nsplit = 1;
+  int pps = qt_cdiv(total, nsplit);
+  pps = qt_cdiv(pps, mcr) * mcr;
+  *pps_out = pps;
+  *nsplit_out = qt_cdiv(total, pps);
+}
+
+constexpr int kGroups = 2;  // wave groups of the default variant (split_ranges depends on it)
+
+template <int G, int D, int NX, int ND>
+int launch_patch(WPArgs a, size_t part_bytes, hipStream_t stream) {
+  constexpr int MCR = WP_CH * G;
+  constexpr int LDS = (NX + ND) * MCR * 128;
+  if (2 * a.halo > a.PP || (2 * a.halo) % MCR != 0 || (2 * a.halo) / MCR + D + 2 > NX || D + 2 > ND) {
+    qt_set_error("qt_conv2d_wgrad: image %dx%d does not fit the streaming kernel", a.H, a.W);
+    return QT_ERR_INVALID_ARG;
+  }
+  a.adv_h = MCR / a.PW;
+  a.adv_w = MCR % a.PW;
+  int real_split;
+  split_ranges(a.total, a.tiles, MCR, &a.pps, &real_split);
+  a.nsplit = real_split;
+  if (a.nsplit >= 6 && (a.nsplit & 7)) a.nsplit = qt_cdiv(a.nsplit, 8) * 8;  // empty tail ranges exit at once
+  const size_t filt = (size_t)a.N * 9 * a.KC;
+  if (a.part && part_bytes < (size_t)real_split * filt * 4) a.part = nullptr;  // too small: atomics
+  auto kern = conv_wgrad_patch_kernel<G, D, NX, ND>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return QT_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(256 * G), LDS, stream, a);
+  QT_CHECK_LAUNCH();
+  if (a.part) {
+    const int nq = (int)(filt / 4);
+    if (real_split > 16)
+      hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, a.part, a.dw, nq,
+                         real_split, (long long)nq);
+    else
+      hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, a.part, a.dw, nq,
+                         real_split, (long long)nq);
+    QT_CHECK_LAUNCH();
+  }
+  return QT_OK;
+}
 
 }  // namespace
 
@@ -234,8 +384,19 @@ bool qt_wgrad_patch_eligible(const qt_conv_desc* d) {
   return true;
 }
 
-int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+// bytes of partial-filter workspace the deterministic path wants for this convolution
+size_t qt_wgrad_patch_workspace_bytes(const qt_conv_desc* d) {
+  if (!qt_wgrad_patch_eligible(d)) return 0;
+  const int total = d->batch * (d->out_h + 2) * (d->out_w + 2);
+  int pps, nsplit;
+  split_ranges(total, (d->n_out / 64) * (d->k_per_tap / 64), WP_CH * kGroups, &pps, &nsplit);
+  return (size_t)nsplit * d->n_out * 9 * d->k_per_tap * 4;
+}
+
+int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   WPArgs a;
+  a.part = static_cast<float*>(workspace);
   a.dy = static_cast<const bf16_t*>(dy);
   a.x = static_cast<const bf16_t*>(x);
   a.dw = dw;
@@ -245,31 +406,25 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   a.dy_ps = a.N; a.dy_rs = a.W * a.N; a.dy_is = (long long)a.H * a.dy_rs;
   a.total = a.B * a.PP;
   a.halo = (a.PW + 1 + 31) / 32 * 32;
-  QT_CHECK_ARG(2 * a.halo <= a.PP && a.halo / 16 + kD + 2 <= kNX, "qt_conv2d_wgrad: image %dx%d does not fit the streaming kernel", a.H, a.W);
-  a.adv_h = WP_CH / a.PW; a.adv_w = WP_CH % a.PW;
   a.div_pp = make_fastdiv((unsigned)a.PP);
   a.div_pw = make_fastdiv((unsigned)a.PW);
   a.tilesC = a.KC / 64;
   a.tiles = (a.N / 64) * a.tilesC;
-  int nsplit = 256 / a.tiles;
-  if (nsplit < 1) nsplit = 1;
-  int pps = qt_cdiv(a.total, nsplit);
-  pps = qt_cdiv(pps, WP_CH) * WP_CH;
-  a.pps = pps;
-  a.nsplit = qt_cdiv(a.total, pps);
-  if (a.nsplit >= 6 && (a.nsplit & 7)) a.nsplit = qt_cdiv(a.nsplit, 8) * 8;  // empty tail ranges exit at once
-  constexpr int LDS = (kNX + kND) * WP_CHB;
-  auto kern = conv_wgrad_patch_kernel<kD, kNX, kND>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
+  a.adv_h = a.adv_w = a.pps = a.nsplit = 0;
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("QTCNN_WP_VARIANT");
+    variant = e ? atoi(e) : 0;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(256), LDS, static_cast<hipStream_t>(stream), a);
-  QT_CHECK_LAUNCH();
-  return QT_OK;
+  static int use_ws = -1;
+  if (use_ws < 0) {
+    const char* e = getenv("QTCNN_WGRAD_WS");
+    use_ws = e ? atoi(e) : 1;
+  }
+  if (!use_ws) a.part = nullptr;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // measured alone on the 56x56 64->64 layer (atomics): 4 waves / 4 K-steps ahead 122 us, 4 waves /
+  // 8 ahead 123 us, 8 waves / 3 macro-chunks ahead (128 KB LDS) 100 us, 8 waves / 2 ahead 99 us
+  if (variant == 1) return launch_patch<1, 4, 16, 8>(a, workspace_bytes, s);
+  return launch_patch<kGroups, 2, 8, 4>(a, workspace_bytes, s);
 }

@@ -77,6 +77,7 @@ struct qt_plan {
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
   size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;
   size_t dw_begin = 0, dw_end = 0;
+  size_t wgrad_part = 0, wgrad_part_bytes = 0;  // partial filters of the streaming weight-gradient kernel
   bool dw_dirty = true;  // weight-gradient scratch holds sums of an earlier backward
   int bwd_rows_bn2 = 0;  // carried from the layer4 phase to the rest-of-backbone phase  // BatchNorm-backward partials emitted by dgrad epilogues
   // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
@@ -260,6 +261,10 @@ void layout_workspace(qt_plan* p) {
     c.dw = ws.take(n * 4);
   }
   p->dw_end = ws.off;
+  // one partial filter per range of positions (at most 256 workgroups x 64 x 9 x 64 f32, whatever the
+  // batch): the streaming weight-gradient launches run one after another on the side stream and share it
+  p->wgrad_part_bytes = (size_t)256 * 64 * 9 * 64 * 4;
+  p->wgrad_part = ws.take(p->wgrad_part_bytes);
   for (LinL* l : {&p->cls0}) {
     l->w_fwd = ws.take((size_t)l->in * l->out * es);
     l->w_dgrad = ws.take((size_t)l->in * l->out * es);
@@ -735,7 +740,7 @@ struct Bwd : Exec {
       return;
     }
     const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);  // c.dw was zeroed at the start of this backward
-    run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, at<float>(c.dw), ws_));
+    run(qt_conv2d_wgrad_ws(&fwd_desc, at(c.gy), src, at<float>(c.dw), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
     end_timed(slot, ws_);
     if (stem)
       run(qt_unpack_stem_wgrad(at<float>(c.dw), gf(c.w), 0, ws_));

@@ -28,13 +28,20 @@ def timeit(fn, iters=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3  # us
 
-def bench(kind, B, H, Cin, Cout, k, s, p, dt=torch.bfloat16):
+def bench(kind, B, H, Cin, Cout, k, s, p, dt=torch.bfloat16, workspace=False):
     st = L.stream_ptr()
     if kind == "wgrad":
         d, Ho = desc(dt, L.QT_CONV_FWD, B, H, Cin, Cout, k, s, p)
         x = torch.randn(B, H, H, Cin, device=dev).to(dt); dy = torch.randn(B, Ho, Ho, Cout, device=dev).to(dt)
         dw = torch.zeros(Cout, k * k, Cin, device=dev)
         fn = lambda: L.check(L.lib().qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dy), L.ptr(x), L.ptr(dw), st))
+        if workspace:
+            L.lib().qt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+            nb = L.lib().qt_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+            wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            fn = lambda: L.check(L.lib().qt_conv2d_wgrad_ws(ctypes.byref(d), L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(wsb),
+                                                          ctypes.c_size_t(nb), st))
+            kind = "wgradW"
     else:
         mode = L.QT_CONV_FWD if kind == "fwd" else L.QT_CONV_DGRAD
         d, Ho = desc(dt, mode, B, H, Cin, Cout, k, s, p)
@@ -74,5 +81,7 @@ if __name__ == "__main__":
             bench("wgrad", B, 14, 256, 256, 3, 1, 1)
     if which == "wgrad1":   # streaming kernel only (QTCNN_WP_* env experiments)
         L.lib().qt_set_wgrad_patch_min_width(14)
-        bench("wgrad", B, 56, 64, 64, 3, 1, 1)
-        bench("wgrad", B, 28, 128, 128, 3, 1, 1)
+        for w in (False, True):
+            bench("wgrad", B, 56, 64, 64, 3, 1, 1, workspace=w)
+            bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=w)
+            bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=w)

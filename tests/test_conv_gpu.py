@@ -195,7 +195,8 @@ def test_conv_rejects_bad_args():
     assert st == -1 and b"dtype" in L.lib().qt_last_error()
 
 
-def run_wgrad(L, dt, dy_nhwc, x_nhwc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw, stride, pad, quad=0, strides=None):
+def run_wgrad(L, dt, dy_nhwc, x_nhwc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw, stride, pad, quad=0, strides=None,
+              workspace=False):
     dev = x_nhwc.device
     d = L.ConvDesc()
     d.dtype = L.qt_dtype(dt)
@@ -211,8 +212,16 @@ def run_wgrad(L, dt, dy_nhwc, x_nhwc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw
     d.src_img_stride, d.src_row_stride, d.src_pix_stride = strides
     d.quad = quad
     dw = torch.zeros(n_out, kh * kw, k_per_tap, dtype=torch.float32, device=dev)
-    L.check(L.lib().qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dy_nhwc), L.ptr(x_nhwc), L.ptr(dw), L.stream_ptr()),
-            "qt_conv2d_wgrad")
+    if workspace:
+        L.lib().qt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = L.lib().qt_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+        assert nbytes > 0, "this shape was expected to use the partial-filter workspace"
+        ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=dev)  # must be fully overwritten
+        L.check(L.lib().qt_conv2d_wgrad_ws(ctypes.byref(d), L.ptr(dy_nhwc), L.ptr(x_nhwc), L.ptr(dw), L.ptr(ws),
+                                           ctypes.c_size_t(nbytes), L.stream_ptr()), "qt_conv2d_wgrad_ws")
+    else:
+        L.check(L.lib().qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dy_nhwc), L.ptr(x_nhwc), L.ptr(dw), L.stream_ptr()),
+                "qt_conv2d_wgrad")
     torch.cuda.synchronize()
     return dw
 
@@ -263,13 +272,17 @@ def test_conv_wgrad_streaming_kernel(cfg):
     try:
         L.lib().qt_set_wgrad_patch_min_width(14)
         dw = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1)
+        dw_ws = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1, workspace=True)
+        dw_ws2 = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1, workspace=True)
         L.lib().qt_set_wgrad_patch_min_width(0)
         dw_generic = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1)
     finally:
         L.lib().qt_set_wgrad_patch_min_width(-1)
-    got = dw.cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-    assert rel_err(got, ref) <= 3e-5
+    for name, t in (("atomic", dw), ("workspace", dw_ws)):
+        got = t.cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        assert rel_err(got, ref) <= 3e-5, name
     assert rel_err(dw.cpu(), dw_generic.cpu()) <= 3e-5
+    assert torch.equal(dw_ws, dw_ws2)  # partial filters are summed in a fixed order: bit-reproducible
 
 
 def test_conv_wgrad_streaming_kernel_channel_slice():
