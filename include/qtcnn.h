@@ -181,9 +181,10 @@ int qt_bn_bwd_apply(int dtype, const void* g, const void* mask, const void* y, c
 
 /* stem: relu(y*scale+shift) then MaxPool2d(3,2,1): [B][112][112][64] -> [B][56][56][64]
  * (torchvision bn1/relu/maxpool, Quadtree_from scratch/models.py:224-226); argmax (u8, optional)
- * records the winning tap for the backward. */
+ * records the winning tap for the backward, y_at_max (optional, same shape and type as pooled)
+ * the raw conv1 output at that tap (input of qt_stem_bn_bwd_sums). */
 int qt_stem_pool(int dtype, const void* y, const float* scale, const float* shift, void* pooled,
-                 unsigned char* argmax, int batch, void* stream);
+                 unsigned char* argmax, void* y_at_max, int batch, void* stream);
 int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
                      const float* shift, void* g, int batch, void* stream);
 /* The same gradient fused with bn1's backward, without materialising it: _reduce emits
@@ -193,6 +194,11 @@ int qt_stem_bn_bwd_rows(int batch);
 int qt_stem_bn_bwd_reduce(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
                           const float* scale, const float* shift, const float* mean, const float* invstd,
                           float* partial, int batch, void* stream);
+/* The same partial sums from the pooled side (each pooled cell feeds one conv1 position): reads
+ * dpooled and y_at_max only.  qt_stem_bn_bwd_sums_rows(batch) rows. */
+int qt_stem_bn_bwd_sums_rows(int batch);
+int qt_stem_bn_bwd_sums(int dtype, const void* dpooled, const void* y_at_max, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, float* partial, int batch, void* stream);
 int qt_stem_bn_bwd_apply(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
                          const float* shift, const float* mean, const float* invstd, const float* coef, void* dy,
                          int batch, void* stream);

@@ -274,7 +274,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict
 template <typename T>
 __global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                  const float* __restrict__ shift, T* __restrict__ pooled,
-                                 unsigned char* __restrict__ argmax, int batch) {
+                                 unsigned char* __restrict__ argmax, T* __restrict__ y_at_max, int batch) {
   constexpr int H = 112, W = 112, C = 64, PH = 56, PW = 56;
   const long long total = (long long)batch * PH * PW * (C / 8);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -286,11 +286,12 @@ __global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restric
     float sc[8], sh[8];
     load8f(scale + c0, sc);
     load8f(shift + c0, sh);
-    float best[8];
+    float best[8], braw[8];
     int bidx[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       best[e] = -INFINITY;
+      braw[e] = 0.f;
       bidx[e] = 0;
     }
 #pragma unroll
@@ -308,6 +309,7 @@ __global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restric
           const float a = fmaxf(v[e] * sc[e] + sh[e], 0.f);
           if (a > best[e]) {
             best[e] = a;
+            braw[e] = v[e];
             bidx[e] = kh * 3 + kw;
           }
         }
@@ -321,6 +323,59 @@ __global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restric
       pk.y = bidx[4] | (bidx[5] << 8) | (bidx[6] << 16) | (bidx[7] << 24);
       *reinterpret_cast<uint2*>(argmax + off) = pk;
     }
+    if (y_at_max) QtVec8<T>::store(y_at_max + off, braw);
+  }
+}
+
+// BatchNorm-backward sums of the stem from the POOLED side: every pooled cell sends its gradient
+// to exactly one conv1 position (its argmax), so
+//   sum_pos g = sum_cells [bn(y*) > 0] d,   sum_pos g*xhat = sum_cells [bn(y*) > 0] d * (y* - mean) * invstd
+// with y* = the raw conv1 output at the argmax (saved by stem_pool_kernel).  Reads 2 x 103 MB at
+// B = 256 instead of the 822 MB a reduction over the conv1 map costs.  One partial row per block.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_bwd_sums_kernel(const T* __restrict__ dpooled, const T* __restrict__ y_at_max,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               float* __restrict__ partial, long long total) {
+  constexpr int C = 64;
+  const int c0 = (threadIdx.x & 7) * 8;  // gridDim.x * blockDim.x is a multiple of 8
+  float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+  load8f(scale + c0, sc);
+  load8f(shift + c0, sh);
+  load8f(mean + c0, mu);
+  load8f(invstd + c0, is);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    float d[8], v[8];
+    QtVec8<T>::load(dpooled + i * 8, d);
+    QtVec8<T>::load(y_at_max + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float g = (v[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
+      s1[e] += g;
+      s2[e] += g * (v[e] - mu[e]) * is[e];
+    }
+  }
+  __shared__ float red[32][64][2];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[rl][cg * 8 + e][0] = s1[e];
+    red[rl][cg * 8 + e][1] = s2[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < 32; ++r) {
+      a += red[r][threadIdx.x][0];
+      b += red[r][threadIdx.x][1];
+    }
+    partial[((long long)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+    partial[((long long)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
   }
 }
 
@@ -712,17 +767,17 @@ extern "C" int qt_bn_bwd_apply(int dtype, const void* g, const void* mask, const
 }
 
 extern "C" int qt_stem_pool(int dtype, const void* y, const float* scale, const float* shift, void* pooled,
-                            unsigned char* argmax, int batch, void* stream) {
+                            unsigned char* argmax, void* y_at_max, int batch, void* stream) {
   QT_DT_OK(dtype, "qt_stem_pool");
   QT_CHECK_ARG(y && scale && shift && pooled && batch > 0, "qt_stem_pool: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for((long long)batch * 56 * 56 * 8);
   if (dtype == QT_F32)
     hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift,
-                       (float*)pooled, argmax, batch);
+                       (float*)pooled, argmax, (float*)y_at_max, batch);
   else
     hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
-                       (bf16_t*)pooled, argmax, batch);
+                       (bf16_t*)pooled, argmax, (bf16_t*)y_at_max, batch);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
@@ -774,6 +829,31 @@ extern "C" int qt_stem_bn_bwd_reduce(int dtype, const void* dpooled, const unsig
     launch_stem_bwd<float>(1, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, nullptr, partial, nullptr, batch);
   else
     launch_stem_bwd<bf16_t>(1, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, nullptr, partial, nullptr, batch);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+static int stem_sums_rows(int batch) {
+  const long long blocks = ((long long)batch * 56 * 56 * 8 + 255) / 256;
+  return (int)(blocks > 1024 ? 1024 : blocks);
+}
+extern "C" int qt_stem_bn_bwd_sums_rows(int batch) { return batch > 0 ? stem_sums_rows(batch) : QT_ERR_INVALID_ARG; }
+
+extern "C" int qt_stem_bn_bwd_sums(int dtype, const void* dpooled, const void* y_at_max, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd, float* partial,
+                                   int batch, void* stream) {
+  QT_DT_OK(dtype, "qt_stem_bn_bwd_sums");
+  QT_CHECK_ARG(dpooled && y_at_max && scale && shift && mean && invstd && partial && batch > 0,
+               "qt_stem_bn_bwd_sums: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = stem_sums_rows(batch);
+  const long long total = (long long)batch * 56 * 56 * 8;
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(stem_bn_bwd_sums_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dpooled,
+                       (const float*)y_at_max, scale, shift, mean, invstd, partial, total);
+  else
+    hipLaunchKernelGGL(stem_bn_bwd_sums_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dpooled,
+                       (const bf16_t*)y_at_max, scale, shift, mean, invstd, partial, total);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

@@ -72,7 +72,7 @@ struct qt_plan {
   int fused_ld = 0, img_cols = 0, mlp_col0 = 0, hidden_dim = 0;
   // workspace offsets
   size_t ws_bytes = 0;
-  size_t xpad = 0, p0 = 0, argmax = 0, g_p0 = 0;
+  size_t xpad = 0, p0 = 0, argmax = 0, g_p0 = 0, ymax = 0;
   size_t q = 0, dq = 0, fused = 0, dfused = 0, h1 = 0, dh1 = 0, hidden = 0, dhidden = 0;
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
   size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;
@@ -274,6 +274,7 @@ void layout_workspace(qt_plan* p) {
     p->p0 = ws.take(B * 56 * 56 * 64 * es);
     p->g_p0 = ws.take(B * 56 * 56 * 64 * es);
     p->argmax = ws.take(B * 56 * 56 * 64);
+    p->ymax = ws.take(B * 56 * 56 * 64 * es);  // raw conv1 output at the pooling argmax (bn1 backward sums)
     for (size_t i = 0; i < p->convs.size(); ++i) {
       ConvL& c = p->convs[i];
       const size_t imgs = ((int)i == p->quad_conv) ? B * 4 : B;
@@ -553,12 +554,12 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     e.conv_bn_stats(c0, sd, e.at(p->xpad), tr);
     if (tr) {
       e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), e.at(p->p0),
-                         e.at<unsigned char>(p->argmax), batch, stream));
+                         e.at<unsigned char>(p->argmax), e.at(p->ymax), batch, stream));
     } else {
       e.igemm(sd, e.at(p->xpad), e.at(c0.w_fwd), e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), nullptr,
               nullptr, nullptr, 1);
-      e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(p->ones), e.at<float>(p->zeros), e.at(p->p0), nullptr, batch,
-                         stream));
+      e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(p->ones), e.at<float>(p->zeros), e.at(p->p0), nullptr, nullptr,
+                         batch, stream));
     }
     // ---- residual stages ----
     size_t x = p->p0;
@@ -919,12 +920,26 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // ---- stem ----
     const ConvL& c0 = p->convs[0];
     const BnL& bn0 = p->bns[c0.bn];
-    // max-pool backward + ReLU mask, then bn1 backward.  (The fused qt_stem_bn_bwd_reduce/_apply
-    // pair, which never materialises this gradient, measured SLOWER on MI355X -- 2 x 333 us vs
-    // 260 + 87 + 120 us: the 4-cell argmax gather is ALU-heavy and would run twice.)
-    e.run(qt_stem_pool_bwd(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
-                           e.at<float>(bn0.shift), e.at(c0.gy), B, stream));
-    e.bn_backward(c0, e.at(c0.gy), nullptr);
+    // max-pool backward + ReLU mask + bn1 backward without materialising d(loss)/d(relu output):
+    // the BatchNorm sums come from the pooled side (each pooled cell feeds exactly one conv1
+    // position: 2 x 103 MB read instead of a pass over two 411 MB maps), then one kernel gathers
+    // the <= 4 pooled cells of every conv1 position and writes d(loss)/d(conv1 output) directly.
+    // QTCNN_STEM_FUSED=0 keeps the three-pass form (pool backward, reduce, apply) for A/B runs.
+    static const bool fused = !(getenv("QTCNN_STEM_FUSED") && atoi(getenv("QTCNN_STEM_FUSED")) == 0);
+    if (fused) {
+      const int rows = qt_stem_bn_bwd_sums_rows(B);
+      e.run(qt_stem_bn_bwd_sums(dt, e.at(p->g_p0), e.at(p->ymax), e.at<float>(bn0.scale), e.at<float>(bn0.shift),
+                                e.at<float>(bn0.mean), e.at<float>(bn0.invstd), e.at<float>(p->stats), B, stream));
+      e.run(qt_bn_bwd_finalize(e.at<float>(p->stats), rows, bn0.C, (long long)B * 112 * 112, e.tf(bn0.gamma),
+                               e.at<float>(bn0.invstd), e.gf(bn0.gamma), e.gf(bn0.beta), 0, e.at<float>(bn0.coef), stream));
+      e.run(qt_stem_bn_bwd_apply(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
+                                 e.at<float>(bn0.shift), e.at<float>(bn0.mean), e.at<float>(bn0.invstd),
+                                 e.at<float>(bn0.coef), e.at(c0.gy), B, stream));
+    } else {
+      e.run(qt_stem_pool_bwd(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
+                             e.at<float>(bn0.shift), e.at(c0.gy), B, stream));
+      e.bn_backward(c0, e.at(c0.gy), nullptr);
+    }
     e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
     }
   }

@@ -1,0 +1,120 @@
+"""Stem tail (bn1 -> ReLU -> MaxPool2d(3,2,1), /root/reference/Quadtree_from scratch/models.py:224-226 via
+torchvision resnet18) through the C ABI, forward and backward, against torch autograd on the CPU.
+
+The backward never materialises d(loss)/d(relu output): BatchNorm sums come from the pooled side
+(qt_stem_bn_bwd_sums), the data gradient from the gathering apply kernel (qt_stem_bn_bwd_apply);
+the three-pass form (qt_stem_pool_bwd + qt_bn_bwd_reduce + qt_bn_bwd_apply) and the position-side
+reduction (qt_stem_bn_bwd_reduce) must agree with it.
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_stem_pool_and_fused_backward(dt, tol):
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    B, C, H, P = 3, 64, 112, 56
+    eps = 1e-5
+    g = torch.Generator().manual_seed(21)
+    y = (torch.randn(B, C, H, H, generator=g) * 1.5 + 0.2).to(dt).float()
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    dp = torch.randn(B, C, P, P, generator=g).to(dt).float()
+
+    # ---- reference: train-mode BatchNorm (batch statistics) -> ReLU -> max pool, autograd backward ----
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out = F.max_pool2d(F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, eps)), 3, 2, 1)
+    out.backward(dp)
+    mean = y.mean(dim=(0, 2, 3))
+    var = y.var(dim=(0, 2, 3), unbiased=False)
+    invstd = (var + eps).rsqrt()
+    scale = gamma * invstd
+    shift = beta - mean * scale
+
+    f32 = dict(device=dev, dtype=torch.float32)
+    yd = nhwc(y).to(dev, dt)
+    dpd = nhwc(dp).to(dev, dt)
+    sc, sh, mu, isd, gam = (t.to(**f32) for t in (scale, shift, mean, invstd, gamma))
+    pooled = torch.empty(B, P, P, C, device=dev, dtype=dt)
+    ymax = torch.empty_like(pooled)
+    argmax = torch.empty(B, P, P, C, device=dev, dtype=torch.uint8)
+    st = L.stream_ptr()
+    qdt = L.qt_dtype(dt)
+    L.check(lib.qt_stem_pool(qdt, L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(pooled), L.ptr(argmax), L.ptr(ymax), B, st),
+            "qt_stem_pool")
+    assert rel_err(pooled.float().cpu().permute(0, 3, 1, 2), out.detach()) <= (1e-6 if dt == torch.float32 else 4e-3)
+    # y_at_max really is the conv1 output at the recorded tap
+    am = argmax.cpu().long()
+    ypad = F.pad(nhwc(y), (0, 0, 1, 1, 1, 1))  # [B][114][114][C]
+    ph = torch.arange(P).view(1, P, 1, 1)
+    pw = torch.arange(P).view(1, 1, P, 1)
+    hh = (2 * ph + am // 3).expand(B, P, P, C)
+    ww = (2 * pw + am % 3).expand(B, P, P, C)
+    bb = torch.arange(B).view(B, 1, 1, 1).expand(B, P, P, C)
+    cc = torch.arange(C).view(1, 1, 1, C).expand(B, P, P, C)
+    assert torch.equal(ymax.float().cpu(), ypad[bb, hh, ww, cc])
+
+    M = B * H * H
+
+    def finalize(partial, rows):
+        dgam = torch.empty(C, **f32)
+        dbet = torch.empty(C, **f32)
+        coef = torch.empty(3, C, **f32)
+        L.check(lib.qt_bn_bwd_finalize(L.ptr(partial), rows, C, ctypes.c_longlong(M), L.ptr(gam), L.ptr(isd), L.ptr(dgam),
+                                       L.ptr(dbet), 0, L.ptr(coef), st), "qt_bn_bwd_finalize")
+        return dgam, dbet, coef
+
+    # pooled-side sums
+    rows = lib.qt_stem_bn_bwd_sums_rows(B)
+    assert rows > 0
+    part = torch.full((lib.qt_stats_capacity_rows(rows), 2, C), float("nan"), **f32)
+    L.check(lib.qt_stem_bn_bwd_sums(qdt, L.ptr(dpd), L.ptr(ymax), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(isd), L.ptr(part),
+                                    B, st), "qt_stem_bn_bwd_sums")
+    dgam, dbet, coef = finalize(part, rows)
+    # position-side sums (the older fused reduction) agree
+    rows2 = lib.qt_stem_bn_bwd_rows(B)
+    part2 = torch.full((lib.qt_stats_capacity_rows(rows2), 2, C), float("nan"), **f32)
+    L.check(lib.qt_stem_bn_bwd_reduce(qdt, L.ptr(dpd), L.ptr(argmax), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mu),
+                                      L.ptr(isd), L.ptr(part2), B, st), "qt_stem_bn_bwd_reduce")
+    dgam2, dbet2, _ = finalize(part2, rows2)
+    torch.cuda.synchronize()
+    assert rel_err(dgam.cpu(), dgam2.cpu()) <= 1e-5 and rel_err(dbet.cpu(), dbet2.cpu()) <= 1e-5
+    assert rel_err(dgam.cpu(), gr.grad) <= tol and rel_err(dbet.cpu(), br.grad) <= tol
+
+    # gathering apply: d(loss)/d(conv1 output)
+    dy = torch.empty(B, H, H, C, device=dev, dtype=dt)
+    L.check(lib.qt_stem_bn_bwd_apply(qdt, L.ptr(dpd), L.ptr(argmax), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(isd),
+                                     L.ptr(coef), L.ptr(dy), B, st), "qt_stem_bn_bwd_apply")
+    # three-pass form
+    gfull = torch.empty(B, H, H, C, device=dev, dtype=dt)
+    L.check(lib.qt_stem_pool_bwd(qdt, L.ptr(dpd), L.ptr(argmax), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(gfull), B, st),
+            "qt_stem_pool_bwd")
+    dy3 = torch.empty_like(dy)
+    L.check(lib.qt_bn_bwd_apply(qdt, L.ptr(gfull), None, L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef), L.ptr(dy3), None,
+                                ctypes.c_longlong(M), C, st), "qt_bn_bwd_apply")
+    torch.cuda.synchronize()
+    ref = yr.grad
+    assert rel_err(dy.float().cpu().permute(0, 3, 1, 2), ref) <= tol
+    assert rel_err(dy3.float().cpu().permute(0, 3, 1, 2), ref) <= tol
+    if dt == torch.float32:
+        assert rel_err(dy.cpu(), dy3.cpu()) <= 1e-6
