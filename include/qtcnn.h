@@ -101,6 +101,11 @@ typedef struct qt_conv_io {
  * one-tile-per-workgroup kernel is experimental), 2 (default) only the persistent sliding-ring
  * kernel for the 56x56 64->64 bf16 layers. */
 void qt_set_patch_conv(int mode);
+/* The packed bf16 stem convolution (desc of qt_pack_stem_input: kh 7|8, kw 1, stride 2, k_per_tap 32,
+ * 64 outputs, no residual / mask / bwd_bn) takes a dedicated kernel (csrc/conv_stem.hip: input
+ * rows of a 4 x 112 pixel tile in LDS, filter in registers, one partial-statistics row per
+ * workgroup).  1 (default) on, 0 generic implicit GEMM. */
+void qt_set_stem_conv(int mode);
 int qt_conv2d_stats_rows(const qt_conv_desc* desc);
 int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream);
 

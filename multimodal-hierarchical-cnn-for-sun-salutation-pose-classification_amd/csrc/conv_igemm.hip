@@ -467,10 +467,15 @@ int dispatch(const qt_conv_desc* d, const ConvArgs& a, hipStream_t stream) {
 bool qt_patch_eligible(const qt_conv_desc* d);
 int qt_patch_stats_rows(const qt_conv_desc* d);
 int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream);
+// conv_stem.hip: the packed 7x7/2 stem convolution (bf16) with its input rows held in LDS
+bool qt_stem_eligible(const qt_conv_desc* d, const qt_conv_io* io);
+int qt_stem_stats_rows(const qt_conv_desc* d);
+int qt_stem_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream);
 
 extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   if (!d) return QT_ERR_INVALID_ARG;
   if (qt_patch_eligible(d)) return qt_patch_stats_rows(d);
+  if (qt_stem_eligible(d, nullptr)) return qt_stem_stats_rows(d);
   const long long M = (long long)d->batch * (d->quad && d->mode == QT_CONV_FWD ? 4 : 1) * d->out_h * d->out_w;
   const int esz = d->dtype == QT_F32 ? 4 : 2;
   return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
@@ -503,6 +508,7 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG((d->src_pix_stride * esz) % 16 == 0 || d->stride * d->src_pix_stride * esz % 16 == 0,
                "qt_conv2d_igemm: pixel stride %d breaks 16-byte alignment", d->src_pix_stride);
 
+  if (qt_stem_eligible(d, io)) return qt_stem_launch(d, io, stream);
   if (qt_patch_eligible(d)) {
     for (int k = 0; k < 2; ++k)
       QT_CHECK_ARG(!io->bwd_bn[k].y || (io->bwd_bn[k].mean && io->bwd_bn[k].invstd && io->bwd_bn[k].partial &&

@@ -1,0 +1,222 @@
+// Stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels) on the packed NHWC4 input, bf16.
+//
+// Replaces the F.conv2d behind torchvision resnet18.conv1, reached at
+// /root/reference/Quadtree_from scratch/models.py:223 (self.base_cnn.conv1) in
+// forward() (models.py:274-276) -- first op of the QuadtreeCNN forward pass.
+//
+// The generic implicit GEMM stages, per output pixel, 7 row taps x 64 B through LDS although
+// neighbouring pixels share 3/4 of every tap row, and runs 8 taps (K = 256) because its K-step
+// is two taps wide.  Here a workgroup keeps the INPUT rows of a 4 x 112 pixel output tile in LDS
+// (13 packed rows = one contiguous 24 KB block of the [B][230][232][4] image), and
+//   * an MFMA B-fragment of pixel ow / tap kh / k-group g is the 16 bytes at row (2*oh+kh),
+//     byte 16*(ow+g): the im2col overlap is expressed by overlapping LDS reads, nothing is copied;
+//   * the whole filter (64 x 7 x 32 bf16 = 28 KB) lives in registers, 28 fragments per wave, for all
+//     the tiles a workgroup walks (persistent grid), so one LDS read feeds four MFMAs (K = 224);
+//   * the next tile's rows arrive by LDS-DMA while the current tile is multiplied;
+//   * the epilogue transposes each 16-pixel block through LDS into one contiguous 2 KB store and
+//     keeps BatchNorm sums in registers across tiles (one partial row per workgroup).
+// Bound: the 411 MB output write (HBM), not MFMA.
+#include <stdlib.h>
+
+#include "qt_common.h"
+
+namespace {
+
+struct StemArgs {
+  const bf16_t* x;        // [B][230][232][4]
+  const bf16_t* w;        // [64][taps][32]
+  bf16_t* y;              // [B][112][112][64]
+  const float* scale;     // nullable
+  const float* shift;
+  float* stats;           // [gridDim.x][2][64] or NULL
+  int relu, taps, ntiles;
+};
+
+constexpr int ST_TH = 4;                          // output rows per tile
+constexpr int ST_ROWB = QT_STEM_PAD_W * 4 * 2;    // 1856 bytes per packed input row
+constexpr int ST_IN_ROWS = 2 * ST_TH + 5;         // 13
+constexpr int ST_BUF = 24 * 1024;                 // whole 1 KB DMA instructions
+static_assert(ST_IN_ROWS * ST_ROWB <= ST_BUF, "a tile's input rows fit one buffer");
+constexpr int ST_STG_ROW = 144;                   // 128 B of channels + 16 B pad per pixel
+constexpr int ST_STG = 16 * ST_STG_ROW;           // per-wave epilogue staging
+constexpr int ST_LDS = 2 * ST_BUF + 4 * ST_STG;
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const unsigned smem_base = lds_addr_of(smem);
+
+  // contiguous share of the tiles (tile = image * 28 + row group)
+  const int t_beg = (int)((long long)blockIdx.x * p.ntiles / gridDim.x);
+  const int t_end = (int)((long long)(blockIdx.x + 1) * p.ntiles / gridDim.x);
+
+  // filter fragments: A operand, row = output channel 16*cb + li, k = 8*lg .. 8*lg+7 of tap kh
+  uint4 wf[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      wf[kh][cb] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(cb * 16 + li) * p.taps + kh) * 32 + lg * 8);
+
+  float sc[4][4], sh[4][4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = cb * 16 + lg * 4 + r;
+      sc[cb][r] = p.scale ? p.scale[ch] : 1.f;
+      sh[cb][r] = p.scale ? p.shift[ch] : 0.f;
+    }
+  float s1[4][4], s2[4][4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[cb][r] = s2[cb][r] = 0.f;
+
+  // 24 DMA instructions of 1 KB per tile, 6 per wave
+  auto dma_tile = [&](int tile, int buf) {
+    const int img = tile / 28, rg = tile - img * 28;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) +
+                               ((size_t)img * QT_STEM_PAD_H + (size_t)rg * 2 * ST_TH) * ST_ROWB;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int blk = wave * 6 + i;
+      glds16(src + blk * 1024 + lane * 16, smem_base + buf * ST_BUF + blk * 1024);
+    }
+  };
+
+  unsigned char* stg = smem + 2 * ST_BUF + wave * ST_STG;
+  if (t_beg < t_end) dma_tile(t_beg, 0);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int buf = (t - t_beg) & 1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // tile t landed; buffer buf^1 is free
+    if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);
+    const unsigned char* in = smem + buf * ST_BUF;
+    const int img = t / 28, rg = t - img * 28;
+#pragma unroll 1
+    for (int j = 0; j < 7; ++j) {
+      const int rb = wave + 4 * j;       // 28 blocks of 16 pixels: 4 rows x 7
+      const int orow = rb / 7, ob = rb - orow * 7;
+      const unsigned char* a0 = in + (2 * orow) * ST_ROWB + 16 * (ob * 16 + li + lg);
+      uint4 xf[7];
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) xf[kh] = *reinterpret_cast<const uint4*>(a0 + kh * ST_ROWB);
+      f32x4 acc[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kh][cb]),
+                                                            __builtin_bit_cast(bf16x8, xf[kh]), acc[cb], 0, 0, 0);
+      // lane: pixel li of the block, channels 16*cb + 4*lg + r
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[cb][r];
+          s1[cb][r] += a;
+          s2[cb][r] += a * a;
+          v[r] = a * sc[cb][r] + sh[cb][r];
+          if (p.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+        *reinterpret_cast<bf16x4*>(stg + li * ST_STG_ROW + cb * 32 + lg * 8) = o;
+      }
+      // the 16 pixels x 128 B of this block are contiguous in y: two 16-byte stores per lane
+      bf16_t* dst = p.y + (((size_t)img * 112 + rg * ST_TH + orow) * 112 + ob * 16) * 64;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int px = h * 8 + (lane >> 3), ck = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + px * ST_STG_ROW + ck * 16);
+        *reinterpret_cast<uint4*>(dst + px * 64 + ck * 8) = v;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (p.stats) {
+    // [wave][lane][32] f32 over the (now idle) input buffers, then 128 threads add 64 values each
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[(tid * 32) + cb * 4 + r] = s1[cb][r];
+        red[(tid * 32) + 16 + cb * 4 + r] = s2[cb][r];
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int stat = tid >> 6, ch = tid & 63;
+      const int cb = ch >> 4, g = (ch >> 2) & 3, r = ch & 3;
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int l = 0; l < 16; ++l) s += red[((w * 64 + g * 16 + l) * 32) + stat * 16 + cb * 4 + r];
+      p.stats[((size_t)blockIdx.x * 2 + stat) * 64 + ch] = s;
+    }
+  }
+}
+
+int g_stem_enabled = -1;
+bool stem_enabled() {
+  if (g_stem_enabled < 0) {
+    const char* e = getenv("QTCNN_STEM_CONV");
+    g_stem_enabled = e ? atoi(e) : 1;
+  }
+  return g_stem_enabled != 0;
+}
+
+int stem_grid(int batch) {
+  const int ntiles = batch * (112 / ST_TH);
+  return ntiles < 512 ? ntiles : 512;  // two workgroups per CU
+}
+
+}  // namespace
+
+// 1 (default): the packed bf16 stem convolution takes the dedicated kernel; 0: generic implicit GEMM
+extern "C" void qt_set_stem_conv(int mode) { g_stem_enabled = mode < 0 ? 1 : (mode != 0); }
+
+bool qt_stem_eligible(const qt_conv_desc* d, const qt_conv_io* io) {
+  if (!stem_enabled() || d->dtype != QT_BF16 || d->mode != QT_CONV_FWD) return false;
+  if (d->k_per_tap != 32 || d->kw != 1 || (d->kh != 7 && d->kh != 8) || d->stride != 2 || d->pad != 0) return false;
+  if (d->n_out != 64 || d->out_h != 112 || d->out_w != 112 || d->in_h != QT_STEM_PAD_H || d->in_w != QT_STEM_PAD_W)
+    return false;
+  if (d->src_pix_stride != 4 || d->src_row_stride != QT_STEM_PAD_W * 4 ||
+      d->src_img_stride != (long long)QT_STEM_PAD_H * QT_STEM_PAD_W * 4)
+    return false;
+  if (d->quad || d->dst_sub) return false;
+  if (io && (io->residual || io->relu_mask || io->bwd_bn[0].y || io->bwd_bn[1].y)) return false;
+  return true;
+}
+
+int qt_stem_stats_rows(const qt_conv_desc* d) { return stem_grid(d->batch); }
+
+int qt_stem_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
+  QT_CHECK_ARG((io->scale == nullptr) == (io->shift == nullptr), "qt_conv2d_igemm: scale and shift come together");
+  StemArgs a;
+  a.x = static_cast<const bf16_t*>(io->src);
+  a.w = static_cast<const bf16_t*>(io->weight);
+  a.y = static_cast<bf16_t*>(io->dst);
+  a.scale = io->scale; a.shift = io->shift; a.stats = io->stats_partial;
+  a.relu = d->relu; a.taps = d->kh; a.ntiles = d->batch * (112 / ST_TH);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    if (e != hipSuccess) {
+      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", ST_LDS, hipGetErrorString(e));
+      return QT_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_stem_kernel, dim3(stem_grid(d->batch)), dim3(256), ST_LDS, static_cast<hipStream_t>(stream), a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

@@ -118,3 +118,65 @@ def test_stem_pool_and_fused_backward(dt, tol):
     assert rel_err(dy3.float().cpu().permute(0, 3, 1, 2), ref) <= tol
     if dt == torch.float32:
         assert rel_err(dy.cpu(), dy3.cpu()) <= 1e-6
+
+
+def _stem_conv(L, dt, image, w, taps, want_stats, scale=None, shift=None, relu=0):
+    """conv1 through the C ABI: pack input and weights, run the packed-stem descriptor."""
+    dev = image.device
+    lib = L.lib()
+    B = image.shape[0]
+    st = L.stream_ptr()
+    qdt = L.qt_dtype(dt)
+    xpad = torch.empty(B, 230, 232, 4, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_input(qdt, L.ptr(image), L.ptr(xpad), B, st), "qt_pack_stem_input")
+    wp = torch.empty(64, taps, 32, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_weight(qdt, L.ptr(w), L.ptr(wp), taps, st), "qt_pack_stem_weight")
+    d = L.ConvDesc()
+    d.dtype, d.mode, d.batch = qdt, L.QT_CONV_FWD, B
+    d.in_h, d.in_w, d.out_h, d.out_w = 230, 232, 112, 112
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = 32, 64, taps, 1, 2, 0
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = 230 * 232 * 4, 232 * 4, 4
+    d.relu = relu
+    y = torch.empty(B, 112, 112, 64, device=dev, dtype=dt)
+    stats = None
+    if want_stats:
+        rows = lib.qt_conv2d_stats_rows(ctypes.byref(d))
+        stats = torch.full((rows, 2, 64), float("nan"), dtype=torch.float32, device=dev)
+    io = L.ConvIO(L.ptr(xpad), L.ptr(wp), L.ptr(y), L.ptr(scale), L.ptr(shift), None, None, L.ptr(stats))
+    L.check(lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), st), "qt_conv2d_igemm")
+    torch.cuda.synchronize()
+    return y, stats
+
+
+@pytest.mark.parametrize("B", [1, 3, 20])   # 28, 84, 560 tiles: fewer / more tiles than workgroups
+def test_stem_conv_dedicated_kernel(B):
+    """csrc/conv_stem.hip (bf16) against F.conv2d and against the generic implicit GEMM."""
+    dev = _dev()
+    L = pkg("_lib")
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(22 + B)
+    image = torch.randn(B, 3, 224, 224, generator=g).to(dt).float()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(dt).float()
+    ref = F.conv2d(image, w, None, 2, 3)                      # f32 math on bf16-representable operands
+    scale = (torch.rand(64, generator=g) + 0.5).to(dev)
+    shift = torch.randn(64, generator=g).to(dev)
+    imd, wd = image.to(dev), w.to(dev)
+    try:
+        L.lib().qt_set_stem_conv(1)
+        y, stats = _stem_conv(L, dt, imd, wd, 8, True)
+        y_act, _ = _stem_conv(L, dt, imd, wd, 8, False, scale, shift, relu=1)
+        L.lib().qt_set_stem_conv(0)
+        y_gen, stats_gen = _stem_conv(L, dt, imd, wd, 8, True)
+    finally:
+        L.lib().qt_set_stem_conv(-1)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= 4e-3                           # one bf16 rounding of the output
+    assert torch.equal(y, y_gen) or rel_err(y.float().cpu(), y_gen.float().cpu()) <= 4e-3
+    # statistics come from the f32 accumulators: sum and sum of squares per channel
+    s = stats.sum(dim=0).cpu().double()
+    sg = stats_gen.sum(dim=0).cpu().double()
+    assert rel_err(s[0], ref.double().sum(dim=(0, 2, 3))) <= 1e-4
+    assert rel_err(s[1], (ref.double() ** 2).sum(dim=(0, 2, 3))) <= 1e-5
+    assert rel_err(s, sg) <= 1e-4
+    act = F.relu(ref * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1))
+    assert rel_err(y_act.float().cpu().permute(0, 3, 1, 2), act) <= 4e-3
