@@ -324,7 +324,7 @@ void split_ranges(int total, int tiles, int mcr, int* pps_out, int* nsplit_out) 
   *nsplit_out = qt_cdiv(total, pps);
 }
 
-constexpr int kGroups = 2;  // wave groups of the default variant (split_ranges depends on it)
+constexpr int kGroups = 1;  // wave groups of the default variant (split_ranges depends on it)
 
 template <int G, int D, int NX, int ND>
 int launch_patch(WPArgs a, size_t part_bytes, hipStream_t stream) {
@@ -423,8 +423,12 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   }
   if (!use_ws) a.part = nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // measured alone on the 56x56 64->64 layer (atomics): 4 waves / 4 K-steps ahead 122 us, 4 waves /
-  // 8 ahead 123 us, 8 waves / 3 macro-chunks ahead (128 KB LDS) 100 us, 8 waves / 2 ahead 99 us
-  if (variant == 1) return launch_patch<1, 4, 16, 8>(a, workspace_bytes, s);
-  return launch_patch<kGroups, 2, 8, 4>(a, workspace_bytes, s);
+  // Alone, two wave groups win (56x56 64->64, atomics: 99 us vs 122 us): a second wave per SIMD
+  // covers LDS reads and address arithmetic.  Inside the training step the launch overlaps the
+  // main stream's data-gradient / BatchNorm kernels, and two 252-VGPR waves per SIMD leave no room
+  // for any of their waves: short kernels then queue behind whole workgroups.  One group per
+  // workgroup (one wave per SIMD, 96 KB LDS) keeps half of every CU's registers free and measures
+  // 1.7 % faster per step (7.43 vs 7.56 ms); 48 KB of LDS with a shallower ring measures slower (7.60).
+  if (variant == 2) return launch_patch<2, 2, 8, 4>(a, workspace_bytes, s);
+  return launch_patch<kGroups, 4, 16, 8>(a, workspace_bytes, s);
 }
