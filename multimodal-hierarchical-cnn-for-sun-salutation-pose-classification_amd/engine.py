@@ -100,6 +100,9 @@ class PlanEngine:
         self.workspace_bytes = nbytes
         self._tensor_ptrs = (ctypes.c_void_p * n)()
         self._packed_version = None
+        # parameter gradients were handed out since the last pack: an optimizer step follows, and fused /
+        # foreach optimizers update parameters without bumping Tensor._version
+        self._weights_stale = True
         self.fwd_counter = 0
         self.grad_sync = None  # optional callable(bucket: Tensor, phase: int) for data parallelism
 
@@ -142,16 +145,28 @@ class PlanEngine:
             want = torch.int64 if self.kinds[i] == 2 else torch.float32
             if t.dtype != want or t.device != self.device or not t.is_contiguous():
                 raise QtError(f"{name}: expected contiguous {want} on {self.device}, got {t.dtype} on {t.device}")
-            self._tensor_ptrs[i] = t.data_ptr()
+            ptr = t.data_ptr()
+            if self._tensor_ptrs[i] != ptr:
+                self._weights_stale = True      # a parameter was replaced (load / .to() / new storage)
+            self._tensor_ptrs[i] = ptr
+
+    def invalidate_weights(self):
+        """The f32 master weights changed behind the model's back: re-pack them at the next forward."""
+        self._weights_stale = True
 
     def pack_weights(self, version, for_backward):
+        """Re-pack the compute-dtype operand copies when the f32 masters may have changed: the
+        parameters' version counters moved, a parameter's storage was replaced, or gradients were
+        produced since the last pack (torch's fused Adam/SGD kernels update parameters WITHOUT
+        bumping Tensor._version, so the counter alone would leave the plan on stale weights)."""
         key = (version, bool(for_backward))
-        if self._packed_version is not None and self._packed_version[0] == version and \
+        if not self._weights_stale and self._packed_version is not None and self._packed_version[0] == version and \
                 (self._packed_version[1] or not for_backward):
             return
         _lib.check(self.L.qt_plan_pack_weights(self.handle, self.ws_ptr, self._tensor_ptrs, int(for_backward),
                                                _lib.stream_ptr()), "qt_plan_pack_weights")
         self._packed_version = key
+        self._weights_stale = False
 
     # -- execution --------------------------------------------------------------
     def forward(self, image, numerical, training, seed):
@@ -191,6 +206,9 @@ class PlanEngine:
             v = flat[offs[idx]:offs[idx] + sizes[idx]].view(shape)
             views[idx] = v
             grad_ptrs[idx] = v.data_ptr()
+
+        if wanted:
+            self._weights_stale = True
 
         def run(phase):
             _lib.check(self.L.qt_plan_backward(self.handle, self.ws_ptr, self._tensor_ptrs, grad_ptrs,

@@ -42,6 +42,12 @@ class _PlanModel(nn.Module):
     def _plan_mode(self):
         return getattr(self, "mode", "fusion")
 
+    def invalidate_packed_weights(self):
+        """Call after changing parameters in a way torch does not record (no version bump, no
+        backward since the last forward): the next forward re-packs the bf16/f32 operand copies."""
+        if self._engine is not None:
+            self._engine.invalidate_weights()
+
     def _ensure_engine(self, batch, device):
         key = (str(device), self.compute_dtype)
         if self._engine is not None and self._engine_key == key and batch <= self._engine.max_batch:

@@ -229,6 +229,38 @@ def test_three_optimizer_steps_follow_the_oracle_trajectory():
     assert rel_err(e1, e2) <= 5e-3
 
 
+@pytest.mark.parametrize("opt_kw", [dict(fused=True), dict(foreach=True), dict(foreach=False)])
+def test_updated_weights_are_used_after_fused_optimizer_step(opt_kw):
+    """torch's fused Adam updates parameters without bumping Tensor._version, so the plan must not
+    key its packed operand copies on the version counters alone: after optimizer.step() the next
+    forward has to see the new weights (Quadtree_train.py:62-66 relies on that every step)."""
+    dev = _dev()
+    synth = pkg("synth")
+    B = 4
+    m = build("quadtree", torch.bfloat16, dropout=0.0).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, **opt_kw)
+    x, f = synth.synth_images(B, salt=40).to(dev), synth.synth_pose_features(B, salt=40).to(dev)
+    y = synth.synth_labels(B, 12, salt=40).to(dev)
+    m.eval()
+    with torch.no_grad():
+        before = m(x, f).clone()
+    m.train()
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x, f), y).backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = m(x, f).clone()
+    # a fresh model loaded with the updated state_dict is the ground truth for "the new weights"
+    fresh = build("quadtree", torch.bfloat16, dropout=0.0)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    fresh = fresh.to(dev).eval()
+    with torch.no_grad():
+        want = fresh(x, f)
+    assert not torch.equal(before, after), "the optimizer step did not reach the forward pass"
+    assert torch.equal(after, want)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_batch_growth_and_dropout_statistics(dt):
     """The engine is rebuilt when the batch outgrows the plan; dropout keeps about half of the
