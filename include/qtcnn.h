@@ -143,6 +143,16 @@ int qt_pack_stem_input(int dtype, const float* image_nchw, void* dst, int batch,
  * and/or [I][kh][kw][O] (w_dgrad); either may be NULL.  Linear layers: kh=kw=1. */
 int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int O, int I, int kh, int kw,
                         void* stream);
+/* Every conv / linear weight of a model in one launch (LDS tile transposes): per item the same
+ * result as qt_pack_conv_weight, or, with stride2_dgrad != 0 and k == 3, w_dgrad in the parity-class
+ * layout of qt_pack_dgrad_s2.  O and I must be multiples of 32 (k = 3) or 64 (k = 1); at most 32 items. */
+typedef struct qt_pack_item {
+  const float* w_oihw;
+  void* w_fwd;   /* nullable */
+  void* w_dgrad; /* nullable */
+  int O, I, k, stride2_dgrad;
+} qt_pack_item;
+int qt_pack_weights_batched(int dtype, const qt_pack_item* items, int n, void* stream);
 /* Data-gradient operand of a stride-2 conv (k = 3 pad 1, or k = 1 pad 0) split by the parity
  * (ph, pw) of the input pixel: class c = ph*2+pw gets [I][taps_c][O] with only the taps that
  * reach it (k=3: 1,2,2,4 taps; k=1: 1,0,0,0), stored back to back in class order.  Row taps of

@@ -5,6 +5,8 @@
 //  * OIHW f32 master weights (the reference's state_dict layout)
 //    -> [O][kh][kw][I] forward operand and [I][kh][kw][O] data-gradient operand.
 //  * [O][kh][kw][I] f32 weight gradients -> OIHW f32 .grad tensors.
+#include <string.h>
+
 #include "qt_common.h"
 
 namespace {
@@ -55,6 +57,98 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
     const float v = w[((long long)o * I + i) * taps + tap];
     if (fwd) fwd[idx] = qt_from_f32<T>(v);
     if (dgrad) dgrad[((long long)i * taps + tap) * O + o] = qt_from_f32<T>(v);
+  }
+}
+
+// All conv / linear weights of a model in ONE launch.  A block transposes a 32(o) x 32(i) x taps
+// tile through LDS: the OIHW rows are read as contiguous runs of 32*taps floats, the forward operand
+// [o][tap][i] is written in runs of 32 i, the data-gradient operand [i][tap][o] (or its parity-class
+// form for stride-2 convs, see pack_dgrad_s2_kernel) in runs of 32 o.  The per-element kernels above
+// scatter 2-byte stores with a stride of taps*O elements and need one launch per layer (0.42 ms per
+// training step for the 26 M parameters of QuadtreeCNN); this one moves the same bytes in ~60 us.
+constexpr int PK_MAX_ITEMS = 32;
+struct PackBatchArgs {
+  const float* w[PK_MAX_ITEMS];
+  void* fwd[PK_MAX_ITEMS];
+  void* dgrad[PK_MAX_ITEMS];
+  int O[PK_MAX_ITEMS], I[PK_MAX_ITEMS];
+  unsigned char k[PK_MAX_ITEMS], s2[PK_MAX_ITEMS];
+  int first_block[PK_MAX_ITEMS + 1];
+  int n;
+};
+
+template <typename T> struct PackPair;  // two consecutive elements as one store
+template <> struct PackPair<float> {
+  static __device__ __forceinline__ void store(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+};
+template <> struct PackPair<bf16_t> {
+  static __device__ __forceinline__ void store(bf16_t* p, float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(bf16_t)a, (bf16_t)b};
+    *reinterpret_cast<bf16x2*>(p) = v;
+  }
+};
+
+// one TO(o) x TI(i) x TAPS tile; `tile` holds it as [o][i*TAPS + tap] with an odd row stride
+template <typename T, int TAPS, int TO, int TI>
+__device__ __forceinline__ void pack_tile(float* tile, const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dg,
+                                          int O, int I, int o0, int i0, bool s2) {
+  constexpr int RUN = TI * TAPS, S = RUN + 1, TOTAL = TO * RUN;
+  for (int e = threadIdx.x; e < TOTAL; e += 256) {
+    const int o = e / RUN, r = e - o * RUN;
+    tile[o * S + r] = w[((long long)(o0 + o) * I + i0) * TAPS + r];
+  }
+  __syncthreads();
+  if (fwd) {
+    for (int e = threadIdx.x; e < TOTAL / 2; e += 256) {
+      const int i = (e % (TI / 2)) * 2, ot = e / (TI / 2);
+      const int o = ot / TAPS, tap = ot - o * TAPS;
+      const float* t = tile + o * S + i * TAPS + tap;
+      PackPair<T>::store(fwd + ((long long)(o0 + o) * TAPS + tap) * I + i0 + i, t[0], t[TAPS]);
+    }
+  }
+  if (dg) {
+    for (int e = threadIdx.x; e < TOTAL / 2; e += 256) {
+      const int o = (e % (TO / 2)) * 2, it2 = e / (TO / 2);
+      const int i = it2 / TAPS, tap = it2 - i * TAPS;
+      const float* t = tile + o * S + i * TAPS + tap;
+      long long dst;
+      if (TAPS == 1 || !s2) {
+        dst = ((long long)(i0 + i) * TAPS + tap) * O + o0 + o;
+      } else {
+        // parity-class layout of pack_dgrad_s2_kernel: class (ph,pw), taps {1} / {2,0} per axis
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int ph = kh != 1, pw = kw != 1;
+        const int th = ph ? (kh == 2 ? 0 : 1) : 0, tw = pw ? (kw == 2 ? 0 : 1) : 0;
+        const int nh = ph ? 2 : 1, nw = pw ? 2 : 1;
+        const int cls = ph * 2 + pw;
+        const long long IO = (long long)I * O;
+        const long long base = cls == 0 ? 0 : (cls == 1 ? IO : (cls == 2 ? 3 * IO : 5 * IO));
+        dst = base + ((long long)(i0 + i) * (nh * nw) + th * nw + tw) * O + o0 + o;
+      }
+      PackPair<T>::store(dg + dst, t[0], t[S]);
+    }
+  }
+}
+
+constexpr int PK_T1 = 64;  // tile edge of 1x1 filters; 3x3 filters use 32
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(PackBatchArgs a) {
+  __shared__ float tile[32 * (32 * 9 + 1)];
+  static_assert(PK_T1 * (PK_T1 + 1) <= 32 * (32 * 9 + 1), "1x1 tile fits the 3x3 tile's LDS");
+  int it = 0;
+  while (it + 1 < a.n && (int)blockIdx.x >= a.first_block[it + 1]) ++it;
+  const int O = a.O[it], I = a.I[it];
+  const int b = blockIdx.x - a.first_block[it];
+  T* fwd = static_cast<T*>(a.fwd[it]);
+  T* dg = static_cast<T*>(a.dgrad[it]);
+  if (a.k[it] == 1) {
+    const int tiles_i = I / PK_T1;
+    pack_tile<T, 1, PK_T1, PK_T1>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) * PK_T1, (b % tiles_i) * PK_T1, false);
+  } else {
+    const int tiles_i = I >> 5;
+    pack_tile<T, 9, 32, 32>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) << 5, (b % tiles_i) << 5, a.s2[it] != 0);
   }
 }
 
@@ -148,6 +242,35 @@ extern "C" int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, 
   else
     hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw,
                        static_cast<bf16_t*>(w_fwd), static_cast<bf16_t*>(w_dgrad), O, I, kh * kw);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pack_weights_batched(int dtype, const qt_pack_item* items, int n, void* stream) {
+  QT_CHECK_ARG(items && n > 0 && n <= PK_MAX_ITEMS, "qt_pack_weights_batched: 1..%d items", PK_MAX_ITEMS);
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pack_weights_batched: bad dtype %d", dtype);
+  PackBatchArgs a;
+  memset(&a, 0, sizeof(a));
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const qt_pack_item& q = items[j];
+    const int te = q.k == 1 ? PK_T1 : 32;
+    QT_CHECK_ARG(q.w_oihw && (q.w_fwd || q.w_dgrad) && (q.k == 1 || q.k == 3) && q.O > 0 && q.I > 0 && q.O % te == 0 &&
+                     q.I % te == 0,
+                 "qt_pack_weights_batched: item %d: O=%d I=%d must be multiples of %d for k=%d (k in {1,3})", j, q.O, q.I,
+                 te, q.k);
+    a.w[j] = q.w_oihw; a.fwd[j] = q.w_fwd; a.dgrad[j] = q.w_dgrad;
+    a.O[j] = q.O; a.I[j] = q.I; a.k[j] = (unsigned char)q.k; a.s2[j] = q.stride2_dgrad ? 1 : 0;
+    a.first_block[j] = blocks;
+    blocks += (q.O / te) * (q.I / te);
+  }
+  a.first_block[n] = blocks;
+  a.n = n;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

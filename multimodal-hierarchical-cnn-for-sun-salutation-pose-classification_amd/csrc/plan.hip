@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -496,22 +497,26 @@ struct Exec {
 
 int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, void* stream) {
   Exec e{p, static_cast<unsigned char*>(workspace), T, stream, p->d.batch, p->d.dtype};
+  // one launch for every conv / linear operand (plus the 9 K-element stem filter)
+  std::vector<qt_pack_item> items;
+  auto add = [&](const float* w, void* fwd, void* dgrad, int O, int I, int k, bool s2) {
+    qt_pack_item q;
+    q.w_oihw = w; q.w_fwd = fwd; q.w_dgrad = dgrad; q.O = O; q.I = I; q.k = k; q.stride2_dgrad = s2;
+    items.push_back(q);
+  };
   if (p->has_image) {
     for (size_t i = 0; i < p->convs.size(); ++i) {
       const ConvL& c = p->convs[i];
-      if (i == 0) {
+      if (i == 0)
         e.run(qt_pack_stem_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), e.stem_taps(), stream));
-      } else {
-        const bool s2 = c.stride == 2;
-        e.run(qt_pack_conv_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), (for_backward && !s2) ? e.at(c.w_dgrad) : nullptr,
-                                  c.cout, c.cin, c.k, c.k, stream));
-        if (for_backward && s2)
-          e.run(qt_pack_dgrad_s2(e.dt, e.tf(c.w), e.at(c.w_dgrad), c.cout, c.cin, c.k, nullptr, nullptr, nullptr, stream));
-      }
+      else
+        add(e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2);
     }
   }
-  e.run(qt_pack_conv_weight(e.dt, e.tf(p->cls0.w), e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr,
-                            p->cls0.out, p->cls0.in, 1, 1, stream));
+  add(e.tf(p->cls0.w), e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1,
+      false);
+  for (size_t j = 0; j < items.size() && e.ok(); j += 32)
+    e.run(qt_pack_weights_batched(e.dt, items.data() + j, (int)std::min<size_t>(32, items.size() - j), stream));
   return e.status;
 }
 

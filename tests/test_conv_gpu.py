@@ -371,3 +371,44 @@ def test_stride2_dgrad_by_parity_classes(dt, cfg):
     if k == 1:  # pixels no tap reaches were never written: only class (0,0) is defined
         got, ref = got[:, :, ::2, ::2], ref[:, :, ::2, ::2]
     assert rel_err(got, ref) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batched_weight_pack_matches_per_layer_packing(dt):
+    """qt_pack_weights_batched (one launch, LDS tile transposes) must reproduce qt_pack_conv_weight and
+    the parity-class layout of qt_pack_dgrad_s2 bit for bit."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+
+    class Item(ctypes.Structure):
+        _fields_ = [("w", ctypes.c_void_p), ("fwd", ctypes.c_void_p), ("dgrad", ctypes.c_void_p),
+                    ("O", ctypes.c_int), ("I", ctypes.c_int), ("k", ctypes.c_int), ("s2", ctypes.c_int)]
+
+    g = torch.Generator().manual_seed(31)
+    shapes = [(64, 64, 3, 0), (128, 64, 3, 1), (128, 64, 1, 1), (512, 256, 3, 1), (128, 192, 1, 0), (2688, 5376, 1, 0)]
+    qdt = L.qt_dtype(dt)
+    st = L.stream_ptr()
+    items = (Item * len(shapes))()
+    keep, want = [], []
+    for j, (O, I, k, s2) in enumerate(shapes):
+        w = torch.randn(O, I, k, k, generator=g).to(dev)
+        fwd = torch.zeros(O * k * k * I, dtype=dt, device=dev)
+        dg = torch.zeros(O * k * k * I, dtype=dt, device=dev)
+        rf, rd = torch.zeros_like(fwd), torch.zeros_like(dg)
+        if s2:
+            L.check(lib.qt_pack_conv_weight(qdt, L.ptr(w), L.ptr(rf), None, O, I, k, k, st), "qt_pack_conv_weight")
+            L.check(lib.qt_pack_dgrad_s2(qdt, L.ptr(w), L.ptr(rd), O, I, k, None, None, None, st), "qt_pack_dgrad_s2")
+        else:
+            L.check(lib.qt_pack_conv_weight(qdt, L.ptr(w), L.ptr(rf), L.ptr(rd), O, I, k, k, st), "qt_pack_conv_weight")
+        items[j] = Item(w.data_ptr(), fwd.data_ptr(), dg.data_ptr(), O, I, k, s2)
+        keep.append((w, fwd, dg))
+        want.append((rf, rd))
+    L.check(lib.qt_pack_weights_batched(qdt, items, len(shapes), st), "qt_pack_weights_batched")
+    torch.cuda.synchronize()
+    for (w, fwd, dg), (rf, rd), shp in zip(keep, want, shapes):
+        assert torch.equal(fwd, rf), shp
+        assert torch.equal(dg, rd), shp
+    # bad shapes are refused, not mangled
+    bad = (Item * 1)(Item(keep[0][0].data_ptr(), keep[0][1].data_ptr(), None, 48, 64, 3, 0))
+    assert lib.qt_pack_weights_batched(qdt, bad, 1, st) == -1 and b"multiples of" in lib.qt_last_error()
