@@ -209,7 +209,8 @@ def main():
                 traffic, traffic_src = fam["hbm_bytes_per_launch"], os.path.relpath(tf, ROOT)
             except Exception:
                 pass
-            roofline = {"kernel": "conv_igemm_kernel (implicit-GEMM conv, fwd + dgrad launches)",
+            roofline = {"kernel": "forward + data-gradient conv launches (conv_igemm_kernel; conv_l1_ring_kernel for the "
+                                  "56x56 64->64 layers; conv_stem_kernel for conv1)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(1e3 * (ms[0] + ms[1]) / nig, 2),
