@@ -182,6 +182,13 @@ int qt_bn_finalize(float* partial, int rows, int C, long long count, const float
 /* eval mode: scale/shift from running statistics */
 int qt_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int C, float* scale, float* shift, void* stream);
+/* the same for up to 32 BatchNorms in one launch (an eval forward needs all of them up front) */
+typedef struct qt_bn_eval_item {
+  const float *gamma, *beta, *running_mean, *running_var;
+  float *scale, *shift;
+  int C;
+} qt_bn_eval_item;
+int qt_bn_eval_affine_batched(const qt_bn_eval_item* items, int n, float eps, void* stream);
 /* out = relu?( y*scale+shift + (residual ? residual*res_scale+res_shift : 0) ), [M][C] */
 int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
               const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C, void* stream);

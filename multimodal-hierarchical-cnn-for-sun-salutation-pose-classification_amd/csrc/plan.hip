@@ -488,10 +488,20 @@ struct Exec {
       run(qt_bn_finalize(part, rows, bn.C, rows_of(c), tf(bn.gamma), tf(bn.beta), tf(bn.rmean),
                          tf(bn.rvar), static_cast<long long*>(T[bn.nbt]), p->d.bn_momentum, p->d.bn_eps,
                          at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.scale), at<float>(bn.shift), stream));
-    } else {
-      run(qt_bn_eval_affine(tf(bn.gamma), tf(bn.beta), tf(bn.rmean), tf(bn.rvar), p->d.bn_eps, bn.C,
-                            at<float>(bn.scale), at<float>(bn.shift), stream));
     }
+    // eval: scale / shift of every BatchNorm were set by eval_affines() at the start of the forward
+  }
+  // eval mode: running statistics -> scale / shift of all BatchNorms in one launch
+  void eval_affines() {
+    std::vector<qt_bn_eval_item> items;
+    for (const BnL& bn : p->bns) {
+      qt_bn_eval_item q;
+      q.gamma = tf(bn.gamma); q.beta = tf(bn.beta); q.running_mean = tf(bn.rmean); q.running_var = tf(bn.rvar);
+      q.scale = at<float>(bn.scale); q.shift = at<float>(bn.shift); q.C = bn.C;
+      items.push_back(q);
+    }
+    for (size_t j = 0; j < items.size() && ok(); j += 32)
+      run(qt_bn_eval_affine_batched(items.data() + j, (int)std::min<size_t>(32, items.size() - j), p->d.bn_eps, stream));
   }
 };
 
@@ -551,6 +561,7 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
                         e.at<unsigned char>(p->fused) + (size_t)p->mlp_col0 * p->esz, e.stream));
   };
   if (p->has_image) {
+    if (!tr) e.eval_affines();
     // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
     e.run(qt_pack_stem_input(dt, image, e.at(p->xpad), batch, stream));
     const ConvL& c0 = p->convs[0];
