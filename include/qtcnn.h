@@ -241,6 +241,17 @@ int qt_relu_mask_scale(int dtype, void* g, const void* act, long long n, float m
 /* out[c] (+)= sum_r x[r*ld+c]  (bias gradients) */
 int qt_col_sum(int dtype, const void* x, long long rows, int cols, int ld, float* out, int accumulate, void* stream);
 
+/* nn.Linear on a small batch with a large weight matrix (classifier.0: Linear(5376 -> 2688) + ReLU,
+ * Quadtree_from scratch/models.py:266-268, and its backward-input product), bf16:
+ *   y[m][n] = relu?( bias[n] + sum_k x[m][k] * w[n][k] ),  x [M][K], w [N][K], y [M][N]
+ * split over K so that every CU streams a disjoint block of the weights once; partial products go
+ * through `workspace` (qt_linear_workspace_bytes, f32 [S][M][N]) and are added in a fixed order.
+ * Covers M <= 256, N % 64 == 0, K % 64 == 0; anything else returns QT_ERR_UNSUPPORTED (use
+ * qt_conv2d_igemm with a 1x1 descriptor). */
+size_t qt_linear_workspace_bytes(int M, int N, int K);
+int qt_linear_bf16(const void* x, const void* w, const float* bias, int relu, void* y, int M, int N, int K,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Thin dense products (nn.Linear 47->94->256 and 2688->12 and their gradients,
  * Quadtree_from scratch/models.py:255-260,270): C[m][n] = relu?(acc? + bias[n] +

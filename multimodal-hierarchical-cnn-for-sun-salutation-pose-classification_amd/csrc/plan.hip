@@ -78,6 +78,7 @@ struct qt_plan {
   size_t stats = 0, ones = 0, zeros = 0, gbase_tmp = 0;
   size_t stats_bn2 = 0, stats_ds = 0, stats_bn1 = 0;
   size_t dw_begin = 0, dw_end = 0;
+  size_t lin_ws = 0, lin_ws_bytes = 0;          // split-K partials of classifier.0 (forward / backward-input)
   size_t wgrad_part = 0, wgrad_part_bytes = 0;  // partial filters of the streaming weight-gradient kernel
   bool dw_dirty = true;  // weight-gradient scratch holds sums of an earlier backward
   int bwd_rows_bn2 = 0;  // carried from the layer4 phase to the rest-of-backbone phase  // BatchNorm-backward partials emitted by dgrad epilogues
@@ -266,6 +267,12 @@ void layout_workspace(qt_plan* p) {
   // batch): the streaming weight-gradient launches run one after another on the side stream and share it
   p->wgrad_part_bytes = (size_t)256 * 64 * 9 * 64 * 4;
   p->wgrad_part = ws.take(p->wgrad_part_bytes);
+  {
+    const int mb = B < 256 ? (int)B : 256;
+    const size_t f = qt_linear_workspace_bytes(mb, p->cls0.out, p->cls0.in), g = qt_linear_workspace_bytes(mb, p->cls0.in, p->cls0.out);
+    p->lin_ws_bytes = f > g ? f : g;
+    p->lin_ws = ws.take(p->lin_ws_bytes > 0 ? p->lin_ws_bytes : 16);
+  }
   for (LinL* l : {&p->cls0}) {
     l->w_fwd = ws.take((size_t)l->in * l->out * es);
     l->w_dgrad = ws.take((size_t)l->in * l->out * es);
@@ -450,6 +457,24 @@ struct Exec {
     const int slot = begin_timed(conv_flops(d), kind >= 0 ? kind : (d.mode == QT_CONV_FWD ? 0 : 1));
     run(qt_conv2d_igemm(&dd, &io, stream));
     end_timed(slot);
+  }
+
+  // classifier.0 and its backward-input product: split-K kernel for small batches in bf16 (every CU
+  // streams a slice of the 29 MB weight matrix once); other shapes and the f32 build run as an
+  // implicit GEMM on 1x1 images.  d describes the product like a 1x1 convolution.
+  void linear(const qt_conv_desc& d, const void* x, const void* w, void* y, const float* bias, int relu) {
+    if (!ok()) return;
+    if (dt == QT_BF16 && B <= 256) {
+      const int slot = begin_timed(conv_flops(d), d.mode == QT_CONV_FWD ? 0 : 1);
+      const int st = qt_linear_bf16(x, w, bias, relu, y, B, d.n_out, d.k_per_tap, at(p->lin_ws), p->lin_ws_bytes, stream);
+      end_timed(slot);
+      if (st == QT_OK) return;
+      if (st != QT_ERR_UNSUPPORTED) {
+        run(st);
+        return;
+      }
+    }
+    igemm(d, x, w, y, nullptr, bias, nullptr, nullptr, nullptr, relu);
   }
 
   // algorithmic FLOPs (2*MAC of the convolution as the reference computes it: the
@@ -648,8 +673,8 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
   if (p->has_numerical && !p->has_image) mlp_branch();  // numerical_only: nothing to overlap with
   e.join();  // quadrant + MLP columns of the fused matrix are complete
   // ---- classifier: Linear -> ReLU -> Dropout -> Linear ----
-  e.igemm(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD), e.at(p->fused), e.at(p->cls0.w_fwd), e.at(p->hidden),
-          nullptr, e.tf(p->cls0.b), nullptr, nullptr, nullptr, 1);
+  e.linear(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD), e.at(p->fused), e.at(p->cls0.w_fwd), e.at(p->hidden),
+           e.tf(p->cls0.b), 1);
   if (tr && p->d.dropout_p > 0.f)
     e.run(qt_dropout(dt, e.at(p->hidden), batch, p->hidden_dim, p->hidden_dim, seed ^ 0xA5A5A5A55A5A5A5Aull,
                      p->d.dropout_p, stream));
@@ -824,8 +849,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     }
     const bool need_dfused = p->has_numerical || (p->has_image && (!p->standard || backbone_grads));
     if (need_dfused)
-      e.igemm(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_DGRAD), e.at(p->dhidden), e.at(p->cls0.w_dgrad),
-              e.at(p->dfused), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+      e.linear(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_DGRAD), e.at(p->dhidden), e.at(p->cls0.w_dgrad), e.at(p->dfused),
+               nullptr, 0);
     // ---- numerical MLP ----
     if (p->has_numerical) {
       const unsigned char* dz = e.at<unsigned char>(p->dfused) + (size_t)p->mlp_col0 * p->esz;

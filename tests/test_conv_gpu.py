@@ -412,3 +412,39 @@ def test_batched_weight_pack_matches_per_layer_packing(dt):
     # bad shapes are refused, not mangled
     bad = (Item * 1)(Item(keep[0][0].data_ptr(), keep[0][1].data_ptr(), None, 48, 64, 3, 0))
     assert lib.qt_pack_weights_batched(qdt, bad, 1, st) == -1 and b"multiples of" in lib.qt_last_error()
+
+
+@pytest.mark.parametrize("cfg", [
+    (256, 2688, 5376, True, 1),    # classifier.0 forward
+    (256, 5376, 2688, False, 0),   # its backward-input product
+    (37, 2688, 5376, True, 1),     # ragged batch
+    (5, 64, 64, True, 0),          # one tile, one K-step
+    (200, 192, 448, False, 1),     # seven K-steps, not divisible into 256/3 slices
+])
+def test_linear_splitk_bf16(cfg):
+    """qt_linear_bf16 (csrc/linear.hip) against F.linear in f32 on bf16-representable operands."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    M, N, K, with_bias, relu = cfg
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) if with_bias else None
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    if relu:
+        ref = torch.relu(ref)
+    lib.qt_linear_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = lib.qt_linear_workspace_bytes(M, N, K)
+    assert nbytes >= M * N * 4
+    ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=dev)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    xd, wd = x.to(dev), w.to(dev)
+    bd = b.to(dev) if b is not None else None
+    L.check(lib.qt_linear_bf16(L.ptr(xd), L.ptr(wd), L.ptr(bd), relu, L.ptr(y), M, N, K, L.ptr(ws), ctypes.c_size_t(nbytes),
+                               L.stream_ptr()), "qt_linear_bf16")
+    torch.cuda.synchronize()
+    assert rel_err(y.float().cpu(), ref) <= 4e-3   # one bf16 rounding of the output
+    # uncovered shapes are reported, not mangled
+    assert lib.qt_linear_bf16(L.ptr(xd), L.ptr(wd), L.ptr(bd), relu, L.ptr(y), 300, N, K, L.ptr(ws), ctypes.c_size_t(nbytes),
+                              L.stream_ptr()) == -3   # QT_ERR_UNSUPPORTED
