@@ -851,33 +851,36 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     if (need_dfused)
       e.linear(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_DGRAD), e.at(p->dhidden), e.at(p->cls0.w_dgrad), e.at(p->dfused),
                nullptr, 0);
-    // ---- numerical MLP ----
+    // ---- numerical MLP: seven small dependent kernels that only need dfused; they run on the side
+    // stream (behind classifier.0's weight gradient) while the main stream enters the backbone ----
     if (p->has_numerical) {
+      e.fork();
+      void* ms = e.wstream ? e.wstream : stream;
       const unsigned char* dz = e.at<unsigned char>(p->dfused) + (size_t)p->mlp_col0 * p->esz;
-      if (e.gf(p->mlp1.b)) e.run(qt_col_sum(dt, dz, B, p->mlp1.out, p->fused_ld, e.gf(p->mlp1.b), 0, stream));
+      if (e.gf(p->mlp1.b)) e.run(qt_col_sum(dt, dz, B, p->mlp1.out, p->fused_ld, e.gf(p->mlp1.b), 0, ms));
       if (e.gf(p->mlp1.w)) {
         memset(&g, 0, sizeof(g));
         g.M = p->mlp1.out; g.N = p->mlp1.in; g.K = B;
         g.a_dtype = dt; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
         g.a_row_stride = 1; g.a_k_stride = p->fused_ld; g.b_row_stride = 1; g.b_k_stride = p->mlp1.in;
         g.c_row_stride = p->mlp1.in;
-        e.run(qt_gemm_small(&g, dz, e.at(p->h1), nullptr, e.gf(p->mlp1.w), stream));
+        e.run(qt_gemm_small(&g, dz, e.at(p->h1), nullptr, e.gf(p->mlp1.w), ms));
       }
       memset(&g, 0, sizeof(g));
       g.M = B; g.N = p->mlp1.in; g.K = p->mlp1.out;
       g.a_dtype = dt; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
       g.a_row_stride = p->fused_ld; g.a_k_stride = 1; g.b_row_stride = 1; g.b_k_stride = p->mlp1.in;
       g.c_row_stride = p->mlp1.in;
-      e.run(qt_gemm_small(&g, dz, e.tf(p->mlp1.w), nullptr, e.at(p->dh1), stream));
-      e.run(qt_relu_mask_scale(QT_F32, e.at(p->dh1), e.at(p->h1), (long long)B * p->mlp0.out, drop_mul, stream));
-      if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, p->mlp0.out, p->mlp0.out, e.gf(p->mlp0.b), 0, stream));
+      e.run(qt_gemm_small(&g, dz, e.tf(p->mlp1.w), nullptr, e.at(p->dh1), ms));
+      e.run(qt_relu_mask_scale(QT_F32, e.at(p->dh1), e.at(p->h1), (long long)B * p->mlp0.out, drop_mul, ms));
+      if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, p->mlp0.out, p->mlp0.out, e.gf(p->mlp0.b), 0, ms));
       if (e.gf(p->mlp0.w)) {
         memset(&g, 0, sizeof(g));
         g.M = p->mlp0.out; g.N = p->mlp0.in; g.K = B;
         g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
         g.a_row_stride = 1; g.a_k_stride = p->mlp0.out; g.b_row_stride = 1; g.b_k_stride = p->mlp0.in;
         g.c_row_stride = p->mlp0.in;
-        e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), stream));
+        e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), ms));
       }
     }
     // ---- quadrant head (weights are trainable in every variant) ----
