@@ -14,7 +14,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: F401,E402  (loads the process-wide HIP runtime first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqtcnn_hip.so")
+# QTCNN_LIB_PATH: another build of the same ABI (A/B measurements of two kernel versions on one box)
+LIB_PATH = os.environ.get("QTCNN_LIB_PATH") or os.path.join(_HERE, "libqtcnn_hip.so")
 
 QT_F32, QT_BF16 = 0, 1
 QT_CONV_FWD, QT_CONV_DGRAD = 0, 1

@@ -819,16 +819,9 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
 
   if (phases & QT_BWD_HEAD) {
     qt_gemm_small_desc g;
-    // ---- classifier.3 ----
-    if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, B, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, stream));
-    if (e.gf(p->cls3.w)) {
-      memset(&g, 0, sizeof(g));
-      g.M = p->cls3.out; g.N = p->cls3.in; g.K = B;
-      g.a_dtype = QT_F32; g.b_dtype = dt; g.c_dtype = QT_F32;
-      g.a_row_stride = 1; g.a_k_stride = p->cls3.out; g.b_row_stride = 1; g.b_k_stride = p->cls3.in;
-      g.c_row_stride = p->cls3.in;
-      e.run(qt_gemm_small(&g, dlogits, e.at(p->hidden), nullptr, e.gf(p->cls3.w), stream));
-    }
+    // The chain the backbone waits for is  dlogits -> dhidden -> dfused -> (pool backward); bias sums and
+    // weight gradients hang off it and go to the side stream as soon as their inputs exist.
+    // ---- classifier.3: d(loss)/d(hidden), then ReLU + dropout backward ----
     memset(&g, 0, sizeof(g));
     g.M = B; g.N = p->cls3.in; g.K = p->cls3.out;
     g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = dt;
@@ -836,16 +829,27 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     g.c_row_stride = p->cls3.in;
     e.run(qt_gemm_small(&g, dlogits, e.tf(p->cls3.w), nullptr, e.at(p->dhidden), stream));
     e.run(qt_relu_mask_scale(dt, e.at(p->dhidden), e.at(p->hidden), (long long)B * p->hidden_dim, drop_mul, stream));
-    // ---- classifier.0 ----
-    if (e.gf(p->cls0.b))
-      e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, stream));
     const qt_conv_desc lf = e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD);
-    if (e.gf(p->cls0.w)) {
+    {
       e.fork();
-      e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, e.wstream));
-      const int slot = e.begin_timed(e.conv_flops(lf), 2, e.wstream);
-      e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), e.wstream));
-      e.end_timed(slot, e.wstream);
+      void* ss = e.wstream ? e.wstream : stream;
+      if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, B, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, ss));
+      if (e.gf(p->cls3.w)) {
+        memset(&g, 0, sizeof(g));
+        g.M = p->cls3.out; g.N = p->cls3.in; g.K = B;
+        g.a_dtype = QT_F32; g.b_dtype = dt; g.c_dtype = QT_F32;
+        g.a_row_stride = 1; g.a_k_stride = p->cls3.out; g.b_row_stride = 1; g.b_k_stride = p->cls3.in;
+        g.c_row_stride = p->cls3.in;
+        e.run(qt_gemm_small(&g, dlogits, e.at(p->hidden), nullptr, e.gf(p->cls3.w), ss));
+      }
+      // ---- classifier.0: bias and weight gradients ----
+      if (e.gf(p->cls0.b)) e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, ss));
+      if (e.gf(p->cls0.w)) {
+        e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, ss));
+        const int slot = e.begin_timed(e.conv_flops(lf), 2, ss);
+        e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), ss));
+        e.end_timed(slot, ss);
+      }
     }
     const bool need_dfused = p->has_numerical || (p->has_image && (!p->standard || backbone_grads));
     if (need_dfused)
@@ -887,7 +891,10 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     if (p->has_image && !p->standard) {
       const ConvL& cq = p->convs[p->quad_conv];
       e.run(qt_quad_pool_bwd(dt, e.at(p->dfused), e.at(p->q), e.at(p->dq), B, p->fused_ld, 512, stream));
-      if (e.gf(cq.bias)) e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, stream));
+      if (e.gf(cq.bias)) {
+        e.fork();
+        e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, e.wstream ? e.wstream : stream));
+      }
       e.wgrad(cq, e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), false);
     }
   }
