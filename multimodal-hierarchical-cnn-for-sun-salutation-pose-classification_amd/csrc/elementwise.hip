@@ -367,6 +367,87 @@ __global__ void stem_pool_kernel(const T* __restrict__ y, const float* __restric
   }
 }
 
+// d(loss)/d(conv1 output) of the stem in one pass, 2 x 2 conv1 positions per thread: the four
+// positions (2a..2a+1, 2b..2b+1) receive gradient from the pooled cells (a,b), (a,b+1), (a+1,b),
+// (a+1,b+1) only, so a thread loads each cell once (a per-position gather loads 9 cells for the same
+// four outputs) and has 12 independent 16-byte loads in flight.  Same sums in the same order as
+// stem_pool_bwd_kernel<T, 2>.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_bwd_apply2x2_kernel(
+    const T* __restrict__ dpooled, const unsigned char* __restrict__ argmax, const T* __restrict__ y,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ out, int batch) {
+  constexpr int H = 112, W = 112, C = 64, PH = 56, PW = 56;
+  const long long total = (long long)batch * PH * PW * (C / 8);
+  const int c0 = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) % (C / 8)) * 8;
+  float sc[8], sh[8], mu[8], is[8], ca[8], cb[8], cc[8];
+  load8f(scale + c0, sc);
+  load8f(shift + c0, sh);
+  load8f(mean + c0, mu);
+  load8f(invstd + c0, is);
+  load8f(coef + c0, ca);
+  load8f(coef + C + c0, cb);
+  load8f(coef + 2 * C + c0, cc);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)((i / (C / 8)) % PW);
+    const int a = (int)((i / ((C / 8) * PW)) % PH);
+    const int n = (int)(i / ((long long)(C / 8) * PW * PH));
+    const bool a1 = a + 1 < PH, b1 = b + 1 < PW;
+    const long long cell = (((long long)n * PH + a) * PW + b) * C + c0;
+    uint2 k00 = *reinterpret_cast<const uint2*>(argmax + cell), k01 = make_uint2(0xffffffffu, 0xffffffffu), k10 = k01, k11 = k01;
+    float d00[8], d01[8], d10[8], d11[8];
+    QtVec8<T>::load(dpooled + cell, d00);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d01[e] = d10[e] = d11[e] = 0.f;
+    if (b1) {
+      k01 = *reinterpret_cast<const uint2*>(argmax + cell + C);
+      QtVec8<T>::load(dpooled + cell + C, d01);
+    }
+    if (a1) {
+      k10 = *reinterpret_cast<const uint2*>(argmax + cell + PW * C);
+      QtVec8<T>::load(dpooled + cell + PW * C, d10);
+    }
+    if (a1 && b1) {
+      k11 = *reinterpret_cast<const uint2*>(argmax + cell + PW * C + C);
+      QtVec8<T>::load(dpooled + cell + PW * C + C, d11);
+    }
+    const long long pos = (((long long)n * H + 2 * a) * W + 2 * b) * C + c0;
+    float y00[8], y01[8], y10[8], y11[8];
+    QtVec8<T>::load(y + pos, y00);
+    QtVec8<T>::load(y + pos + C, y01);
+    QtVec8<T>::load(y + pos + W * C, y10);
+    QtVec8<T>::load(y + pos + W * C + C, y11);
+    float o00[8], o01[8], o10[8], o11[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int sft = (e & 3) * 8;
+      const int i00 = ((e < 4 ? k00.x : k00.y) >> sft) & 0xff, i01 = ((e < 4 ? k01.x : k01.y) >> sft) & 0xff;
+      const int i10 = ((e < 4 ? k10.x : k10.y) >> sft) & 0xff, i11 = ((e < 4 ? k11.x : k11.y) >> sft) & 0xff;
+      // taps kh*3+kw with kh = h - (2*ph - 1), kw = w - (2*pw - 1)
+      float g00 = i00 == 4 ? d00[e] : 0.f;
+      float g01 = (i00 == 5 ? d00[e] : 0.f) + (i01 == 3 ? d01[e] : 0.f);
+      float g10 = (i00 == 7 ? d00[e] : 0.f) + (i10 == 1 ? d10[e] : 0.f);
+      float g11 = (i00 == 8 ? d00[e] : 0.f);
+      g11 += (i01 == 6 ? d01[e] : 0.f);
+      g11 += (i10 == 2 ? d10[e] : 0.f);
+      g11 += (i11 == 0 ? d11[e] : 0.f);
+      g00 = (y00[e] * sc[e] + sh[e] > 0.f) ? g00 : 0.f;
+      g01 = (y01[e] * sc[e] + sh[e] > 0.f) ? g01 : 0.f;
+      g10 = (y10[e] * sc[e] + sh[e] > 0.f) ? g10 : 0.f;
+      g11 = (y11[e] * sc[e] + sh[e] > 0.f) ? g11 : 0.f;
+      o00[e] = ca[e] * (g00 - cb[e] - (y00[e] - mu[e]) * is[e] * cc[e]);
+      o01[e] = ca[e] * (g01 - cb[e] - (y01[e] - mu[e]) * is[e] * cc[e]);
+      o10[e] = ca[e] * (g10 - cb[e] - (y10[e] - mu[e]) * is[e] * cc[e]);
+      o11[e] = ca[e] * (g11 - cb[e] - (y11[e] - mu[e]) * is[e] * cc[e]);
+    }
+    QtVec8<T>::store(out + pos, o00);
+    QtVec8<T>::store(out + pos + C, o01);
+    QtVec8<T>::store(out + pos + W * C, o10);
+    QtVec8<T>::store(out + pos + W * C + C, o11);
+  }
+}
+
 // BatchNorm-backward sums of the stem from the POOLED side: every pooled cell sends its gradient
 // to exactly one conv1 position (its argmax), so
 //   sum_pos g = sum_cells [bn(y*) > 0] d,   sum_pos g*xhat = sum_cells [bn(y*) > 0] d * (y* - mean) * invstd
@@ -921,11 +1002,13 @@ extern "C" int qt_stem_bn_bwd_apply(int dtype, const void* dpooled, const unsign
   QT_CHECK_ARG(dpooled && argmax && y && scale && shift && mean && invstd && coef && dy && batch > 0,
                "qt_stem_bn_bwd_apply: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int grid = grid_for((long long)batch * 112 * 112 * 8);
+  const int grid = grid_for((long long)batch * 56 * 56 * 8);
   if (dtype == QT_F32)
-    launch_stem_bwd<float>(2, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, coef, nullptr, dy, batch);
+    hipLaunchKernelGGL(stem_bn_bwd_apply2x2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dpooled, argmax,
+                       (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, batch);
   else
-    launch_stem_bwd<bf16_t>(2, grid, s, dpooled, argmax, y, scale, shift, mean, invstd, coef, nullptr, dy, batch);
+    hipLaunchKernelGGL(stem_bn_bwd_apply2x2_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dpooled, argmax,
+                       (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, batch);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
