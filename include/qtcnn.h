@@ -153,6 +153,28 @@ typedef struct qt_pack_item {
   int O, I, k, stride2_dgrad;
 } qt_pack_item;
 int qt_pack_weights_batched(int dtype, const qt_pack_item* items, int n, void* stream);
+/* Adam with L2-in-gradient weight decay, torch.optim.Adam semantics without amsgrad / maximize
+ * (the reference's optimizer, Quadtree_from scratch/Quadtree_train.py:45: lr 1e-4, weight_decay 1e-4):
+ *   g = grad*grad_scale + wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)                 all f32
+ * qt_adam_multi: any list of tensors in one launch per 48 tensors.
+ * qt_adam_pack_weights_batched: the same update INSIDE the one-launch weight packing, so the f32
+ * masters, both moments and the packed operand copies are each touched once per step
+ * (opt[j].param must be items[j].w_oihw).  `step` counts from 1; grad_scale 0 means 1. */
+typedef struct qt_adam_desc {
+  float lr, beta1, beta2, eps, weight_decay, grad_scale;
+  int step;
+} qt_adam_desc;
+typedef struct qt_adam_item {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long numel;
+} qt_adam_item;
+int qt_adam_multi(const qt_adam_item* items, int n, const qt_adam_desc* adam, void* stream);
+int qt_adam_pack_weights_batched(int dtype, const qt_pack_item* items, const qt_adam_item* opt, const qt_adam_desc* adam,
+                                 int n, void* stream);
 /* Data-gradient operand of a stride-2 conv (k = 3 pad 1, or k = 1 pad 0) split by the parity
  * (ph, pw) of the input pixel: class c = ph*2+pw gets [I][taps_c][O] with only the taps that
  * reach it (k=3: 1,2,2,4 taps; k=1: 1,0,0,0), stored back to back in class order.  Row taps of
@@ -332,6 +354,12 @@ int qt_plan_profile_end(qt_plan* plan, double* flops3, double* ms3, int* launche
 int qt_plan_side_fence(qt_plan* plan, void* waiting_stream);
 int qt_plan_init_workspace(qt_plan* plan, void* workspace, void* stream);
 int qt_plan_pack_weights(qt_plan* plan, void* workspace, void* const* tensors, int for_backward, void* stream);
+/* Optimizer step fused with the re-packing (replaces optimizer.step() + qt_plan_pack_weights of a
+ * training step; Quadtree_from scratch/Quadtree_train.py:66): per plan tensor one gradient pointer
+ * (NULL = frozen / unused: only re-packed) and its two Adam moments.  The conv / linear weights are
+ * updated inside the one-launch packing kernel, the rest by qt_adam_multi. */
+int qt_plan_adam_step(qt_plan* plan, void* workspace, void* const* tensors, float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const qt_adam_desc* adam, int for_backward, void* stream);
 int qt_plan_forward(qt_plan* plan, void* workspace, void* const* tensors, const float* image, const float* numerical,
                     float* logits, int batch, int training, unsigned long long seed, void* stream);
 int qt_plan_backward(qt_plan* plan, void* workspace, void* const* tensors, float* const* grads, const float* numerical,

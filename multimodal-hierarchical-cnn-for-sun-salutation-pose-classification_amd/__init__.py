@@ -7,6 +7,7 @@ or put `<this dir>/quadtree_from_scratch` (or `/resnet`) on sys.path and keep th
 reference's `from models import get_model`.
 """
 from ._lib import LIB_PATH, QtError  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
 from .quadtree import QuadtreeCNN, StandardResNetCNN  # noqa: F401
 
-__all__ = ["QuadtreeCNN", "StandardResNetCNN", "QtError", "LIB_PATH"]
+__all__ = ["QuadtreeCNN", "StandardResNetCNN", "FusedAdam", "QtError", "LIB_PATH"]

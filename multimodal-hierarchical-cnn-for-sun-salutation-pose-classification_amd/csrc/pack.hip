@@ -5,6 +5,7 @@
 //  * OIHW f32 master weights (the reference's state_dict layout)
 //    -> [O][kh][kw][I] forward operand and [I][kh][kw][O] data-gradient operand.
 //  * [O][kh][kw][I] f32 weight gradients -> OIHW f32 .grad tensors.
+#include <math.h>
 #include <string.h>
 
 #include "qt_common.h"
@@ -66,8 +67,31 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
 // form for stride-2 convs, see pack_dgrad_s2_kernel) in runs of 32 o.  The per-element kernels above
 // scatter 2-byte stores with a stride of taps*O elements and need one launch per layer (0.42 ms per
 // training step for the 26 M parameters of QuadtreeCNN); this one moves the same bytes in ~60 us.
+// Adam with L2-in-gradient weight decay, torch.optim.Adam semantics (amsgrad / maximize off):
+//   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// (the reference's optimizer: Quadtree_from scratch/Quadtree_train.py:45, resnet/train_cnn_model.py:65)
+struct AdamScalars {
+  float lr, b1, b2, eps, wd;
+  float step_size;     // lr / (1 - b1^t)
+  float inv_sqrt_bc2;  // 1 / sqrt(1 - b2^t)
+  float grad_scale;    // multiplies the incoming gradient (1 = none)
+  int enabled;
+};
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamScalars& h) {
+  g = g * h.grad_scale + h.wd * p;
+  m = h.b1 * m + (1.f - h.b1) * g;
+  v = h.b2 * v + (1.f - h.b2) * g * g;
+  const float denom = sqrtf(v) * h.inv_sqrt_bc2 + h.eps;
+  return p - h.step_size * (m / denom);
+}
+
 constexpr int PK_MAX_ITEMS = 32;
 struct PackBatchArgs {
+  AdamScalars adam;                  // enabled: the masters are updated in the same pass
+  const float* g[PK_MAX_ITEMS];
+  float* m[PK_MAX_ITEMS];
+  float* v[PK_MAX_ITEMS];
   const float* w[PK_MAX_ITEMS];
   void* fwd[PK_MAX_ITEMS];
   void* dgrad[PK_MAX_ITEMS];
@@ -91,12 +115,22 @@ template <> struct PackPair<bf16_t> {
 
 // one TO(o) x TI(i) x TAPS tile; `tile` holds it as [o][i*TAPS + tap] with an odd row stride
 template <typename T, int TAPS, int TO, int TI>
-__device__ __forceinline__ void pack_tile(float* tile, const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dg,
-                                          int O, int I, int o0, int i0, bool s2) {
+__device__ __forceinline__ void pack_tile(float* tile, const float* w, T* __restrict__ fwd, T* __restrict__ dg,
+                                          int O, int I, int o0, int i0, bool s2, const AdamScalars& adam,
+                                          const float* __restrict__ g, float* m, float* v) {
   constexpr int RUN = TI * TAPS, S = RUN + 1, TOTAL = TO * RUN;
   for (int e = threadIdx.x; e < TOTAL; e += 256) {
     const int o = e / RUN, r = e - o * RUN;
-    tile[o * S + r] = w[((long long)(o0 + o) * I + i0) * TAPS + r];
+    const long long idx = ((long long)(o0 + o) * I + i0) * TAPS + r;
+    float pv = w[idx];
+    if (adam.enabled) {  // optimizer step on the f32 master, then the fresh value is what gets packed
+      float mv = m[idx], vv = v[idx];
+      pv = adam_update(pv, g[idx], mv, vv, adam);
+      m[idx] = mv;
+      v[idx] = vv;
+      const_cast<float*>(w)[idx] = pv;
+    }
+    tile[o * S + r] = pv;
   }
   __syncthreads();
   if (fwd) {
@@ -145,10 +179,46 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(PackBatchArgs
   T* dg = static_cast<T*>(a.dgrad[it]);
   if (a.k[it] == 1) {
     const int tiles_i = I / PK_T1;
-    pack_tile<T, 1, PK_T1, PK_T1>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) * PK_T1, (b % tiles_i) * PK_T1, false);
+    pack_tile<T, 1, PK_T1, PK_T1>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) * PK_T1, (b % tiles_i) * PK_T1, false, a.adam,
+                                  a.g[it], a.m[it], a.v[it]);
   } else {
     const int tiles_i = I >> 5;
-    pack_tile<T, 9, 32, 32>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) << 5, (b % tiles_i) << 5, a.s2[it] != 0);
+    pack_tile<T, 9, 32, 32>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) << 5, (b % tiles_i) << 5, a.s2[it] != 0, a.adam,
+                            a.g[it], a.m[it], a.v[it]);
+  }
+}
+
+// Plain multi-tensor Adam for everything that has no packed copy (biases, BatchNorm affine
+// parameters, the small linears, conv1): one launch, 4096 elements per block.
+constexpr int AD_MAX_ITEMS = 48, AD_CHUNK = 4096;
+struct AdamBatchArgs {
+  AdamScalars adam;
+  float* p[AD_MAX_ITEMS];
+  const float* g[AD_MAX_ITEMS];
+  float* m[AD_MAX_ITEMS];
+  float* v[AD_MAX_ITEMS];
+  long long numel[AD_MAX_ITEMS];
+  int first_block[AD_MAX_ITEMS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamBatchArgs a) {
+  int it = 0;
+  while (it + 1 < a.n && (int)blockIdx.x >= a.first_block[it + 1]) ++it;
+  const long long base = (long long)(blockIdx.x - a.first_block[it]) * AD_CHUNK;
+  const long long n = a.numel[it];
+  float* __restrict__ p = a.p[it];
+  const float* __restrict__ g = a.g[it];
+  float* __restrict__ m = a.m[it];
+  float* __restrict__ v = a.v[it];
+#pragma unroll 4
+  for (int k = 0; k < AD_CHUNK / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      float mv = m[i], vv = v[i];
+      p[i] = adam_update(p[i], g[i], mv, vv, a.adam);
+      m[i] = mv;
+      v[i] = vv;
+    }
   }
 }
 
@@ -246,11 +316,67 @@ extern "C" int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, 
   return QT_OK;
 }
 
+static int make_adam_scalars(const qt_adam_desc* d, AdamScalars* h) {
+  QT_CHECK_ARG(d && d->step >= 1 && d->lr >= 0.f && d->beta1 >= 0.f && d->beta1 < 1.f && d->beta2 >= 0.f && d->beta2 < 1.f &&
+                   d->eps >= 0.f && d->weight_decay >= 0.f,
+               "qt_adam: bad hyper-parameters (step counts from 1)");
+  h->lr = d->lr; h->b1 = d->beta1; h->b2 = d->beta2; h->eps = d->eps; h->wd = d->weight_decay;
+  const double bc1 = 1.0 - pow((double)d->beta1, (double)d->step), bc2 = 1.0 - pow((double)d->beta2, (double)d->step);
+  h->step_size = (float)((double)d->lr / bc1);
+  h->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  h->grad_scale = d->grad_scale == 0.f ? 1.f : d->grad_scale;
+  h->enabled = 1;
+  return QT_OK;
+}
+
+static int pack_batched(int dtype, const qt_pack_item* items, const qt_adam_item* opt, const qt_adam_desc* adam, int n,
+                        void* stream);
+
 extern "C" int qt_pack_weights_batched(int dtype, const qt_pack_item* items, int n, void* stream) {
+  return pack_batched(dtype, items, nullptr, nullptr, n, stream);
+}
+
+extern "C" int qt_adam_pack_weights_batched(int dtype, const qt_pack_item* items, const qt_adam_item* opt,
+                                            const qt_adam_desc* adam, int n, void* stream) {
+  QT_CHECK_ARG(opt && adam, "qt_adam_pack_weights_batched: null optimizer state");
+  return pack_batched(dtype, items, opt, adam, n, stream);
+}
+
+extern "C" int qt_adam_multi(const qt_adam_item* items, int n, const qt_adam_desc* adam, void* stream) {
+  QT_CHECK_ARG(items && n > 0, "qt_adam_multi: no tensors");
+  AdamScalars h;
+  if (int st = make_adam_scalars(adam, &h)) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int j0 = 0; j0 < n; j0 += AD_MAX_ITEMS) {
+    AdamBatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.adam = h;
+    const int cnt = n - j0 < AD_MAX_ITEMS ? n - j0 : AD_MAX_ITEMS;
+    int blocks = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const qt_adam_item& q = items[j0 + j];
+      QT_CHECK_ARG(q.param && q.grad && q.exp_avg && q.exp_avg_sq && q.numel > 0, "qt_adam_multi: item %d incomplete", j0 + j);
+      a.p[j] = q.param; a.g[j] = q.grad; a.m[j] = q.exp_avg; a.v[j] = q.exp_avg_sq; a.numel[j] = q.numel;
+      a.first_block[j] = blocks;
+      blocks += (int)((q.numel + AD_CHUNK - 1) / AD_CHUNK);
+    }
+    a.first_block[cnt] = blocks;
+    a.n = cnt;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
+    QT_CHECK_LAUNCH();
+  }
+  return QT_OK;
+}
+
+static int pack_batched(int dtype, const qt_pack_item* items, const qt_adam_item* opt, const qt_adam_desc* adam, int n,
+                        void* stream) {
   QT_CHECK_ARG(items && n > 0 && n <= PK_MAX_ITEMS, "qt_pack_weights_batched: 1..%d items", PK_MAX_ITEMS);
   QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pack_weights_batched: bad dtype %d", dtype);
   PackBatchArgs a;
   memset(&a, 0, sizeof(a));
+  if (opt) {
+    if (int st = make_adam_scalars(adam, &a.adam)) return st;
+  }
   int blocks = 0;
   for (int j = 0; j < n; ++j) {
     const qt_pack_item& q = items[j];
@@ -260,6 +386,13 @@ extern "C" int qt_pack_weights_batched(int dtype, const qt_pack_item* items, int
                  "qt_pack_weights_batched: item %d: O=%d I=%d must be multiples of %d for k=%d (k in {1,3})", j, q.O, q.I,
                  te, q.k);
     a.w[j] = q.w_oihw; a.fwd[j] = q.w_fwd; a.dgrad[j] = q.w_dgrad;
+    if (opt) {
+      const qt_adam_item& u = opt[j];
+      QT_CHECK_ARG(u.param == q.w_oihw && u.grad && u.exp_avg && u.exp_avg_sq &&
+                       u.numel == (long long)q.O * q.I * q.k * q.k,
+                   "qt_adam_pack_weights_batched: item %d: optimizer state does not match the weight", j);
+      a.g[j] = u.grad; a.m[j] = u.exp_avg; a.v[j] = u.exp_avg_sq;
+    }
     a.O[j] = q.O; a.I[j] = q.I; a.k[j] = (unsigned char)q.k; a.s2[j] = q.stride2_dgrad ? 1 : 0;
     a.first_block[j] = blocks;
     blocks += (q.O / te) * (q.I / te);

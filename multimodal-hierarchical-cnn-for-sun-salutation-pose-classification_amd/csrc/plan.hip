@@ -555,6 +555,63 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
   return e.status;
 }
 
+// Optimizer step + operand re-packing in one pass over the parameters: the conv /
+// linear weights that have packed copies are updated INSIDE the packing kernel, everything else by the
+// plain multi-tensor kernel; tensors without a gradient are only re-packed.
+int adam_step(qt_plan* p, void* workspace, void* const* T, float* const* G, float* const* M1, float* const* M2,
+              const qt_adam_desc* adam, int for_backward, void* stream) {
+  Exec e{p, static_cast<unsigned char*>(workspace), T, stream, p->d.batch, p->d.dtype};
+  std::vector<bool> fused(p->tensors.size(), false);
+  std::vector<qt_pack_item> upd_items, pack_items;
+  std::vector<qt_adam_item> upd_state, plain;
+  auto numel_of = [&](int idx) {
+    long long n = 1;
+    for (int d = 0; d < p->tensors[idx].ndim; ++d) n *= p->tensors[idx].shape[d];
+    return n;
+  };
+  auto add = [&](int widx, void* fwd, void* dgrad, int O, int I, int k, bool s2) -> int {
+    qt_pack_item q;
+    q.w_oihw = e.tf(widx); q.w_fwd = fwd; q.w_dgrad = dgrad; q.O = O; q.I = I; q.k = k; q.stride2_dgrad = s2;
+    if (G[widx]) {
+      QT_CHECK_ARG(M1[widx] && M2[widx], "qt_plan_adam_step: %s has a gradient but no optimizer state",
+                   p->tensors[widx].name.c_str());
+      qt_adam_item u;
+      u.param = e.tf(widx); u.grad = G[widx]; u.exp_avg = M1[widx]; u.exp_avg_sq = M2[widx]; u.numel = numel_of(widx);
+      upd_items.push_back(q);
+      upd_state.push_back(u);
+    } else {
+      pack_items.push_back(q);
+    }
+    fused[widx] = true;
+    return (int)QT_OK;
+  };
+  if (p->has_image)
+    for (size_t i = 1; i < p->convs.size(); ++i) {
+      const ConvL& c = p->convs[i];
+      if (int st = add(c.w, e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2)) return st;
+    }
+  if (int st = add(p->cls0.w, e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1, false))
+    return st;
+  for (size_t i = 0; i < p->tensors.size(); ++i) {
+    if (p->tensors[i].kind != 0 || fused[i] || !G[i]) continue;
+    QT_CHECK_ARG(T[i] && M1[i] && M2[i], "qt_plan_adam_step: %s has a gradient but no parameter / optimizer state",
+                 p->tensors[i].name.c_str());
+    qt_adam_item u;
+    u.param = e.tf((int)i); u.grad = G[i]; u.exp_avg = M1[i]; u.exp_avg_sq = M2[i]; u.numel = numel_of((int)i);
+    plain.push_back(u);
+  }
+  if (!plain.empty()) e.run(qt_adam_multi(plain.data(), (int)plain.size(), adam, stream));
+  if (p->has_image)  // conv1's filter was updated by the plain kernel above
+    e.run(qt_pack_stem_weight(e.dt, e.tf(p->convs[0].w), e.at(p->convs[0].w_fwd), e.stem_taps(), stream));
+  for (size_t j = 0; j < upd_items.size() && e.ok(); j += 32) {
+    const int cnt = (int)std::min<size_t>(32, upd_items.size() - j);
+    e.run(qt_adam_pack_weights_batched(e.dt, upd_items.data() + j, upd_state.data() + j, adam, cnt, stream));
+  }
+  for (size_t j = 0; j < pack_items.size() && e.ok(); j += 32)
+    e.run(qt_pack_weights_batched(e.dt, pack_items.data() + j, (int)std::min<size_t>(32, pack_items.size() - j), stream));
+  return e.status;
+}
+
 int forward(qt_plan* p, void* workspace, void* const* T, const float* image, const float* numerical, float* logits,
             int batch, int training, unsigned long long seed, void* stream) {
   Exec e{p, static_cast<unsigned char*>(workspace), T, stream, batch, p->d.dtype};
@@ -1146,6 +1203,13 @@ extern "C" int qt_plan_init_workspace(qt_plan* p, void* workspace, void* stream)
 extern "C" int qt_plan_pack_weights(qt_plan* p, void* workspace, void* const* tensors, int for_backward, void* stream) {
   QT_CHECK_ARG(p && workspace && tensors, "qt_plan_pack_weights: null argument");
   return pack_weights(p, workspace, tensors, for_backward, stream);
+}
+
+extern "C" int qt_plan_adam_step(qt_plan* p, void* workspace, void* const* tensors, float* const* grads,
+                                 float* const* exp_avg, float* const* exp_avg_sq, const qt_adam_desc* adam, int for_backward,
+                                 void* stream) {
+  QT_CHECK_ARG(p && workspace && tensors && grads && exp_avg && exp_avg_sq && adam, "qt_plan_adam_step: null argument");
+  return adam_step(p, workspace, tensors, grads, exp_avg, exp_avg_sq, adam, for_backward, stream);
 }
 
 extern "C" int qt_plan_forward(qt_plan* p, void* workspace, void* const* tensors, const float* image,

@@ -37,6 +37,16 @@ def default_compute_dtype():
     raise QtError(f"QTCNN_DTYPE={name!r}: expected bf16 or f32")
 
 
+class AdamDesc(ctypes.Structure):   # qt_adam_desc
+    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("weight_decay", ctypes.c_float), ("grad_scale", ctypes.c_float), ("step", ctypes.c_int)]
+
+
+class AdamItem(ctypes.Structure):   # qt_adam_item
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("numel", ctypes.c_longlong)]
+
+
 def _bind_api(L):
     if getattr(L, "_plan_bound", False):
         return
@@ -57,6 +67,8 @@ def _bind_api(L):
     L.qt_plan_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.qt_plan_side_fence.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.qt_plan_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.POINTER(AdamDesc), ctypes.c_int, ctypes.c_void_p]
     L.qt_plan_find_buffer.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
     L._plan_bound = True
 
@@ -149,6 +161,23 @@ class PlanEngine:
             if self._tensor_ptrs[i] != ptr:
                 self._weights_stale = True      # a parameter was replaced (load / .to() / new storage)
             self._tensor_ptrs[i] = ptr
+
+    def adam_step(self, by_index, desc):
+        """Fused optimizer step + operand re-packing (qt_plan_adam_step).  by_index: plan tensor
+        index -> (grad, exp_avg, exp_avg_sq) f32 tensors on this device; the parameters themselves
+        are the tensors bound by the last forward."""
+        n = len(self.names)
+        g, m, v = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        for idx, (gt, mt, vt) in by_index.items():
+            for t in (gt, mt, vt):
+                if t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous():
+                    raise QtError(f"{self.names[idx]}: gradient / Adam state must be contiguous f32 on {self.device}")
+            g[idx], m[idx], v[idx] = gt.data_ptr(), mt.data_ptr(), vt.data_ptr()
+        _lib.check(self.L.qt_plan_adam_step(self.handle, self.ws_ptr, self._tensor_ptrs, g, m, v, ctypes.byref(desc), 1,
+                                            _lib.stream_ptr()), "qt_plan_adam_step")
+        self._weights_stale = False   # the step re-packed every operand copy from the updated masters
+        if self._packed_version is not None:
+            self._packed_version = (self._packed_version[0], True)
 
     def invalidate_weights(self):
         """The f32 master weights changed behind the model's back: re-pack them at the next forward."""

@@ -13,6 +13,7 @@ if os.path.dirname(_PKG_DIR) not in sys.path:
     sys.path.insert(0, os.path.dirname(_PKG_DIR))
 _impl = importlib.import_module(_PKG + ".quadtree")
 QtError = importlib.import_module(_PKG + "._lib").QtError
+FusedAdam = importlib.import_module(_PKG + ".optim").FusedAdam  # optional replacement of optim.Adam(...)
 
 StandardResNetCNN = _impl.StandardResNetCNN
 
