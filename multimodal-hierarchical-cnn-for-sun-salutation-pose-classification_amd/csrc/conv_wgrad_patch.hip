@@ -379,7 +379,7 @@ bool qt_wgrad_patch_eligible(const qt_conv_desc* d) {
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->quad) return false;
   if (d->in_h != d->out_h || d->in_w != d->out_w) return false;
   if (d->n_out % 64 || d->k_per_tap % 64) return false;
-  if (d->out_w < mw || d->out_w < 14 || d->out_h < 14 || d->out_w > 120) return false;
+  if (d->out_w < mw || d->out_w < 7 || d->out_h < 7 || d->out_w > 120) return false;
   if ((long long)d->batch * (d->out_h + 2) * (d->out_w + 2) >= (1ll << 30)) return false;
   return true;
 }

@@ -80,8 +80,11 @@ if __name__ == "__main__":
             bench("wgrad", B, 28, 128, 128, 3, 1, 1)
             bench("wgrad", B, 14, 256, 256, 3, 1, 1)
     if which == "wgrad1":   # streaming kernel only (QTCNN_WP_* env experiments)
-        L.lib().qt_set_wgrad_patch_min_width(14)
+        L.lib().qt_set_wgrad_patch_min_width(0)
+        bench("wgrad", B, 7, 512, 512, 3, 1, 1)
+        L.lib().qt_set_wgrad_patch_min_width(7)
         for w in (False, True):
+            bench("wgrad", B, 7, 512, 512, 3, 1, 1, workspace=w)
             bench("wgrad", B, 56, 64, 64, 3, 1, 1, workspace=w)
             bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=w)
             bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=w)

@@ -256,6 +256,7 @@ def test_conv_wgrad(dt, cfg):
     (9, 64, 128, 28),     # ragged batch, rectangular channel tiles
     (2, 256, 256, 14),    # layer3: 16 tiles, 30 % padding overhead
     (300, 64, 64, 14),    # more ranges than workgroups' worth of images: ranges cut through images
+    (6, 512, 512, 7),     # layer4: 9x9 padded positions, a 32-position step spans three padded rows
 ])
 def test_conv_wgrad_streaming_kernel(cfg):
     """3x3 / stride 1 weight gradient with all nine taps accumulated by one workgroup
@@ -270,7 +271,7 @@ def test_conv_wgrad_streaming_kernel(cfg):
     ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, 1, 1)
     xd, dyd = nhwc(x).to(dev, dt), nhwc(dy).to(dev, dt)
     try:
-        L.lib().qt_set_wgrad_patch_min_width(14)
+        L.lib().qt_set_wgrad_patch_min_width(7)
         dw = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1)
         dw_ws = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1, workspace=True)
         dw_ws2 = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1, workspace=True)
