@@ -368,3 +368,44 @@ def test_adam_multi_kernel_matches_torch_single_tensor_adam():
         assert rel_err(p.cpu(), r.detach()) <= 2e-6
         assert rel_err(m.cpu(), opt.state[r]["exp_avg"]) <= 2e-6
         assert rel_err(v.cpu(), opt.state[r]["exp_avg_sq"]) <= 2e-6
+
+
+@pytest.mark.parametrize("mode", ["image_only", "numerical_only"])
+def test_frozen_backbone_modes_train_step_matches_oracle(mode):
+    """resnet/ variant with TRAINING_MODE image_only / numerical_only (resnet/models.py:115-129,
+    resnet/train_cnn_model.py:15): frozen backbone, train-mode BatchNorm, dropout 0, f32 build.
+    Loss and every trainable parameter's gradient against the CPU oracle; the branch the mode ignores
+    gets uninitialised input, as the reference's callers pass it."""
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    B = 3
+    m = build("quadtree", torch.float32, dropout=0.0, mode=mode, frozen=True)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    x, f = synth.synth_images(B, salt=70), synth.synth_pose_features(B, salt=70)
+    y = synth.synth_labels(B, 12, salt=70)
+    xin = x.to(dev) if mode != "numerical_only" else torch.empty(B, 3, 224, 224, device=dev)
+    fin = f.to(dev) if mode != "image_only" else torch.empty(B, 47, device=dev)
+    loss = torch.nn.functional.cross_entropy(m(xin, fin), y.to(dev))
+    loss.backward()
+    keys = [k for k in o.trainable_keys(sd0, True)
+            if not (mode == "image_only" and k.startswith("numerical_mlp."))
+            and not (mode == "numerical_only" and k.startswith("quadrant_processor."))]
+    sd = o.unique_params(sd0, keys)
+    ref_loss = torch.nn.functional.cross_entropy(o.quadtree_forward(sd, x, f, mode=mode, train=True, dropout_p=0.0), y)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-3 * max(1.0, abs(ref_loss.item()))
+    got = dict(m.named_parameters())
+    checked = 0
+    for k in keys:
+        if sd[k].grad is None:
+            assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0, k
+            continue
+        assert got[k].grad is not None, k
+        assert rel_err(got[k].grad.cpu(), sd[k].grad) <= 1e-3, k
+        checked += 1
+    assert checked >= 4
+    for k, p in got.items():   # the frozen backbone hands out no gradients
+        if k.startswith("base_cnn.") or k.startswith("features_extractor.") or k.startswith("global_processor."):
+            assert p.grad is None, k
