@@ -122,6 +122,11 @@ int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, flo
 size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* desc);
 int qt_conv2d_wgrad_ws(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The shapes with a workspace (bf16 3x3 stride 1): the gradient is WRITTEN (not accumulated) in the
+ * reference's OIHW layout by the kernel that sums the partial filters -- no [O][kh][kw][I] scratch,
+ * no zero fill, no qt_unpack_conv_wgrad.  QT_ERR_UNSUPPORTED for every other shape. */
+int qt_conv2d_wgrad_oihw(const qt_conv_desc* desc, const void* dy, const void* x, float* grad_oihw, void* workspace,
+                         size_t workspace_bytes, void* stream);
 /* bf16 3x3 / stride 1 / pad 1 weight gradients of images at least `min_width` wide take the
  * streaming kernel (csrc/conv_wgrad_patch.hip: one workgroup accumulates all nine taps of a
  * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default. */

@@ -375,7 +375,7 @@ int launch(WgradArgs a, hipStream_t stream) {
 bool qt_wgrad_patch_eligible(const qt_conv_desc* d);
 size_t qt_wgrad_patch_workspace_bytes(const qt_conv_desc* d);
 int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          size_t workspace_bytes, int oihw, void* stream);
 
 extern "C" size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* d) {
   return d ? qt_wgrad_patch_workspace_bytes(d) : 0;
@@ -383,6 +383,19 @@ extern "C" size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* d) {
 
 extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
   return qt_conv2d_wgrad_ws(d, dy, x, dw, nullptr, 0, stream);
+}
+
+extern "C" int qt_conv2d_wgrad_oihw(const qt_conv_desc* d, const void* dy, const void* x, float* grad_oihw, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  QT_CHECK_ARG(d && dy && x && grad_oihw && workspace, "qt_conv2d_wgrad_oihw: null argument");
+  QT_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)grad_oihw % 4) == 0 &&
+                   ((uintptr_t)workspace % 16) == 0,
+               "qt_conv2d_wgrad_oihw: misaligned pointer");
+  if (d->mode != QT_CONV_FWD || !qt_wgrad_patch_eligible(d)) {
+    qt_set_error("qt_conv2d_wgrad_oihw: only the shapes of the streaming kernel (bf16 3x3 stride 1)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  return qt_wgrad_patch_launch(d, dy, x, grad_oihw, workspace, workspace_bytes, 1, stream);
 }
 
 extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
@@ -408,7 +421,7 @@ extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const v
   a.div_ow = make_fastdiv((unsigned)d->out_w);
   a.tilesN = a.tilesC = a.gtaps = a.ksplit = a.pix_per_split = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (qt_wgrad_patch_eligible(d)) return qt_wgrad_patch_launch(d, dy, x, dw, workspace, workspace_bytes, stream);
+  if (qt_wgrad_patch_eligible(d)) return qt_wgrad_patch_launch(d, dy, x, dw, workspace, workspace_bytes, 0, stream);
   // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
   const bool stem = d->k_per_tap == 32 && d->kw == 1 && d->kh == 7 && d->n_out == 64;
   if (d->dtype == QT_BF16) {

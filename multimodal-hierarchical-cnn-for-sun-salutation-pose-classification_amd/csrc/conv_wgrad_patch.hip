@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256 * G) void conv_wgrad_patch_kernel(WPArgs p) {
 // few (<= 8) dependent loads: the launch overlaps HBM-heavy kernels and must not be a latency chain.
 template <int SG>
 __global__ __launch_bounds__(256) void wgrad_partial_sum_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                int nq, int nsplit, long long stride_q) {
+                                                                int nq, int nsplit, long long stride_q, int KC, int oihw) {
   constexpr int JQ = 256 / SG;
   __shared__ float4 red[SG][JQ];
   const int col = threadIdx.x % JQ, sg = threadIdx.x / JQ;
@@ -296,13 +296,25 @@ __global__ __launch_bounds__(256) void wgrad_partial_sum_kernel(const float* __r
   red[sg][col] = s;
   __syncthreads();
   if (sg == 0 && jq < nq) {
-    float4 o = reinterpret_cast<float4*>(dw)[jq];
+    float4 o = oihw ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dw)[jq];
 #pragma unroll
     for (int g = 0; g < SG; ++g) {
       const float4 v = red[g][col];
       o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
     }
-    reinterpret_cast<float4*>(dw)[jq] = o;
+    if (!oihw) {
+      reinterpret_cast<float4*>(dw)[jq] = o;
+    } else {
+      // j = (n*9 + tap)*KC + c  ->  OIHW element (n*KC + c)*9 + tap: the gradient is WRITTEN in the
+      // reference's layout, no [O][kh][kw][I] scratch, no zero fill, no separate permutation launch
+      const long long j = (long long)jq * 4;
+      const int c = (int)(j % KC);
+      const long long nt = j / KC;
+      const int tap = (int)(nt % 9);
+      const long long n = nt / 9;
+      float* dst = dw + (n * KC + c) * 9 + tap;
+      dst[0] = o.x; dst[9] = o.y; dst[18] = o.z; dst[27] = o.w;
+    }
   }
 }
 
@@ -329,7 +341,7 @@ void split_ranges(int total, int tiles, int mcr, int* pps_out, int* nsplit_out) 
 constexpr int kGroups = 1;  // wave groups of the default variant (split_ranges depends on it)
 
 template <int G, int D, int NX, int ND>
-int launch_patch(WPArgs a, size_t part_bytes, hipStream_t stream) {
+int launch_patch(WPArgs a, size_t part_bytes, int oihw, hipStream_t stream) {
   constexpr int MCR = WP_CH * G;
   constexpr int LDS = (NX + ND) * MCR * 128;
   if (2 * a.halo > a.PP || (2 * a.halo) % MCR != 0 || (2 * a.halo) / MCR + D + 2 > NX || D + 2 > ND) {
@@ -344,6 +356,10 @@ int launch_patch(WPArgs a, size_t part_bytes, hipStream_t stream) {
   if (a.nsplit >= 6 && (a.nsplit & 7)) a.nsplit = qt_cdiv(a.nsplit, 8) * 8;  // empty tail ranges exit at once
   const size_t filt = (size_t)a.N * 9 * a.KC;
   if (a.part && part_bytes < (size_t)real_split * filt * 4) a.part = nullptr;  // too small: atomics
+  if (oihw && !a.part) {
+    qt_set_error("qt_conv2d_wgrad_oihw: workspace of %zu bytes needed", (size_t)real_split * filt * 4);
+    return QT_ERR_INVALID_ARG;
+  }
   auto kern = conv_wgrad_patch_kernel<G, D, NX, ND>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -360,10 +376,10 @@ int launch_patch(WPArgs a, size_t part_bytes, hipStream_t stream) {
     const int nq = (int)(filt / 4);
     if (real_split > 16)
       hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, a.part, a.dw, nq,
-                         real_split, (long long)nq);
+                         real_split, (long long)nq, a.KC, oihw);
     else
       hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, a.part, a.dw, nq,
-                         real_split, (long long)nq);
+                         real_split, (long long)nq, a.KC, oihw);
     QT_CHECK_LAUNCH();
   }
   return QT_OK;
@@ -396,7 +412,7 @@ size_t qt_wgrad_patch_workspace_bytes(const qt_conv_desc* d) {
 }
 
 int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          size_t workspace_bytes, int oihw, void* stream) {
   WPArgs a;
   a.part = static_cast<float*>(workspace);
   a.dy = static_cast<const bf16_t*>(dy);
@@ -423,7 +439,7 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
     const char* e = getenv("QTCNN_WGRAD_WS");
     use_ws = e ? atoi(e) : 1;
   }
-  if (!use_ws) a.part = nullptr;
+  if (!use_ws && !oihw) a.part = nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // Alone, two wave groups win (56x56 64->64, atomics: 99 us vs 122 us): a second wave per SIMD
   // covers LDS reads and address arithmetic.  Inside the training step the launch overlaps the
@@ -431,6 +447,6 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   // for any of their waves: short kernels then queue behind whole workgroups.  One group per
   // workgroup (one wave per SIMD, 96 KB LDS) keeps half of every CU's registers free and measures
   // 1.7 % faster per step (7.43 vs 7.56 ms); 48 KB of LDS with a shallower ring measures slower (7.60).
-  if (variant == 2) return launch_patch<2, 2, 8, 4>(a, workspace_bytes, s);
-  return launch_patch<kGroups, 4, 16, 8>(a, workspace_bytes, s);
+  if (variant == 2) return launch_patch<2, 2, 8, 4>(a, workspace_bytes, oihw, s);
+  return launch_patch<kGroups, 4, 16, 8>(a, workspace_bytes, oihw, s);
 }

@@ -839,6 +839,12 @@ struct Bwd : Exec {
       return;
     }
     const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);  // c.dw was zeroed at the start of this backward
+    if (!stem && qt_conv2d_wgrad_workspace_bytes(&fwd_desc) > 0) {
+      // streaming kernel: the partial-filter sum writes .grad in OIHW directly
+      run(qt_conv2d_wgrad_oihw(&fwd_desc, at(c.gy), src, gf(c.w), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
+      end_timed(slot, ws_);
+      return;
+    }
     run(qt_conv2d_wgrad_ws(&fwd_desc, at(c.gy), src, at<float>(c.dw), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
     end_timed(slot, ws_);
     if (stem)

@@ -279,6 +279,26 @@ def test_conv_wgrad_streaming_kernel(cfg):
         dw_generic = run_wgrad(L, dt, dyd, xd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1)
     finally:
         L.lib().qt_set_wgrad_patch_min_width(-1)
+    # .grad written directly in OIHW by the partial-filter sum (NaN-filled destination: fully overwritten)
+    lib = L.lib()
+    d = L.ConvDesc()
+    d.dtype, d.mode, d.batch = L.qt_dtype(dt), L.QT_CONV_FWD, B
+    d.in_h = d.in_w = d.out_h = d.out_w = H
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = Cin, Cout, 3, 3, 1, 1
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = H * H * Cin, H * Cin, Cin
+    lib.qt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    g_oihw = torch.full((Cout, Cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+    try:
+        lib.qt_set_wgrad_patch_min_width(7)
+        nbytes = lib.qt_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+        wsb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.qt_conv2d_wgrad_oihw(ctypes.byref(d), L.ptr(dyd), L.ptr(xd), L.ptr(g_oihw), L.ptr(wsb),
+                                         ctypes.c_size_t(nbytes), L.stream_ptr()), "qt_conv2d_wgrad_oihw")
+    finally:
+        lib.qt_set_wgrad_patch_min_width(-1)
+    torch.cuda.synchronize()
+    assert rel_err(g_oihw.cpu(), ref) <= 3e-5
+    assert torch.equal(g_oihw, dw_ws.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2))
     for name, t in (("atomic", dw), ("workspace", dw_ws)):
         got = t.cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         assert rel_err(got, ref) <= 3e-5, name
