@@ -88,3 +88,12 @@ if __name__ == "__main__":
             bench("wgrad", B, 56, 64, 64, 3, 1, 1, workspace=w)
             bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=w)
             bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=w)
+    if which == "igemm":   # forward / dgrad of the 3x3 stride-1 layers (QTCNN_IGEMM_VARIANT experiments)
+        for kind in ("fwd", "dgrad"):
+            bench(kind, B, 28, 128, 128, 3, 1, 1)
+            bench(kind, B, 14, 256, 256, 3, 1, 1)
+            bench(kind, B, 7, 512, 512, 3, 1, 1)
+    if which == "l1generic":   # generic 128x64 tile on the layer1 shape (occupancy experiment)
+        L.lib().qt_set_patch_conv(0)
+        bench("fwd", B, 56, 64, 64, 3, 1, 1)
+        bench("dgrad", B, 56, 64, 64, 3, 1, 1)
