@@ -450,7 +450,9 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 //   256x128 tile, four 128x64 wave tiles, 3 stages (fewest LDS reads per MFMA, one workgroup per CU): 130 / 105 / 94 us;
 //   128x128 with 3 or 4 stages (one workgroup per CU, deeper prefetch): 142 / 133 / 117 us, no better with 4 than with 3;
 //   128x64 tiles for N >= 128 (three workgroups per CU, 64x32 wave tiles): 98 / 102 / 108 us;
-//   64-byte K-steps (half-deep; 3 stages + half-tile epilogue = 48 KB, three workgroups per CU): 102 / 110 / 95 us.
+//   64-byte K-steps (half-deep; 3 stages + half-tile epilogue = 48 KB, three workgroups per CU): 102 / 110 / 95 us;
+//   64-byte K-steps, 4 stages, fragments of step ks+1 read into a second register set under the MFMAs of step ks
+//   (two workgroups per CU, 216-228 VGPRs): 120 / 114 / 104 us.
 // Workgroups per CU on the 128x64 kernel (LDS padded): 1 / 2 / 3 -> 242 / 149 / 121 us.  A second wave per SIMD is worth
 // 1.6x, a third 1.2x; neither deeper DMA prefetch nor fewer LDS reads per MFMA pays while a wave's own LDS-read -> MFMA ->
 // barrier chain is exposed, and halving the K-step costs more in barriers than the third workgroup returns.
