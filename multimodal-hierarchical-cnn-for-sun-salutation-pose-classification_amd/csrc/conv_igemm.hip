@@ -16,6 +16,8 @@
 // each lane ends up with 4 consecutive channels of one pixel: the epilogue
 // stages the f32 tile through LDS and writes whole NHWC rows (16 B per lane),
 // fusing scale/shift (+residual) (+ReLU) (+ReLU-mask) and BatchNorm partial sums.
+#include <stdlib.h>
+
 #include "qt_common.h"
 
 namespace {
@@ -53,8 +55,12 @@ struct ConvArgs {
 
 constexpr int kRowBytes = 128;  // bytes of K per row per K-step
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
+// NSTAGE == 1: single-buffered tiles (every fragment of a K-step is read into registers, a second
+// barrier, then the next K-step's DMA is issued under the MFMAs) + EH == 2: the f32 epilogue staging
+// holds half of the rows at a time -> 32 KB of LDS, three workgroups per CU.
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD, int EH = 1>
+__global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_kernel(ConvArgs p) {
+  static_assert(EH == 1 || (EH == 2 && WM == 2), "the split epilogue takes one wave row per pass");
   constexpr int NT = 64 * WM * WN;   // threads
   constexpr int RG = NT / 8;         // rows staged per pass of the whole workgroup
   constexpr int BK = kRowBytes / (int)sizeof(T);
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
   const T* a_ptr[RA];
   unsigned a_mask[RA];
   const int OHW = p.OH * p.OW;
-  const bool slow = DGRAD && p.stride == 2;
+  const bool slow = DGRAD && NSTAGE != 1 && p.stride == 2;  // (the single-buffered shape is never dispatched for it)
   auto axis_ok = [&](int o, int k, int extent) -> bool {
     if (!DGRAD) return (unsigned)(o * p.stride - p.pad + k) < (unsigned)extent;
     const int t = o + p.pad - k;
@@ -248,36 +254,67 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
   // is visible and nobody still reads the buffer about to be refilled), issue stage
   // ks+NSTAGE-1, then the MFMAs of stage ks.
   constexpr int DPS = RA + RW;  // DMA instructions per wave per stage
+  if constexpr (NSTAGE == 1) {
+    if (nk > 0) dma_stage(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // this K-step's tiles have landed
+      const unsigned char* sa = smem;
+      const unsigned char* sw = sa + BM * kRowBytes;
+      uint4 fw[2][TN], fa[2][TM];
 #pragma unroll
-  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nk) dma_stage(s0, s0);
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks % NSTAGE;
-    if (NSTAGE >= 3 && ks + NSTAGE - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int r = wn * (BN / WN) + i * 16 + frow;
+          fw[kk][i] = *reinterpret_cast<const uint4*>(sw + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int r = wm * (BM / WM) + j * 16 + frow;
+          fa[kk][j] = *reinterpret_cast<const uint4*>(sa + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave holds its fragments: the tiles are free
+      if (ks + 1 < nk) dma_stage(ks + 1, 0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[kk][i], fa[kk][j]);
     }
-    if (ks + NSTAGE - 1 < nk) dma_stage(ks + NSTAGE - 1, (ks + NSTAGE - 1) % NSTAGE);
-    const unsigned char* sa = smem + buf * STAGE_BYTES;
-    const unsigned char* sw = sa + BM * kRowBytes;
+  } else {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      uint4 fw[TN], fa[TM];
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int r = wn * (BN / WN) + i * 16 + frow;
-        fw[i] = *reinterpret_cast<const uint4*>(sw + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+      if (s0 < nk) dma_stage(s0, s0);
+    for (int ks = 0; ks < nk; ++ks) {
+      const int buf = ks % NSTAGE;
+      if (NSTAGE >= 3 && ks + NSTAGE - 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int r = wm * (BM / WM) + j * 16 + frow;
-        fa[j] = *reinterpret_cast<const uint4*>(sa + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+      if (ks + NSTAGE - 1 < nk) dma_stage(ks + NSTAGE - 1, (ks + NSTAGE - 1) % NSTAGE);
+      const unsigned char* sa = smem + buf * STAGE_BYTES;
+      const unsigned char* sw = sa + BM * kRowBytes;
+  #pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 fw[TN], fa[TM];
+  #pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int r = wn * (BN / WN) + i * 16 + frow;
+          fw[i] = *reinterpret_cast<const uint4*>(sw + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+        }
+  #pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int r = wm * (BM / WM) + j * 16 + frow;
+          fa[j] = *reinterpret_cast<const uint4*>(sa + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
+        }
+  #pragma unroll
+        for (int i = 0; i < TN; ++i)
+  #pragma unroll
+          for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[i], fa[j]);
       }
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[i], fa[j]);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all reads done before the epilogue reuses LDS
@@ -285,14 +322,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
   // ---- epilogue: accumulators -> LDS f32 [BM][BN] (chunk-swizzled) -------------
   // lane holds channels n = 4*(lane>>4)+r of pixel (lane&15) for each 16x16 tile.
   constexpr int ROWB = BN * 4;  // bytes per staged pixel row
+  constexpr int EROWS = BM / EH;  // rows staged at a time
+  auto stage_acc = [&](int h) {
+    if (EH == 2 && wm != h) return;
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int pm = wm * (BM / WM) + j * 16 + frow;
-      const int c16 = (wn * (BN / WN) + i * 16 + fk * 4) >> 2;  // 16-byte chunk index
-      *reinterpret_cast<f32x4*>(smem + pm * ROWB + ((c16 ^ (pm & 7)) << 4)) = acc[i][j];
-    }
+      for (int j = 0; j < TM; ++j) {
+        const int pm = (EH == 2 ? 0 : wm * (BM / WM)) + j * 16 + frow;
+        const int c16 = (wn * (BN / WN) + i * 16 + fk * 4) >> 2;  // 16-byte chunk index
+        *reinterpret_cast<f32x4*>(smem + pm * ROWB + ((c16 ^ (pm & 7)) << 4)) = acc[i][j];
+      }
+  };
+  stage_acc(0);
   __syncthreads();
 
   constexpr int TPR = BN / 8;          // threads per pixel row (8 channels each)
@@ -326,8 +368,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
   for (int ps = 0; ps < NPASS; ++ps) {
     const int r = r0 + ps * RPP;
     const int m = m0 + r;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg) ^ (r & 7)) << 4));
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg + 1) ^ (r & 7)) << 4));
+    if (EH == 2 && ps == NPASS / 2) {  // second half of the rows replaces the first in the staging
+      __syncthreads();
+      stage_acc(1);
+      __syncthreads();
+    }
+    const int rl = r % EROWS;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + rl * ROWB + (((2 * cg) ^ (rl & 7)) << 4));
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + rl * ROWB + (((2 * cg + 1) ^ (rl & 7)) << 4));
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if (m < p.M && n_ok) {
       long long drow = m;
@@ -413,13 +461,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD, int EH = 1>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * kRowBytes;
-  constexpr int EPI = BM * BN * 4;
-  constexpr int LDS = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
+  constexpr int EPI = BM * BN * 4 / EH;
+  constexpr int RED = (64 * WM * WN / (BN / 8)) * BN * 3 * 4;  // statistics reduction scratch
+  constexpr int LDS0 = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
+  constexpr int LDS = LDS0 > RED ? LDS0 : RED;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, DGRAD>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, DGRAD, EH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -456,6 +506,20 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 // Workgroups per CU on the 128x64 kernel (LDS padded): 1 / 2 / 3 -> 242 / 149 / 121 us.  A second wave per SIMD is worth
 // 1.6x, a third 1.2x; neither deeper DMA prefetch nor fewer LDS reads per MFMA pays while a wave's own LDS-read -> MFMA ->
 // barrier chain is exposed, and halving the K-step costs more in barriers than the third workgroup returns.
+// Single-buffered tiles + half-tile epilogue (32 KB of LDS, three workgroups per CU): every fragment of
+// a K-step is read into registers, a second barrier frees the tiles, and the next K-step's DMA runs
+// under the MFMAs.  Measured alone (B=256, bf16): layer2's 3x3 convs 93 -> 81 us forward, 93 -> 82 us data
+// gradient; layer3 / layer4 (784 / 392 workgroups: no better fit on 768 slots than on 512) unchanged; short
+// K loops (1x1 downsamples, classifier) slower.  Used only where it wins: 9 taps, N == 128, >= 100 k pixels
+// (train step -0.5 %, eval forward -1.0 %).  QTCNN_IGEMM_SINGLE_BUFFER=0 turns it off.
+inline bool igemm_single_buffer() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("QTCNN_IGEMM_SINGLE_BUFFER");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
 inline int tile_m(long long M, int N, int ksteps) { return (M >= 256 * 256 && ksteps >= 36 && N > 64) ? 256 : 128; }
 
 template <typename T, bool DGRAD>
@@ -463,6 +527,8 @@ int dispatch2(const ConvArgs& a, hipStream_t stream) {
   const int bm = tile_m(a.M, a.N, a.ntaps * a.KC * (int)sizeof(T) / kRowBytes);
   if (a.N <= 64) return launch<T, 128, 64, 2, 2, 2, DGRAD>(a, stream);
   if (bm == 256) return launch<T, 256, 128, 4, 2, 3, DGRAD>(a, stream);
+  if (sizeof(T) == 2 && igemm_single_buffer() && !(DGRAD && a.stride == 2) && a.ntaps == 9 && a.N == 128 && a.M >= 100000)
+    return launch<T, 128, 128, 2, 2, 1, DGRAD, 2>(a, stream);
   return launch<T, 128, 128, 2, 2, 2, DGRAD>(a, stream);
 }
 

@@ -69,6 +69,7 @@ def run_conv(L, dt, x_nhwc, w_krsc, B, in_hw, out_hw, k_per_tap, n_out, kh, kw, 
     (2, 64, 128, 56, 1, 2, 0),
     (1, 256, 512, 14, 3, 2, 1),
     (1, 512, 512, 7, 3, 1, 1),   # M = 49: ragged tile
+    (130, 128, 128, 28, 3, 1, 1),  # >= 100 k pixels, N = 128: single-buffered tiles, half-tile epilogue, ragged last tile
 ])
 def test_conv_fwd_epilogue(dt, cfg):
     dev = _dev()
@@ -109,6 +110,7 @@ def test_conv_fwd_epilogue(dt, cfg):
     (2, 64, 128, 56, 3, 2, 1),
     (2, 64, 128, 56, 1, 2, 0),
     (1, 256, 512, 14, 3, 2, 1),
+    (129, 128, 128, 28, 3, 1, 1),  # >= 100 k pixels, 128 channels: single-buffered tiles (bf16)
 ])
 def test_conv_dgrad(dt, cfg):
     dev = _dev()
