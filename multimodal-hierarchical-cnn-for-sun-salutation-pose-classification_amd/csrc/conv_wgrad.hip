@@ -339,7 +339,11 @@ int launch(WgradArgs a, hipStream_t stream) {
   const int gtaps = STEM ? 1 : a.ntaps;
   const int base_blocks = a.tilesN * a.tilesC * gtaps;
   // every workgroup ends with tile-sized f32 atomics (chip-wide ~1.3 TB/s): keep the grid at
-  // about two workgroups per CU instead of maximising the split
+  // about two workgroups per CU instead of maximising the split.
+  // Occupancy was measured both ways for the 128x128 shape: single-buffered tiles (32 KB, three
+  // workgroups per CU) run layer4's 3x3 weight gradient in 125 instead of 135 us alone but cost 3 % of the
+  // training step (7.15 vs 6.94 ms) because they crowd the main stream's kernels off the CUs; padding LDS
+  // to ONE workgroup per CU also costs 2.4 %.  Two per CU is the balance point of the two streams.
   int ksplit = qt_cdiv(512, base_blocks);
   const int max_split = qt_cdiv(a.M, KP * 4);
   if (ksplit > max_split) ksplit = max_split;

@@ -97,3 +97,8 @@ if __name__ == "__main__":
         L.lib().qt_set_patch_conv(0)
         bench("fwd", B, 56, 64, 64, 3, 1, 1)
         bench("dgrad", B, 56, 64, 64, 3, 1, 1)
+    if which == "wgrad4":   # generic weight-gradient kernel on the layer4 / stride-2 shapes (QTCNN_WGRAD_SB experiments)
+        bench("wgrad", B, 7, 512, 512, 3, 1, 1)
+        bench("wgrad", B, 14, 256, 512, 3, 2, 1)
+        bench("wgrad", B, 28, 128, 256, 3, 2, 1)
+        bench("wgrad", B, 14, 256, 128, 3, 1, 1)
