@@ -224,6 +224,19 @@ def main():
                         "mfma_ms_per_step": round(sum(ms) / args.profile_steps, 3),
                         "steps_profiled": args.profile_steps, "by_kernel": per}
 
+    # whole-step HBM traffic from the committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of the same
+    # command, see scripts/collect_profiles.sh) against this run's step time
+    hbm = None
+    if not args.forward_only and args.batch == 256 and args.dtype == "bf16":
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
+            fams = json.load(open(tf))["families"]
+            per_step = sum(v.get("hbm_bytes_per_launch", 0) * v.get("launches_profiled", 0) for v in fams.values()) / 5.0
+            hbm = {"bytes_per_step": int(per_step), "achieved_tb_s": round(per_step / (elapsed / args.steps) / 1e12, 2),
+                   "peak_tb_s": 8.0, "source": os.path.relpath(tf, ROOT) + " (5 profiled steps)"}
+        except Exception:
+            hbm = None
     if dist is not None:
         dist.barrier()
     if rank != 0:
@@ -249,6 +262,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "model_mfma_util": round(gflop_img * value / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
         "roofline": roofline,
+        "hbm": hbm,
     }
     if world == 1 and not args.no_cpu_baseline:
         try:
