@@ -390,7 +390,8 @@ constexpr int L1_PW = 58, L1_RING = 640, L1_WBYTES = 9 * 64 * kRowBytes, L1_RBYT
 constexpr int L1_RED = L1_WBYTES + L1_RBYTES;           // [8 waves][2 i][4 fk][4 r][3] floats
 constexpr int L1_LDS = L1_RED + 8 * 2 * 4 * 4 * 3 * 4;
 
-template <bool FLIP>
+// OPS: the epilogue has memory operands (residual / ReLU mask / BatchNorm links), prefetched per tile.
+template <bool FLIP, bool OPS>
 __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -471,6 +472,39 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma_ring(256 * k + 384 + i * 64);
     }
+    // The epilogue's operands (residual, ReLU mask, saved BatchNorm inputs: 8 bytes per lane and 16x16 tile
+    // each) are requested NOW, behind the window fetch and in front of the 144 MFMAs of the tile: read in the
+    // epilogue itself they were the exposed latency of a one-workgroup-per-CU kernel (alone: 98 -> 148 us with
+    // a residual, 95 -> 179 us with mask + one BatchNorm link).
+    auto out_row = [&](int j) -> int {  // NHWC row of this lane's position in 16x16 tile j, or -1 (halo / past the end)
+      const long long q = (long long)(t0 + k) * BM + wm * 64 + j * 16 + frow;
+      if (q >= p.Q) return -1;
+      const unsigned uq = (unsigned)q;
+      const unsigned img = fdiv(uq, p.div_pp);
+      const unsigned rem = uq - img * (unsigned)p.PP;
+      const unsigned hp = fdiv(rem, p.div_pw);
+      const unsigned wp = rem - hp * (unsigned)L1_PW;
+      return (hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u) ? (int)((img * 56 + (hp - 1)) * 56 + (wp - 1)) : -1;
+    };
+    int prow[4] = {-1, -1, -1, -1};
+    uint2 pre_res[4][2], pre_msk[4][2], pre_y0[4][2], pre_y1[4][2];
+    if constexpr (OPS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        prow[j] = out_row(j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          pre_res[j][i] = pre_msk[j][i] = pre_y0[j][i] = pre_y1[j][i] = make_uint2(0u, 0u);
+          if (prow[j] >= 0) {
+            const long long off = (long long)prow[j] * 64 + wn * 32 + i * 16 + fk * 4;
+            if (res) pre_res[j][i] = *reinterpret_cast<const uint2*>(res + off);
+            if (msk) pre_msk[j][i] = *reinterpret_cast<const uint2*>(msk + off);
+            if (bwd_stats) pre_y0[j][i] = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.bn_y[0]) + off);
+            if (p.bn_y[1]) pre_y1[j][i] = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.bn_y[1]) + off);
+          }
+        }
+      }
+    }
     f32x4 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -506,17 +540,15 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
     if (base >= L1_RING) base -= L1_RING;
 
     // ---- epilogue straight from the accumulators ----
+    auto bf4 = [](const uint2& u, float (&f)[4]) {
+      f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+      f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long long q = (long long)(t0 + k) * BM + wm * 64 + j * 16 + frow;
-      if (q >= p.Q) continue;
-      const unsigned uq = (unsigned)q;
-      const unsigned img = fdiv(uq, p.div_pp);
-      const unsigned rem = uq - img * (unsigned)p.PP;
-      const unsigned hp = fdiv(rem, p.div_pw);
-      const unsigned wp = rem - hp * (unsigned)L1_PW;
-      if (!(hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u)) continue;
-      const long long row = ((long long)img * 56 + (hp - 1)) * 56 + (wp - 1);
+      if constexpr (!OPS) prow[j] = out_row(j);
+      if (prow[j] < 0) continue;
+      const long long row = prow[j];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const long long off = row * 64 + wn * 32 + i * 16 + fk * 4;
@@ -530,33 +562,37 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[i][r] + sh[i][r];
-        if (res) {
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + off);
+        if (OPS && res) {
+          float rv[4];
+          bf4(pre_res[j][i], rv);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
         if (p.relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        if (msk) {
-          const bf16x4 mv = *reinterpret_cast<const bf16x4*>(msk + off);
+        if (OPS && msk) {
+          float mv[4];
+          bf4(pre_msk[j][i], mv);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (float)mv[r] > 0.f ? v[r] : 0.f;
+          for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
         }
         bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
         *reinterpret_cast<bf16x4*>(dst + off) = o;
-        if (bwd_stats) {
-          const bf16x4 yv = *reinterpret_cast<const bf16x4*>(static_cast<const T*>(p.bn_y[0]) + off);
+        if (OPS && bwd_stats) {
+          float yv[4];
+          bf4(pre_y0[j][i], yv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             s1[i][r] += v[r];
-            s2[i][r] += v[r] * ((float)yv[r] - mu0[i][r]) * is0[i][r];
+            s2[i][r] += v[r] * (yv[r] - mu0[i][r]) * is0[i][r];
           }
           if (p.bn_y[1]) {
-            const bf16x4 y2 = *reinterpret_cast<const bf16x4*>(static_cast<const T*>(p.bn_y[1]) + off);
+            float y2[4];
+            bf4(pre_y1[j][i], y2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s3[i][r] += v[r] * ((float)y2[r] - mu1[i][r]) * is1[i][r];
+            for (int r = 0; r < 4; ++r) s3[i][r] += v[r] * (y2[r] - mu1[i][r]) * is1[i][r];
           }
         }
       }
@@ -614,9 +650,9 @@ inline int l1_ring_grid(long long Q) {
   return ntiles < 256 ? ntiles : 256;
 }
 
-template <bool FLIP>
+template <bool FLIP, bool OPS>
 int launch_l1_ring(PatchArgs a, hipStream_t stream) {
-  auto kern = conv_l1_ring_kernel<FLIP>;
+  auto kern = conv_l1_ring_kernel<FLIP, OPS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -695,7 +731,11 @@ int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   a.div_pw = make_fastdiv((unsigned)a.PW);
   a.gridM = a.gridN = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (l1_ring_shape(d)) return a.flip ? launch_l1_ring<true>(a, s) : launch_l1_ring<false>(a, s);
+  if (l1_ring_shape(d)) {
+    const bool ops = a.residual || a.relu_mask || a.bn_y[0];
+    if (a.flip) return ops ? launch_l1_ring<true, true>(a, s) : launch_l1_ring<true, false>(a, s);
+    return ops ? launch_l1_ring<false, true>(a, s) : launch_l1_ring<false, false>(a, s);
+  }
   // 64-channel tiles: all nine taps of a chunk fit the LDS ring, three taps per barrier.
   // bf16: one 64-channel chunk per 128 bytes; f32: 32 channels per chunk.
   if (d->dtype == QT_BF16)

@@ -102,3 +102,41 @@ if __name__ == "__main__":
         bench("wgrad", B, 14, 256, 512, 3, 2, 1)
         bench("wgrad", B, 28, 128, 256, 3, 2, 1)
         bench("wgrad", B, 14, 256, 128, 3, 1, 1)
+
+
+def bench_ring(label, mode, residual=False, mask=False, link=False):
+    """layer1 shape through qt_conv2d_igemm with the epilogue options the plan uses."""
+    dt = torch.bfloat16
+    H, C = 56, 64
+    d, Ho = desc(dt, mode, B, H, C, C, 3, 1, 1)
+    st = L.stream_ptr()
+    x = torch.randn(B, H, H, C, device=dev).to(dt)
+    w = torch.randn(C, 9, C, device=dev).to(dt)
+    y = torch.empty(B * H * H, C, device=dev, dtype=dt)
+    sc = torch.rand(C, device=dev) + 0.5
+    sh = torch.randn(C, device=dev)
+    res = torch.randn(B * H * H, C, device=dev).to(dt) if residual else None
+    msk = torch.randn(B * H * H, C, device=dev).to(dt) if mask else None
+    io = L.ConvIO(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(sc) if residual else None, L.ptr(sh) if residual else None,
+                  L.ptr(res), L.ptr(msk), None)
+    keep = []
+    if link:
+        by = torch.randn(B * H * H, C, device=dev).to(dt)
+        mu, isd = torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+        rows = L.lib().qt_conv2d_stats_rows(ctypes.byref(d))
+        part = torch.zeros(rows + 64, 2, C, device=dev)
+        io.bn0_y, io.bn0_mean, io.bn0_invstd, io.bn0_partial = by.data_ptr(), mu.data_ptr(), isd.data_ptr(), part.data_ptr()
+        keep += [by, mu, isd, part]
+    d.relu = 1 if residual else 0
+    fn = lambda: L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), st))
+    us = timeit(fn)
+    print(f"ring {label:34s}: {us:8.1f} us", flush=True)
+
+
+if __name__ == "__main__" and which == "ring":
+    bench_ring("fwd plain", L.QT_CONV_FWD)
+    bench_ring("fwd + scale/shift + residual + relu", L.QT_CONV_FWD, residual=True)
+    bench_ring("dgrad plain", L.QT_CONV_DGRAD)
+    bench_ring("dgrad + relu mask", L.QT_CONV_DGRAD, mask=True)
+    bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True)
+    bench_ring("dgrad + residual + mask + bn link", L.QT_CONV_DGRAD, residual=True, mask=True, link=True)
