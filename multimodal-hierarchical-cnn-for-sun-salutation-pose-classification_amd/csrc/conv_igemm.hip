@@ -364,6 +364,108 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  // Passes run in batches of PB rows: the batch's memory operands (residual, ReLU mask, saved BatchNorm
+  // inputs; 16 bytes per thread and row each) are all requested before the first row is finished, so a tile
+  // exposes one memory latency per batch instead of one per row (alone, layer2 data gradient with mask +
+  // BatchNorm link: 112 us against 84 us without operands, 31 us of which is the operands' HBM time).
+  constexpr int PB = sizeof(T) == 2 ? (NSTAGE == 1 ? 1 : 4) : 1;  // (the 168-VGPR single-buffered shape has no room for a batch)
+  static_assert(NPASS % PB == 0 && (EH == 1 || (NPASS / 2) % PB == 0), "pass batches");
+  if constexpr (PB > 1) {
+#pragma unroll
+  for (int pb = 0; pb < NPASS; pb += PB) {
+    if (EH == 2 && pb == NPASS / 2) {  // second half of the rows replaces the first in the staging
+      __syncthreads();
+      stage_acc(1);
+      __syncthreads();
+    }
+    long long offs[PB];
+    bool oks[PB];
+    uint4 raw_res[PB], raw_msk[PB], raw_y0[PB], raw_y1[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+      const int m = m0 + r0 + (pb + u) * RPP;
+      oks[u] = m < p.M && n_ok;
+      long long drow = m;
+      if (p.dst_sub && oks[u]) {
+        const unsigned img = fdiv((unsigned)m, p.div_ohw);
+        const unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
+        const unsigned oh = fdiv(rem, p.div_ow);
+        const unsigned ow = rem - oh * (unsigned)p.OW;
+        drow = ((long long)img * p.dst_h + oh * p.dst_sub + p.dst_oh) * p.dst_w + ow * p.dst_sub + p.dst_ow;
+      }
+      offs[u] = drow * p.N + nbase;
+      if constexpr (PB > 1) {
+        raw_res[u] = raw_msk[u] = raw_y0[u] = raw_y1[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (oks[u]) {
+          if (res) raw_res[u] = *reinterpret_cast<const uint4*>(res + offs[u]);
+          if (msk) raw_msk[u] = *reinterpret_cast<const uint4*>(msk + offs[u]);
+          if (bwd_stats) raw_y0[u] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[0]) + offs[u]);
+          if (p.bn_y[1]) raw_y1[u] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[1]) + offs[u]);
+        }
+      }
+    }
+    auto operand = [&](const T* base, const uint4& raw, long long off, float (&f)[8]) {
+      if constexpr (PB > 1) {
+        f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u);
+        f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u);
+        f[4] = __uint_as_float(raw.z << 16); f[5] = __uint_as_float(raw.z & 0xffff0000u);
+        f[6] = __uint_as_float(raw.w << 16); f[7] = __uint_as_float(raw.w & 0xffff0000u);
+      } else {
+        QtVec8<T>::load(base + off, f);
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+      const int r = r0 + (pb + u) * RPP;
+      const int rl = r % EROWS;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + rl * ROWB + (((2 * cg) ^ (rl & 7)) << 4));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + rl * ROWB + (((2 * cg + 1) ^ (rl & 7)) << 4));
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (!oks[u]) continue;
+      const long long off = offs[u];
+      if (!bwd_stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += v[e];
+          s2[e] += v[e] * v[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+      if (res) {
+        float rv[8];
+        operand(res, raw_res[u], off, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (msk) {
+        float mv[8];
+        operand(msk, raw_msk[u], off, mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+      }
+      QtVec8<T>::store(dst + off, v);
+      if (bwd_stats) {
+        float yv[8];
+        operand(static_cast<const T*>(p.bn_y[0]), raw_y0[u], off, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += v[e];
+          s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
+        }
+        if (p.bn_y[1]) {
+          operand(static_cast<const T*>(p.bn_y[1]), raw_y1[u], off, yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
+        }
+      }
+    }
+  }
+  } else {
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int r = r0 + ps * RPP;
@@ -428,6 +530,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         }
       }
     }
+  }
   }
 
   if (p.stats_partial || bwd_stats) {

@@ -104,10 +104,9 @@ if __name__ == "__main__":
         bench("wgrad", B, 14, 256, 128, 3, 1, 1)
 
 
-def bench_ring(label, mode, residual=False, mask=False, link=False):
-    """layer1 shape through qt_conv2d_igemm with the epilogue options the plan uses."""
+def bench_ring(label, mode, residual=False, mask=False, link=False, H=56, C=64):
+    """3x3 stride-1 C->C conv through qt_conv2d_igemm with the epilogue options the plan uses."""
     dt = torch.bfloat16
-    H, C = 56, 64
     d, Ho = desc(dt, mode, B, H, C, C, 3, 1, 1)
     st = L.stream_ptr()
     x = torch.randn(B, H, H, C, device=dev).to(dt)
@@ -140,3 +139,12 @@ if __name__ == "__main__" and which == "ring":
     bench_ring("dgrad + relu mask", L.QT_CONV_DGRAD, mask=True)
     bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True)
     bench_ring("dgrad + residual + mask + bn link", L.QT_CONV_DGRAD, residual=True, mask=True, link=True)
+
+if __name__ == "__main__" and which == "epi":   # generic implicit GEMM, layer2 / layer3 shapes, with epilogue operands
+    for (H, C) in ((28, 128), (14, 256)):
+        print("H", H, "C", C)
+        bench_ring("fwd plain", L.QT_CONV_FWD, H=H, C=C)
+        bench_ring("fwd + scale/shift + residual + relu", L.QT_CONV_FWD, residual=True, H=H, C=C)
+        bench_ring("dgrad plain", L.QT_CONV_DGRAD, H=H, C=C)
+        bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True, H=H, C=C)
+        bench_ring("dgrad + residual + mask + bn link", L.QT_CONV_DGRAD, residual=True, mask=True, link=True, H=H, C=C)
