@@ -435,7 +435,14 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
   // ---- prologue: filter (LDS row t*64 + n) and the first window ----
 #pragma unroll
   for (int t = 0; t < 9; ++t)
-    glds16(wgt + ((long long)rbase * 9 + t) * 64 + chunk * 8, smem_base + (t * 64 + wave * 8) * kRowBytes);
+  {
+    // LDS filter row rho = wn*32 + i*16 + x holds output channel wn*32 + 8*(x>>2) + 4*i + (x&3): a lane's two
+    // 16x16 tiles (i = 0, 1) then own EIGHT consecutive channels fk*8 .. fk*8+7 of a position, so every epilogue
+    // access is one 16-byte load / store per lane instead of two 8-byte ones.
+    const int x = rbase & 15, ii = (rbase >> 4) & 1;
+    const int chan = (rbase & 32) + 8 * (x >> 2) + 4 * ii + (x & 3);
+    glds16(wgt + ((long long)chan * 9 + t) * 64 + chunk * 8, smem_base + (t * 64 + wave * 8) * kRowBytes);
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) dma_ring(i * 64);
 
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = wn * 32 + i * 16 + fk * 4 + r;
+      const int n = wn * 32 + fk * 8 + i * 4 + r;
       sc[i][r] = p.scale ? p.scale[n] : 1.f;
       sh[i][r] = p.shift ? p.shift[n] : 0.f;
       mu0[i][r] = bwd_stats ? p.bn_mean[0][n] : 0.f;
@@ -487,21 +494,18 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
       return (hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u) ? (int)((img * 56 + (hp - 1)) * 56 + (wp - 1)) : -1;
     };
     int prow[4] = {-1, -1, -1, -1};
-    uint2 pre_res[4][2], pre_msk[4][2], pre_y0[4][2], pre_y1[4][2];
+    uint4 pre_res[4], pre_msk[4], pre_y0[4], pre_y1[4];  // 8 channels wn*32 + fk*8 .. +7 of tile j's position
     if constexpr (OPS) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         prow[j] = out_row(j);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          pre_res[j][i] = pre_msk[j][i] = pre_y0[j][i] = pre_y1[j][i] = make_uint2(0u, 0u);
-          if (prow[j] >= 0) {
-            const long long off = (long long)prow[j] * 64 + wn * 32 + i * 16 + fk * 4;
-            if (res) pre_res[j][i] = *reinterpret_cast<const uint2*>(res + off);
-            if (msk) pre_msk[j][i] = *reinterpret_cast<const uint2*>(msk + off);
-            if (bwd_stats) pre_y0[j][i] = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.bn_y[0]) + off);
-            if (p.bn_y[1]) pre_y1[j][i] = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.bn_y[1]) + off);
-          }
+        pre_res[j] = pre_msk[j] = pre_y0[j] = pre_y1[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (prow[j] >= 0) {
+          const long long off = (long long)prow[j] * 64 + wn * 32 + fk * 8;
+          if (res) pre_res[j] = *reinterpret_cast<const uint4*>(res + off);
+          if (msk) pre_msk[j] = *reinterpret_cast<const uint4*>(msk + off);
+          if (bwd_stats) pre_y0[j] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[0]) + off);
+          if (p.bn_y[1]) pre_y1[j] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[1]) + off);
         }
       }
     }
@@ -540,18 +544,18 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
     if (base >= L1_RING) base -= L1_RING;
 
     // ---- epilogue straight from the accumulators ----
-    auto bf4 = [](const uint2& u, float (&f)[4]) {
-      f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-      f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    auto bf4 = [](unsigned lo, unsigned hi, float (&f)[4]) {
+      f[0] = __uint_as_float(lo << 16); f[1] = __uint_as_float(lo & 0xffff0000u);
+      f[2] = __uint_as_float(hi << 16); f[3] = __uint_as_float(hi & 0xffff0000u);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (!OPS) prow[j] = out_row(j);
       if (prow[j] < 0) continue;
-      const long long row = prow[j];
+      const long long off = (long long)prow[j] * 64 + wn * 32 + fk * 8;
+      bf16x8 o;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const long long off = row * 64 + wn * 32 + i * 16 + fk * 4;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         if (!bwd_stats) {
 #pragma unroll
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
         for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[i][r] + sh[i][r];
         if (OPS && res) {
           float rv[4];
-          bf4(pre_res[j][i], rv);
+          bf4(i ? pre_res[j].z : pre_res[j].x, i ? pre_res[j].w : pre_res[j].y, rv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
@@ -574,15 +578,15 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
         }
         if (OPS && msk) {
           float mv[4];
-          bf4(pre_msk[j][i], mv);
+          bf4(i ? pre_msk[j].z : pre_msk[j].x, i ? pre_msk[j].w : pre_msk[j].y, mv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
         }
-        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<bf16x4*>(dst + off) = o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[i * 4 + r] = (bf16_t)v[r];
         if (OPS && bwd_stats) {
           float yv[4];
-          bf4(pre_y0[j][i], yv);
+          bf4(i ? pre_y0[j].z : pre_y0[j].x, i ? pre_y0[j].w : pre_y0[j].y, yv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             s1[i][r] += v[r];
@@ -590,12 +594,13 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
           }
           if (p.bn_y[1]) {
             float y2[4];
-            bf4(pre_y1[j][i], y2);
+            bf4(i ? pre_y1[j].z : pre_y1[j].x, i ? pre_y1[j].w : pre_y1[j].y, y2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s3[i][r] += v[r] * (y2[r] - mu1[i][r]) * is1[i][r];
           }
         }
       }
+      *reinterpret_cast<bf16x8*>(dst + off) = o;
     }
   }
 
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
     }
     __syncthreads();
     if (tid < 64) {
-      const int n = tid, wn_ = n >> 5, i = (n >> 4) & 1, fk_ = (n >> 2) & 3, r = n & 3;
+      const int n = tid, wn_ = n >> 5, fk_ = (n >> 3) & 3, i = (n >> 2) & 1, r = n & 3;  // n = wn*32 + fk*8 + i*4 + r
       float a = 0.f, bb = 0.f, c = 0.f;
       for (int w4 = 0; w4 < 4; ++w4) {
         const float* d = red + (((((wn_ * 4 + w4) * 2 + i) * 4 + fk_) * 4 + r) * 3);
