@@ -41,6 +41,9 @@ constexpr int ST_STG_ROW = 144;                   // 128 B of channels + 16 B pa
 constexpr int ST_STG = 16 * ST_STG_ROW;           // per-wave epilogue staging
 constexpr int ST_LDS = 2 * ST_BUF + 4 * ST_STG;
 
+// AFF: scale / shift (+ReLU) epilogue (eval mode); STATS: BatchNorm partial sums (train mode).  The epilogue's VALU work
+// is comparable to a block's 28 MFMAs, so neither half is compiled in unless it is used.
+template <bool AFF, bool STATS>
 __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -119,10 +122,15 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a = acc[cb][r];
-          s1[cb][r] += a;
-          s2[cb][r] += a * a;
-          v[r] = a * sc[cb][r] + sh[cb][r];
-          if (p.relu) v[r] = fmaxf(v[r], 0.f);
+          if (STATS) {
+            s1[cb][r] += a;
+            s2[cb][r] += a * a;
+          }
+          v[r] = a;
+          if (AFF) {
+            v[r] = a * sc[cb][r] + sh[cb][r];
+            if (p.relu) v[r] = fmaxf(v[r], 0.f);
+          }
         }
         bf16x4 o;
 #pragma unroll
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if (p.stats) {
+  if (STATS && p.stats) {
     // [wave][lane][32] f32 over the (now idle) input buffers, then 128 threads add 64 values each
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
@@ -206,17 +214,20 @@ int qt_stem_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   a.y = static_cast<bf16_t*>(io->dst);
   a.scale = io->scale; a.shift = io->shift; a.stats = io->stats_partial;
   a.relu = d->relu; a.taps = d->kh; a.ntiles = d->batch * (112 / ST_TH);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+  const bool aff = a.scale != nullptr || a.relu, stats = a.stats != nullptr;
+  void (*kern)(StemArgs) = aff ? (stats ? conv_stem_kernel<true, true> : conv_stem_kernel<true, false>)
+                               : (stats ? conv_stem_kernel<false, true> : conv_stem_kernel<false, false>);
+  static bool attr_done[4] = {false, false, false, false};
+  const int ki = (aff ? 2 : 0) + (stats ? 1 : 0);
+  if (!attr_done[ki]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
     if (e != hipSuccess) {
       qt_set_error("hipFuncSetAttribute(%d B LDS): %s", ST_LDS, hipGetErrorString(e));
       return QT_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done[ki] = true;
   }
-  hipLaunchKernelGGL(conv_stem_kernel, dim3(stem_grid(d->batch)), dim3(256), ST_LDS, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(kern, dim3(stem_grid(d->batch)), dim3(256), ST_LDS, static_cast<hipStream_t>(stream), a);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
