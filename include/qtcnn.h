@@ -314,14 +314,16 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *                          grads[i] (f32, same layout as tensors[i]) is written
  *                          (not accumulated) when non-NULL; QT_BWD_HEAD = classifier,
  *                          numerical MLP and quadrant head, QT_BWD_LAYER4 = layer4,
- *                          QT_BWD_REST = layers 3..1 and the stem (lets the caller start the
- *                          gradient all-reduce of a bucket while the next phase runs).
+ *                          QT_BWD_LAYER32 = layers 3 and 2, QT_BWD_LAYER1 = layer1 and the stem
+ *                          (lets the caller start the gradient all-reduce of a bucket while the
+ *                          next phase runs; the last bucket is 0.6 MB).
  * ------------------------------------------------------------------------ */
 enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1 };
 enum { QT_MODE_FUSION = 0, QT_MODE_IMAGE_ONLY = 1, QT_MODE_NUMERICAL_ONLY = 2 };
-/* QT_BWD_BACKBONE = QT_BWD_LAYER4 | QT_BWD_REST; call order HEAD, LAYER4, REST (or any union of
- * consecutive phases in one call). */
-enum { QT_BWD_HEAD = 1, QT_BWD_LAYER4 = 2, QT_BWD_REST = 4, QT_BWD_BACKBONE = 6, QT_BWD_ALL = 7 };
+/* call order HEAD, LAYER4, LAYER32, LAYER1 (or any union of consecutive phases in one call);
+ * QT_BWD_REST = LAYER32 | LAYER1, QT_BWD_BACKBONE = LAYER4 | REST. */
+enum { QT_BWD_HEAD = 1, QT_BWD_LAYER4 = 2, QT_BWD_LAYER32 = 4, QT_BWD_LAYER1 = 8, QT_BWD_REST = 12, QT_BWD_BACKBONE = 14,
+       QT_BWD_ALL = 15 };
 
 typedef struct qt_plan_desc {
   int dtype;

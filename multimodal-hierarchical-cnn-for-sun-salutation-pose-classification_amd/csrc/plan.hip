@@ -864,7 +864,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     e.run(zero(e.at(p->dw_begin), p->dw_end - p->dw_begin, stream));
     p->dw_dirty = false;
   }
-  if (phases & QT_BWD_REST) p->dw_dirty = true;
+  if (phases & QT_BWD_LAYER1) p->dw_dirty = true;
   const int dt = e.dt;
   const int B = e.B;
   const bool tr = p->last_training != 0;
@@ -965,11 +965,13 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   // (no join after a partial phase: the caller orders its consumer behind the side stream with
   //  qt_plan_side_fence, so the main chain never stalls on the weight-gradient stream)
 
-  // The backbone can be run in two calls -- QT_BWD_LAYER4 (blocks 7, 6: 8.4 M of the 11.2 M backbone
-  // parameters) then QT_BWD_REST -- so that a data-parallel caller can start reducing layer4's
-  // gradients while layers 3..1 and the stem are still running.
+  // The backbone can be run in three calls -- QT_BWD_LAYER4 (blocks 7, 6: 8.4 M of the 11.2 M backbone
+  // parameters), QT_BWD_LAYER32 (blocks 5..2: 2.6 M), QT_BWD_LAYER1 (blocks 1, 0 and the stem: 0.16 M) -- so
+  // that a data-parallel caller reduces each bucket while the next phase runs and only 0.6 MB of gradients
+  // is left to reduce after the last kernel.
   if ((phases & QT_BWD_BACKBONE) && backbone_grads) {
-    const bool do_l4 = (phases & QT_BWD_LAYER4) != 0, do_rest = (phases & QT_BWD_REST) != 0;
+    const bool do_l4 = (phases & QT_BWD_LAYER4) != 0, do_l32 = (phases & QT_BWD_LAYER32) != 0;
+    const bool do_rest = (phases & QT_BWD_LAYER1) != 0;  // the last phase: layer1 and the stem
     int rows_bn2 = 0;  // partial rows of bn2 / downsample-BN of the block being entered (0 = none yet)
     if (do_l4) {
       // gradient of layer4's output through avgpool (+ ReLU mask of the block output)
@@ -978,7 +980,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     } else {
       rows_bn2 = p->bwd_rows_bn2;
     }
-    const int bi_hi = do_l4 ? 7 : 5, bi_lo = do_rest ? 0 : 6;
+    const int bi_hi = do_l4 ? 7 : (do_l32 ? 5 : 1), bi_lo = do_rest ? 0 : (do_l32 ? 2 : 6);
     for (int bi = bi_hi; bi >= bi_lo; --bi) {
       const Block& blk = p->blocks[bi];
       const ConvL& c1 = p->convs[blk.conv1];
@@ -1058,7 +1060,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     }
   }
   // the last phase (or a head-only model) joins: afterwards the caller's stream sees every gradient
-  if ((phases & QT_BWD_REST) || !backbone_grads) {
+  if ((phases & QT_BWD_LAYER1) || !backbone_grads) {
     e.forked = e.forked || (p->side != nullptr && e.wstream == p->side);
     e.join();
   }

@@ -15,7 +15,7 @@ from ._lib import QtError
 
 QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET = 0, 1
 MODES = {"fusion": 0, "image_only": 1, "numerical_only": 2}
-QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_REST, QT_BWD_ALL = 1, 2, 4, 7
+QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_LAYER32, QT_BWD_LAYER1, QT_BWD_ALL = 1, 2, 4, 8, 15
 
 
 class PlanDesc(ctypes.Structure):
@@ -211,23 +211,26 @@ class PlanEngine:
     def backward(self, dlogits, numerical, wanted):
         """wanted: list of (plan tensor index, shape) in the order gradients are
         returned.  Gradients are views of one flat f32 buffer laid out
-        [head | layer4 | rest of the backbone]: the order in which backward finishes them, so a
-        data-parallel caller all-reduces three buckets, each while the next phase runs."""
+        [head | layer4 | layer3 + layer2 | layer1 + stem]: the order in which backward finishes them, so a
+        data-parallel caller all-reduces four buckets (59 / 34 / 10.5 / 0.6 MB), each while the next phase
+        runs; only the last, smallest one is exposed."""
         def bucket_of(idx):
             name = self.names[idx]
             if not name.startswith("base_cnn."):
                 return 0
-            return 1 if name.startswith("base_cnn.layer4.") else 2
+            if name.startswith("base_cnn.layer4."):
+                return 1
+            return 2 if name.startswith(("base_cnn.layer3.", "base_cnn.layer2.")) else 3
         order = sorted(wanted, key=lambda w: bucket_of(w[0]))  # stable: keeps parameter order inside a bucket
         sizes = {idx: int(torch.Size(shape).numel()) for idx, shape in wanted}
         # keep every view 16-byte aligned
-        offs, total, ends = {}, 0, [0, 0, 0]
+        offs, total, ends = {}, 0, [0, 0, 0, 0]
         for idx, _ in order:
             offs[idx] = total
             total += (sizes[idx] + 3) // 4 * 4
             ends[bucket_of(idx)] = total
-        ends[1] = max(ends[1], ends[0])
-        ends[2] = max(ends[2], ends[1])
+        for b in range(1, 4):
+            ends[b] = max(ends[b], ends[b - 1])
         flat = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
         grad_ptrs = (ctypes.c_void_p * len(self.names))()
         views = {}
@@ -248,7 +251,7 @@ class PlanEngine:
             run(QT_BWD_ALL)
         else:
             begin = 0
-            for b, phase in enumerate((QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_REST)):
+            for b, phase in enumerate((QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_LAYER32, QT_BWD_LAYER1)):
                 run(phase)
                 if ends[b] > begin:
                     self.grad_sync(flat[begin:ends[b]], phase, self.side_fence)
