@@ -40,10 +40,21 @@ __global__ void gemm_small_thread_kernel(SmallArgs a) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i % a.N), m = (int)(i / a.N);
-    float acc = 0.f;
-    for (int k = 0; k < a.K; ++k)
-      acc += ld(a.A, (long long)m * a.ars + k * a.aks, a.a_bf16) * ld(a.B, (long long)n * a.brs + k * a.bks, a.b_bf16);
-    finish(a, m, n, acc);
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long ab = (long long)m * a.ars, bb = (long long)n * a.brs;
+    int k = 0;
+    for (; k + 3 < a.K; k += 4) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = ld(a.A, ab + (long long)(k + u) * a.aks, a.a_bf16);
+        bv[u] = ld(a.B, bb + (long long)(k + u) * a.bks, a.b_bf16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] += av[u] * bv[u];
+    }
+    for (; k < a.K; ++k) acc4[0] += ld(a.A, ab + (long long)k * a.aks, a.a_bf16) * ld(a.B, bb + (long long)k * a.bks, a.b_bf16);
+    finish(a, m, n, (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]));
   }
 }
 
@@ -53,9 +64,23 @@ __global__ __launch_bounds__(256) void gemm_small_wave_kernel(SmallArgs a) {
   const long long total = (long long)a.M * a.N;
   for (long long i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < total; i += (long long)gridDim.x * 4) {
     const int n = (int)(i % a.N), m = (int)(i / a.N);
-    float acc = 0.f;
-    for (int k = lane; k < a.K; k += 64)
-      acc += ld(a.A, (long long)m * a.ars + k * a.aks, a.a_bf16) * ld(a.B, (long long)n * a.brs + k * a.bks, a.b_bf16);
+    // four independent partial sums: the loop is a chain of dependent scalar loads otherwise (classifier.3
+    // forward, K = 2688: 42 trips of one memory latency each)
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long ab = (long long)m * a.ars, bb = (long long)n * a.brs;
+    int k = lane;
+    for (; k + 192 < a.K; k += 256) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = ld(a.A, ab + (long long)(k + 64 * u) * a.aks, a.a_bf16);
+        bv[u] = ld(a.B, bb + (long long)(k + 64 * u) * a.bks, a.b_bf16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] += av[u] * bv[u];
+    }
+    for (; k < a.K; k += 64) acc4[0] += ld(a.A, ab + (long long)k * a.aks, a.a_bf16) * ld(a.B, bb + (long long)k * a.bks, a.b_bf16);
+    float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) finish(a, m, n, acc);
