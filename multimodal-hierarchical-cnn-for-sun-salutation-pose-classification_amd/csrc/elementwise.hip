@@ -611,7 +611,8 @@ __global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ dst, int
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    for (int p = 0; p < HW; ++p) {
+#pragma unroll 7
+    for (int p = 0; p < HW; ++p) {  // 7 independent 16-byte loads in flight (HW = 49 here)
       float v[8];
       QtVec8<T>::load(x + ((long long)b * HW + p) * C + c0, v);
 #pragma unroll
