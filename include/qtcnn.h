@@ -234,6 +234,11 @@ int qt_bn_bwd_apply(int dtype, const void* g, const void* mask, const void* y, c
  * the raw conv1 output at that tap (input of qt_stem_bn_bwd_sums). */
 int qt_stem_pool(int dtype, const void* y, const float* scale, const float* shift, void* pooled,
                  unsigned char* argmax, void* y_at_max, int batch, void* stream);
+/* Eval forward: conv1 (packed stem descriptor: xpad, qt_pack_stem_weight's [64][taps][32]) + folded BatchNorm
+ * (scale / shift) + ReLU + MaxPool2d(3,2,1) in one launch; the conv1 map never reaches memory.  bf16 only
+ * (QT_ERR_UNSUPPORTED otherwise: qt_conv2d_igemm + qt_stem_pool). */
+int qt_stem_conv_pool(int dtype, const void* xpad, const void* weight, int taps, const float* scale, const float* shift,
+                      void* pooled, int batch, void* stream);
 int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
                      const float* shift, void* g, int batch, void* stream);
 /* The same gradient fused with bn1's backward, without materialising it: _reduce emits

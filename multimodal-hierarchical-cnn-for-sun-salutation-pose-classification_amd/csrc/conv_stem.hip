@@ -172,6 +172,138 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Eval mode: conv1 + folded BatchNorm + ReLU + MaxPool2d(3,2,1) in one kernel (the 411 MB conv1 map
+// is neither written nor read back; SURVEY.md 8(d) lists this fusion).  One 8-wave workgroup per CU
+// walks tiles of TWO pooled rows: the five conv1 rows they need (4k-1 .. 4k+3) are computed exactly as
+// above from 15 packed input rows, written as bf16 into an LDS tile [5][112][64] (144-byte pixel
+// stride), and after a barrier every thread reduces 3x3 windows of that tile to pooled pixels.
+// Post-ReLU values are >= 0, so out-of-image window positions are simply skipped.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_IN_ROWS = 15;
+constexpr int SP_BUF = 28 * 1024;                  // >= 15 * 1856 = 27840
+static_assert(SP_IN_ROWS * ST_ROWB <= SP_BUF, "input rows of a fused tile fit one buffer");
+constexpr int SP_PXB = 144;                        // bytes per pixel in the conv tile (128 + pad)
+constexpr int SP_TILE = 5 * 112 * SP_PXB;          // 80640
+constexpr int SP_LDS = 2 * SP_BUF + SP_TILE;
+
+struct StemPoolArgs {
+  const bf16_t* x;        // [B][230][232][4]
+  const bf16_t* w;        // [64][taps][32]
+  bf16_t* pooled;         // [B][56][56][64]
+  const float* scale;
+  const float* shift;
+  int taps, ntiles;       // ntiles = B * 28
+};
+
+__global__ __launch_bounds__(512) void conv_stem_pool_kernel(StemPoolArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const unsigned smem_base = lds_addr_of(smem);
+  unsigned char* ctile = smem + 2 * SP_BUF;
+
+  const int t_beg = (int)((long long)blockIdx.x * p.ntiles / gridDim.x);
+  const int t_end = (int)((long long)(blockIdx.x + 1) * p.ntiles / gridDim.x);
+
+  uint4 wf[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      wf[kh][cb] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(cb * 16 + li) * p.taps + kh) * 32 + lg * 8);
+  float sc[4][4], sh[4][4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = cb * 16 + lg * 4 + r;
+      sc[cb][r] = p.scale[ch];
+      sh[cb][r] = p.shift[ch];
+    }
+
+  // tile (img, k): LDS row j of the input buffer = packed input row 8k - 2 + j (rows -2, -1 of the first tile of an
+  // image are never read: conv row -1 is skipped).  28 DMA instructions of 1 KB, waves 0..6 take four each.
+  auto dma_tile = [&](int tile, int buf) {
+    if (wave >= 7) return;
+    const int img = tile / 28, k = tile - img * 28;
+    const int row0 = k == 0 ? 0 : 8 * k - 2;   // first packed row fetched
+    const int skip = k == 0 ? 2 : 0;           // LDS rows left untouched in front of it
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)img * QT_STEM_PAD_H + row0) * ST_ROWB;
+    const int nblk = k == 0 ? 24 : 28;         // 13 rows (24128 B) instead of 15 for the first tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int blk = wave * 4 + i;
+      if (blk < nblk) glds16(src + blk * 1024 + lane * 16, smem_base + buf * SP_BUF + skip * ST_ROWB + blk * 1024);
+    }
+  };
+
+  if (t_beg < t_end) dma_tile(t_beg, 0);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int buf = (t - t_beg) & 1;
+    // this tile's rows have landed; every wave is done pooling the previous tile (conv tile free) and reading its input
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);
+    const unsigned char* in = smem + buf * SP_BUF;
+    const int img = t / 28, k = t - img * 28;
+    // ---- conv phase: 35 blocks of 16 pixels (tile row tr = 0..4 <-> conv row 4k - 1 + tr), wave w takes w, w+8, ... ----
+#pragma unroll 1
+    for (int rb = wave; rb < 35; rb += 8) {
+      const int tr = rb / 7, ob = rb - tr * 7;
+      if (k == 0 && tr == 0) continue;           // conv row -1 does not exist
+      const unsigned char* a0 = in + (2 * tr) * ST_ROWB + 16 * (ob * 16 + li + lg);
+      uint4 xf[7];
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) xf[kh] = *reinterpret_cast<const uint4*>(a0 + kh * ST_ROWB);
+      f32x4 acc[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kh][cb]),
+                                                            __builtin_bit_cast(bf16x8, xf[kh]), acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[cb][r] * sc[cb][r] + sh[cb][r], 0.f);
+        *reinterpret_cast<bf16x4*>(ctile + ((tr * 112 + ob * 16 + li) * SP_PXB) + cb * 32 + lg * 8) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the conv tile is complete
+    // ---- pool phase: 2 pooled rows x 56 pixels x 8 channel groups = 896 items ----
+    for (int it = tid; it < 896; it += 512) {
+      const int cg = it & 7, pw = (it >> 3) % 56, pi = it / (8 * 56);
+      float best[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[e] = 0.f;
+#pragma unroll
+      for (int dr = 0; dr < 3; ++dr) {
+        const int tr = 2 * pi + dr;               // conv row 4k - 1 + tr
+        if (k == 0 && tr == 0) continue;
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) {
+          const int col = 2 * pw - 1 + dc;
+          if ((unsigned)col >= 112u) continue;
+          const uint4 raw = *reinterpret_cast<const uint4*>(ctile + (tr * 112 + col) * SP_PXB + cg * 16);
+          float v[8];
+          v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+          v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+          v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+          v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+        }
+      }
+      QtVec8<bf16_t>::store(p.pooled + (((size_t)img * 56 + 2 * k + pi) * 56 + pw) * 64 + cg * 8, best);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int g_stem_enabled = -1;
 bool stem_enabled() {
   if (g_stem_enabled < 0) {
@@ -228,6 +360,35 @@ int qt_stem_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
     attr_done[ki] = true;
   }
   hipLaunchKernelGGL(kern, dim3(stem_grid(d->batch)), dim3(256), ST_LDS, static_cast<hipStream_t>(stream), a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+// conv1 + BatchNorm (as scale / shift) + ReLU + MaxPool2d(3,2,1) of the eval forward in one launch:
+// xpad [B][230][232][4] bf16, weights [64][taps][32] (qt_pack_stem_weight), pooled [B][56][56][64].
+extern "C" int qt_stem_conv_pool(int dtype, const void* xpad, const void* weight, int taps, const float* scale,
+                                 const float* shift, void* pooled, int batch, void* stream) {
+  QT_CHECK_ARG(xpad && weight && scale && shift && pooled && batch > 0 && (taps == 7 || taps == 8),
+               "qt_stem_conv_pool: bad argument");
+  if (dtype != QT_BF16 || !stem_enabled()) {
+    qt_set_error("qt_stem_conv_pool: bf16 only (use qt_conv2d_igemm + qt_stem_pool)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  StemPoolArgs a;
+  a.x = static_cast<const bf16_t*>(xpad); a.w = static_cast<const bf16_t*>(weight);
+  a.pooled = static_cast<bf16_t*>(pooled); a.scale = scale; a.shift = shift; a.taps = taps; a.ntiles = batch * 28;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    if (e != hipSuccess) {
+      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", SP_LDS, hipGetErrorString(e));
+      return QT_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  hipLaunchKernelGGL(conv_stem_pool_kernel, dim3(grid), dim3(512), SP_LDS, static_cast<hipStream_t>(stream), a);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

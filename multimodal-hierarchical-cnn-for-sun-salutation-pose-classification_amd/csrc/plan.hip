@@ -654,10 +654,19 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
       e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), e.at(p->p0),
                          e.at<unsigned char>(p->argmax), e.at(p->ymax), batch, stream));
     } else {
-      e.igemm(sd, e.at(p->xpad), e.at(c0.w_fwd), e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), nullptr,
-              nullptr, nullptr, 1);
-      e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(p->ones), e.at<float>(p->zeros), e.at(p->p0), nullptr, nullptr,
-                         batch, stream));
+      // eval: conv1 + folded bn1 + ReLU + max pool in one kernel (bf16); the conv1 map is not materialised
+      const int slot = e.begin_timed(e.conv_flops(sd), 0);
+      const int fused = qt_stem_conv_pool(dt, e.at(p->xpad), e.at(c0.w_fwd), e.stem_taps(), e.at<float>(bn0.scale),
+                                          e.at<float>(bn0.shift), e.at(p->p0), batch, stream);
+      e.end_timed(slot);
+      if (fused == QT_ERR_UNSUPPORTED) {
+        e.igemm(sd, e.at(p->xpad), e.at(c0.w_fwd), e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), nullptr,
+                nullptr, nullptr, 1);
+        e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(p->ones), e.at<float>(p->zeros), e.at(p->p0), nullptr, nullptr,
+                           batch, stream));
+      } else {
+        e.run(fused);
+      }
     }
     // ---- residual stages ----
     size_t x = p->p0;

@@ -180,3 +180,36 @@ def test_stem_conv_dedicated_kernel(B):
     assert rel_err(s, sg) <= 1e-4
     act = F.relu(ref * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1))
     assert rel_err(y_act.float().cpu().permute(0, 3, 1, 2), act) <= 4e-3
+
+
+@pytest.mark.parametrize("B", [1, 3, 11])   # 28 / 84 / 308 tiles: fewer and more tiles than workgroups
+def test_stem_conv_pool_fused_eval_kernel(B):
+    """qt_stem_conv_pool (conv1 + folded BatchNorm + ReLU + MaxPool2d(3,2,1), eval forward) against torch on the CPU and
+    against the two-kernel form (qt_conv2d_igemm with the affine epilogue + qt_stem_pool)."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    dt = torch.bfloat16
+    qdt = L.qt_dtype(dt)
+    g = torch.Generator().manual_seed(120 + B)
+    image = torch.randn(B, 3, 224, 224, generator=g).to(dt).float()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(dt).float()
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.5
+    ref = F.max_pool2d(F.relu(F.conv2d(image, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1)
+    st = L.stream_ptr()
+    imd, wd, sc, sh = image.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    xpad = torch.empty(B, 230, 232, 4, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_input(qdt, L.ptr(imd), L.ptr(xpad), B, st), "qt_pack_stem_input")
+    wp = torch.empty(64, 8, 32, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_weight(qdt, L.ptr(wd), L.ptr(wp), 8, st), "qt_pack_stem_weight")
+    pooled = torch.full((B, 56, 56, 64), float("nan"), device=dev, dtype=dt)
+    L.check(lib.qt_stem_conv_pool(qdt, L.ptr(xpad), L.ptr(wp), 8, L.ptr(sc), L.ptr(sh), L.ptr(pooled), B, st), "qt_stem_conv_pool")
+    # two-kernel form
+    y, _ = _stem_conv(L, dt, imd, wd, 8, False, sc, sh, relu=1)
+    ones, zeros = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    pooled2 = torch.empty(B, 56, 56, 64, device=dev, dtype=dt)
+    L.check(lib.qt_stem_pool(qdt, L.ptr(y), L.ptr(ones), L.ptr(zeros), L.ptr(pooled2), None, None, B, st), "qt_stem_pool")
+    torch.cuda.synchronize()
+    assert torch.equal(pooled, pooled2)                       # same MFMA order, same rounding: bit-identical
+    assert rel_err(pooled.float().cpu().permute(0, 3, 1, 2), ref) <= 4e-3
