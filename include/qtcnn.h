@@ -64,9 +64,11 @@ typedef struct qt_conv_desc {
   long long src_img_stride; /* elements between images of src */
   int src_row_stride;       /* elements between rows of src */
   int src_pix_stride;       /* elements between pixels of src */
-  int quad;  /* 1: FWD reads the four 2x2 quadrants of a (2*in_h x 2*in_w) map as 4*batch
-                images with zero halo at the seam (models.py:277-287); DGRAD scatters
-                the per-quadrant gradient images back onto the un-split map */
+  int quad;  /* S = 2 (1 means 2) or 4: FWD reads the S x S regions of a (S*in_h x S*in_w) map as
+                S*S*batch images (region rr*S+rc of image n is image n*S*S + rr*S + rc) with zero halo
+                at the seams (Quadtree_from scratch/models.py:277-287 quadrants; :62-78 quadrants and
+                sub-quadrants of AttentionHierarchicalCNN); DGRAD scatters the per-region gradient
+                images back onto the un-split map */
   int relu;
   /* optional strided destination (0 = dense [M][n_out]): row (img, oh, ow) is written to pixel
    * (oh*dst_sub + dst_off_h, ow*dst_sub + dst_off_w) of a dst_h x dst_w image; residual and
@@ -266,6 +268,28 @@ int qt_avgpool_bwd(int dtype, const void* d, const void* x, void* g, int batch, 
  * (Quadtree_from scratch/models.py:237,284-294): q [B*4][7][7][128] -> dst[b][col0 + quad*1152 + c*9 + ph*3 + pw] */
 int qt_quad_pool(int dtype, const void* q, void* dst, int batch, int ld, int col0, void* stream);
 int qt_quad_pool_bwd(int dtype, const void* d, const void* q, void* dq, int batch, int ld, int col0, void* stream);
+/* Heads of AttentionHierarchicalCNN (Quadtree_from scratch/models.py:6-101).
+ * qt_region_avgpool: AdaptiveAvgPool2d((1,1)) + flatten of the per-region conv+ReLU maps x [batch*split^2][hw][C]
+ *   (:21-30) into dst[b*ld + col0 + slot*C + c]; `slot` is the reference's append order -- quadrants TL,TR,BL,BR
+ *   (:62-67), and for split 4 quadrant*4 + sub-quadrant (:70-78).  dst_dtype: `dtype` or QT_F32.
+ * qt_region_avgpool_bwd: g = x > 0 ? d[...]/hw : 0  (mean-pool backward fused with the ReLU mask).
+ * qt_attention_gate (:34-38,:81-89): v [B][16][64] f32; act [B][16][32] = relu(W1 v + b1); alpha [B][16] =
+ *   softmax_j(w2 . act_j + b2); out[b*ld + col0 + c] = sum_j alpha_j v_j[c]   (out has type `dtype`).
+ * qt_attention_gate_bwd: from d[b*ld + col0 + c] -> dv [B][16][64], and the two row-wise factors of the
+ *   parameter gradients: ds [B][16] (d/d score) and dpre [B][16][32] (d/d pre-ReLU hidden), so that
+ *   dW1 = dpre^T v, db1 = sum dpre, dw2 = ds^T act, db2 = sum ds (qt_gemm_small / qt_col_sum).
+ * qt_relu_mask_cols: out[r][c] = act[r*ld+col0+c] > 0 ? d[r*ld+col0+c]*mul : 0  (f32, dense): backward of the
+ *   Linear -> ReLU -> Dropout numerical branch (:43-46) whose output lives inside the fused feature matrix. */
+int qt_region_avgpool(int dtype, const void* x, void* dst, int dst_dtype, int batch, int split, int hw, int C, int ld,
+                      int col0, void* stream);
+int qt_region_avgpool_bwd(int dtype, const void* d, int d_dtype, const void* x, void* g, int batch, int split, int hw,
+                          int C, int ld, int col0, void* stream);
+int qt_attention_gate(int dtype, const float* v, const float* w1, const float* b1, const float* w2, const float* b2,
+                      float* act, float* alpha, void* out, int batch, int ld, int col0, void* stream);
+int qt_attention_gate_bwd(int dtype, const void* d, const float* v, const float* act, const float* alpha, const float* w1,
+                          const float* w2, float* ds, float* dpre, float* dv, int batch, int ld, int col0, void* stream);
+int qt_relu_mask_cols(int dtype, const void* d, const void* act, float* out, long long rows, int cols, int ld, int col0,
+                      float mul, void* stream);
 /* nn.Dropout (Quadtree_from scratch/models.py:258,269), in place, counter-hash RNG */
 int qt_dropout(int dtype, void* x, long long rows, int cols, int ld, unsigned long long seed, float p, void* stream);
 /* g = act > 0 ? g*mul : 0 (ReLU / dropout backward from the forward output) */
@@ -305,6 +329,10 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *   QT_MODEL_QUADTREE         QuadtreeCNN  (Quadtree_from scratch/models.py:214-305;
  *                             resnet/models.py:70-180 with `mode`)
  *   QT_MODEL_STANDARD_RESNET  StandardResNetCNN (resnet/models.py:7-65)
+ *   QT_MODEL_ATTENTION        AttentionHierarchicalCNN (Quadtree_from scratch/models.py:6-101); `mode` is
+ *                             ignored; tensors are listed under base_cnn.* names for the ResNet part (the
+ *                             reference keeps it as a local: bind features_extractor.{0,1,4,5} /
+ *                             global_processor.{0,1} to base_cnn.{conv1,bn1,layer1,layer2} / {layer3,layer4})
  * The tensor table lists every parameter / buffer under the reference's
  * state_dict key (first-seen `base_cnn.*` names); the caller
  * passes one device pointer per entry (f32, reference layouts: OIHW conv
@@ -323,7 +351,7 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *                          (lets the caller start the gradient all-reduce of a bucket while the
  *                          next phase runs; the last bucket is 0.6 MB).
  * ------------------------------------------------------------------------ */
-enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1 };
+enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1, QT_MODEL_ATTENTION = 2 };
 enum { QT_MODE_FUSION = 0, QT_MODE_IMAGE_ONLY = 1, QT_MODE_NUMERICAL_ONLY = 2 };
 /* call order HEAD, LAYER4, LAYER32, LAYER1 (or any union of consecutive phases in one call);
  * QT_BWD_REST = LAYER32 | LAYER1, QT_BWD_BACKBONE = LAYER4 | REST. */
@@ -352,7 +380,8 @@ int qt_plan_tensor_kind(const qt_plan* plan, int i);            /* 0 parameter, 
 int qt_plan_tensor_shape(const qt_plan* plan, int i, int* dims4); /* returns ndim */
 size_t qt_plan_workspace_bytes(const qt_plan* plan);
 /* byte offset inside the workspace of a named activation / gradient buffer:
- * "stem.pooled", "block<0-7>.out|.a1|.gout", "conv<i>.y|.gy", "fused", "dfused", "hidden" */
+ * "stem.pooled", "block<0-7>.out|.a1|.gout", "conv<i>.y|.gy", "fused", "dfused", "hidden";
+ * QT_MODEL_ATTENTION also "attention.vectors" (f32 [B][16][64]) and "attention.weights" (f32 [B][16]) */
 int qt_plan_find_buffer(const qt_plan* plan, const char* name, size_t* offset);
 /* Measurement aid (bench.py roofline): while enabled, every MFMA kernel launch is
  * bracketed by HIP events on its stream; _end sums algorithmic FLOPs, milliseconds

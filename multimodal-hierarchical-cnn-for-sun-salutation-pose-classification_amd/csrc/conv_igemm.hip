@@ -145,17 +145,21 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         if (!DGRAD) {
           // destination = quadrant-local 7x7 pixel of quadrant q of image n;
           // source = the un-split map, offset to the quadrant's corner.
-          const int n = img >> 2, q = img & 3;
+          // (p.quad = S: the map is split into S x S regions, numbered row-major)
+          const int S = p.quad, R = S * S;
+          const int n = img / R, q = img - n * R;
+          const int qr = q / S, qc = q - qr * S;
           base = (long long)n * p.src_img_stride +
-                 (long long)(q >> 1) * p.IH * p.src_row_stride +
-                 (long long)(q & 1) * p.IW * p.src_pix_stride;
+                 (long long)qr * p.IH * p.src_row_stride +
+                 (long long)qc * p.IW * p.src_pix_stride;
         } else {
-          // destination = pixel of the un-split (2*IH x 2*IW) map; source = the
-          // dense per-quadrant gradient image of the quadrant that owns it.
-          const int qh = oh >= p.IH, qw = ow >= p.IW;
-          base = (long long)(img * 4 + qh * 2 + qw) * p.src_img_stride;
-          oh -= qh * p.IH;
-          ow -= qw * p.IW;
+          // destination = pixel of the un-split (S*IH x S*IW) map; source = the
+          // dense per-region gradient image of the region that owns it.
+          const int S = p.quad;
+          int qh = 0, qw = 0;
+          while (oh >= p.IH) { oh -= p.IH; ++qh; }
+          while (ow >= p.IW) { ow -= p.IW; ++qw; }
+          base = (long long)((img * S + qh) * S + qw) * p.src_img_stride;
         }
       } else {
         base = (long long)img * p.src_img_stride;
@@ -660,7 +664,7 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   if (!d) return QT_ERR_INVALID_ARG;
   if (qt_patch_eligible(d)) return qt_patch_stats_rows(d);
   if (qt_stem_eligible(d, nullptr)) return qt_stem_stats_rows(d);
-  const long long M = (long long)d->batch * (d->quad && d->mode == QT_CONV_FWD ? 4 : 1) * d->out_h * d->out_w;
+  const long long M = (long long)d->batch * (d->mode == QT_CONV_FWD ? qt_quad_regions(d->quad) : 1) * d->out_h * d->out_w;
   const int esz = d->dtype == QT_F32 ? 4 : 2;
   return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
 }
@@ -680,6 +684,7 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG(d->kh > 0 && d->kw > 0 && (d->stride == 1 || d->stride == 2) && d->pad >= 0,
                "qt_conv2d_igemm: bad filter geometry kh=%d kw=%d stride=%d pad=%d", d->kh, d->kw, d->stride, d->pad);
   QT_CHECK_ARG(!(d->quad && d->stride != 1), "qt_conv2d_igemm: quadrant mode needs stride 1");
+  QT_CHECK_ARG(d->quad == 0 || d->quad == 1 || d->quad == 2 || d->quad == 4, "qt_conv2d_igemm: quad must be 0, 1 (= 2), 2 or 4");
   QT_CHECK_ARG(d->kh * d->kw <= 32, "qt_conv2d_igemm: at most 32 taps (kh*kw=%d)", d->kh * d->kw);
   QT_CHECK_ARG(2 * d->k_per_tap != bk || d->kw == 1, "qt_conv2d_igemm: half-K-step taps need kw == 1");
   const int esz = d->dtype == QT_F32 ? 4 : 2;
@@ -715,13 +720,13 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.src_img_stride = d->src_img_stride;
   a.src_row_stride = d->src_row_stride;
   a.src_pix_stride = d->src_pix_stride;
-  const int imgs = d->batch * ((d->quad && d->mode == QT_CONV_FWD) ? 4 : 1);
+  const int imgs = d->batch * (d->mode == QT_CONV_FWD ? qt_quad_regions(d->quad) : 1);
   const long long M = (long long)imgs * d->out_h * d->out_w;
   QT_CHECK_ARG(M < (1ll << 31) && M * d->n_out < (1ll << 40), "qt_conv2d_igemm: problem too large");
   a.M = (int)M; a.N = d->n_out;
   a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
   a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw;
-  a.stride = d->stride; a.pad = d->pad; a.quad = d->quad; a.relu = d->relu;
+  a.stride = d->stride; a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.relu = d->relu;
   a.gridM = a.gridN = 0;
   a.dst_sub = d->dst_sub; a.dst_h = d->dst_h; a.dst_w = d->dst_w; a.dst_oh = d->dst_off_h; a.dst_ow = d->dst_off_w;
   a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));

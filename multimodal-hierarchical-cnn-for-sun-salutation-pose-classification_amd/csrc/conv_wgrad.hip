@@ -165,9 +165,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
           unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
           unsigned oh = fdiv(rem, p.div_ow);
           unsigned ow = rem - oh * (unsigned)p.OW;
-          const int n = img >> 2, q = img & 3;
-          const long long base = (long long)n * p.x_img_stride + (long long)(q >> 1) * p.IH * p.x_row_stride +
-                                 (long long)(q & 1) * p.IW * p.x_pix_stride;
+          const int S = p.quad, R = S * S;
+          const int n = (int)img / R, q = (int)img - n * R;
+          const int qr = q / S, qc = q - qr * S;
+          const long long base = (long long)n * p.x_img_stride + (long long)qr * p.IH * p.x_row_stride +
+                                 (long long)qc * p.IW * p.x_pix_stride;
           const int ih = (int)oh * p.stride + dh0, iw = (int)ow * p.stride + dw0;
           if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
             g = x + base + (long long)ih * p.x_row_stride + (long long)iw * p.x_pix_stride + b_coff;
@@ -415,11 +417,11 @@ extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const v
   WgradArgs a;
   a.dy = dy; a.x = x; a.dw = dw;
   a.x_img_stride = d->src_img_stride; a.x_row_stride = d->src_row_stride; a.x_pix_stride = d->src_pix_stride;
-  const long long M = (long long)d->batch * (d->quad ? 4 : 1) * d->out_h * d->out_w;
+  const long long M = (long long)d->batch * qt_quad_regions(d->quad) * d->out_h * d->out_w;
   QT_CHECK_ARG(M > 0 && M < (1ll << 31), "qt_conv2d_wgrad: bad pixel count");
   a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap;
   a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
-  a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad; a.quad = d->quad;
+  a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad; a.quad = qt_quad_split(d->quad);
   a.tap_stride = d->src_row_stride;
   a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
   a.div_ow = make_fastdiv((unsigned)d->out_w);

@@ -9,6 +9,8 @@
 // Graph restated (not copied) from
 //   /root/reference/Quadtree_from scratch/models.py:216-305  (QuadtreeCNN)
 //   /root/reference/resnet/models.py:7-65,70-180              (StandardResNetCNN, modes)
+//   /root/reference/Quadtree_from scratch/models.py:6-101    (AttentionHierarchicalCNN: split after layer2,
+//                                                             quadrant + sub-quadrant heads, attention gate)
 // and torchvision's ResNet-18 BasicBlock wiring.
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +41,7 @@ struct ConvL {
   int w, bias;  // tensor indices (bias -1 if none)
   int cin, cout, k, stride, pad, hin, hout;
   int bn;  // -1 if none
+  int regions = 1;  // images the conv sees per input image (quadrant heads: 4 or 16 regions of the shared map)
   size_t w_fwd, w_dgrad, dw;
   size_t y, gy;
   // stride-2 data gradient as four parity-class gathers (qt_pack_dgrad_s2)
@@ -67,9 +70,11 @@ struct qt_plan {
   std::vector<BnL> bns;
   std::vector<ConvL> convs;  // 0 stem, 1..19 blocks, 20 quadrant conv (if present)
   std::vector<Block> blocks;
-  int quad_conv = -1;
-  bool has_image = true, has_numerical = false, standard = false;
-  LinL mlp0{}, mlp1{}, cls0{}, cls3{};
+  int quad_conv = -1, sub_conv = -1;
+  bool has_image = true, has_numerical = false, standard = false, attention = false;
+  LinL mlp0{}, mlp1{}, cls0{}, cls3{}, att0{}, att2{};
+  // attention head (AttentionHierarchicalCNN): sub-quadrant vectors [B][16][64] f32 and what the gate's backward needs
+  size_t vsub = 0, dvsub = 0, att_act = 0, att_alpha = 0, att_ds = 0, att_dpre = 0, gbase_tmp2 = 0;
   int fused_ld = 0, img_cols = 0, mlp_col0 = 0, hidden_dim = 0;
   // workspace offsets
   size_t ws_bytes = 0;
@@ -153,8 +158,9 @@ struct Bump {
 void build_graph(qt_plan* p) {
   const qt_plan_desc& d = p->d;
   p->standard = d.model == QT_MODEL_STANDARD_RESNET;
-  p->has_image = p->standard || d.mode != QT_MODE_NUMERICAL_ONLY;
-  p->has_numerical = !p->standard && d.mode != QT_MODE_IMAGE_ONLY;
+  p->attention = d.model == QT_MODEL_ATTENTION;
+  p->has_image = p->standard || p->attention || d.mode != QT_MODE_NUMERICAL_ONLY;
+  p->has_numerical = p->attention || (!p->standard && d.mode != QT_MODE_IMAGE_ONLY);
   // ---- backbone (always present in the tensor table: state_dict parity) ----
   {
     const int w = p->add_tensor("base_cnn.conv1.weight", 0, {64, 3, 7, 7});
@@ -200,10 +206,25 @@ void build_graph(qt_plan* p) {
       cin = cout;
     }
   }
-  p->add_tensor("base_cnn.fc.weight", 0, {1000, 512});  // present in the state_dict, never used
-  p->add_tensor("base_cnn.fc.bias", 0, {1000});
-  if (!p->standard) {
+  if (!p->attention) {  // (the attention model keeps its ResNet as a local: no fc in its state_dict, models.py:11)
+    p->add_tensor("base_cnn.fc.weight", 0, {1000, 512});  // present in the state_dict, never used
+    p->add_tensor("base_cnn.fc.bias", 0, {1000});
+  }
+  if (p->attention) {
+    // models.py:21-30: both heads read layer2's 28x28x128 map, as 4 regions of 14x14 and 16 regions of 7x7
+    p->quad_conv = p->add_conv("quadrant_processor.0", 128, 128, 3, 1, 1, 14, -1, true);
+    p->convs[p->quad_conv].regions = 4;
+    p->sub_conv = p->add_conv("sub_quadrant_processor.0", 128, 64, 3, 1, 1, 7, -1, true);
+    p->convs[p->sub_conv].regions = 16;
+    p->att0 = p->add_linear("attention_gate.0", 64, 32);
+    p->att2 = p->add_linear("attention_gate.2", 32, 1);
+    p->mlp0 = p->add_linear("numerical_mlp.0", d.numerical_dim, 128);
+    p->img_cols = 512 + 4 * 128 + 64;  // global + four quadrant vectors + the attended sub-quadrant vector (:41)
+    p->fused_ld = p->img_cols + 128;
+    p->mlp_col0 = p->img_cols;
+  } else if (!p->standard) {
     p->quad_conv = p->add_conv("quadrant_processor.0", 256, 128, 3, 1, 1, 7, -1, true);
+    p->convs[p->quad_conv].regions = 4;
     p->mlp0 = p->add_linear("numerical_mlp.0", d.numerical_dim, d.numerical_dim * 2);
     p->mlp1 = p->add_linear("numerical_mlp.3", d.numerical_dim * 2, 256);
     p->img_cols = 512 + 4 * 1152;
@@ -214,7 +235,7 @@ void build_graph(qt_plan* p) {
     p->fused_ld = 512;
     p->mlp_col0 = 0;
   }
-  p->hidden_dim = p->standard ? 256 : p->fused_ld / 2;
+  p->hidden_dim = p->standard ? 256 : (p->attention ? 1024 : p->fused_ld / 2);
   p->cls0 = p->add_linear("classifier.0", p->fused_ld, p->hidden_dim);
   p->cls3 = p->add_linear("classifier.3", p->hidden_dim, d.num_classes);
 }
@@ -285,8 +306,7 @@ void layout_workspace(qt_plan* p) {
     p->ymax = ws.take(B * 56 * 56 * 64 * es);  // raw conv1 output at the pooling argmax (bn1 backward sums)
     for (size_t i = 0; i < p->convs.size(); ++i) {
       ConvL& c = p->convs[i];
-      const size_t imgs = ((int)i == p->quad_conv) ? B * 4 : B;
-      const size_t n = imgs * c.hout * c.hout * c.cout;
+      const size_t n = B * c.regions * c.hout * c.hout * c.cout;
       c.y = ws.take(n * es);
       c.gy = ws.take(n * es);
     }
@@ -299,7 +319,16 @@ void layout_workspace(qt_plan* p) {
       const ConvL& c1 = p->convs[blk.conv1];
       blk.gtmp = blk.ds >= 0 ? ws.take(B * c1.hin * c1.hin * c1.cin * es) : 0;
     }
-    p->gbase_tmp = ws.take(B * 14 * 14 * 256 * es);
+    p->gbase_tmp = ws.take(B * 28 * 28 * 128 * es);  // (>= layer3's 14x14x256 map)
+    if (p->attention) {
+      p->gbase_tmp2 = ws.take(B * 28 * 28 * 128 * es);
+      p->vsub = ws.take(B * 16 * 64 * 4);
+      p->dvsub = ws.take(B * 16 * 64 * 4);
+      p->att_act = ws.take(B * 16 * 32 * 4);
+      p->att_dpre = ws.take(B * 16 * 32 * 4);
+      p->att_alpha = ws.take(B * 16 * 4);
+      p->att_ds = ws.take(B * 16 * 4);
+    }
   }
   if (!p->standard) {
     p->q = p->convs[p->quad_conv].y;
@@ -424,6 +453,23 @@ struct Exec {
     }
     return d;
   }
+  // a head conv applied to each of the S x S regions of a shared map, zero halo at the seams
+  // (AttentionHierarchicalCNN, models.py:62-78): FWD reads the un-split map, DGRAD scatters back onto it
+  qt_conv_desc region_desc(const ConvL& c, int S, int mode) const {
+    qt_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dt; d.mode = mode; d.batch = B; d.kh = d.kw = c.k; d.stride = 1; d.pad = c.pad; d.quad = S;
+    d.in_h = d.in_w = c.hin;
+    if (mode == QT_CONV_FWD) {
+      d.out_h = d.out_w = c.hin; d.k_per_tap = c.cin; d.n_out = c.cout;
+      d.src_pix_stride = c.cin; d.src_row_stride = S * c.hin * c.cin;
+      d.src_img_stride = (long long)S * c.hin * S * c.hin * c.cin;
+    } else {
+      d.out_h = d.out_w = S * c.hin; d.k_per_tap = c.cout; d.n_out = c.cin;
+      d.src_pix_stride = c.cout; d.src_row_stride = c.hin * c.cout; d.src_img_stride = (long long)c.hin * c.hin * c.cout;
+    }
+    return d;
+  }
   qt_conv_desc linear_desc(int in, int out, int mode) const {
     qt_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -480,7 +526,7 @@ struct Exec {
   // algorithmic FLOPs (2*MAC of the convolution as the reference computes it: the
   // 7x7x3 stem counts 147 taps, a stride-2 dgrad counts the forward conv's MACs)
   double conv_flops(const qt_conv_desc& d) const {
-    const double imgs = (double)d.batch * (d.quad ? 4 : 1);
+    const double imgs = (double)d.batch * qt_quad_regions(d.quad);
     const double fwd_pixels = d.mode == QT_CONV_FWD ? (double)d.out_h * d.out_w : (double)d.in_h * d.in_w;
     const bool stem = d.k_per_tap == 32 && d.kw == 1 && d.stride == 2 && d.n_out == 64;
     const double k = stem ? 147.0 : (double)d.kh * d.kw * d.k_per_tap;
@@ -642,6 +688,31 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     e.run(qt_gemm_small(&g, e.at(p->h1), e.tf(p->mlp1.w), e.tf(p->mlp1.b),
                         e.at<unsigned char>(p->fused) + (size_t)p->mlp_col0 * p->esz, e.stream));
   };
+  // AttentionHierarchicalCNN (models.py:57-97): quadrant and sub-quadrant heads on layer2's map, the attention
+  // gate over the 16 sub-quadrant vectors and the one-layer numerical MLP; all of it only needs layer2's output.
+  auto attn_branch = [&]() {
+    const ConvL& cq = p->convs[p->quad_conv];
+    const ConvL& cs = p->convs[p->sub_conv];
+    const void* base = e.at(p->blocks[3].out);
+    e.igemm(e.region_desc(cq, 2, QT_CONV_FWD), base, e.at(cq.w_fwd), e.at(cq.y), nullptr, e.tf(cq.bias), nullptr, nullptr,
+            nullptr, 1);
+    e.run(qt_region_avgpool(dt, e.at(cq.y), e.at(p->fused), dt, batch, 2, 196, 128, p->fused_ld, 512, e.stream));
+    e.igemm(e.region_desc(cs, 4, QT_CONV_FWD), base, e.at(cs.w_fwd), e.at(cs.y), nullptr, e.tf(cs.bias), nullptr, nullptr,
+            nullptr, 1);
+    e.run(qt_region_avgpool(dt, e.at(cs.y), e.at(p->vsub), QT_F32, batch, 4, 49, 64, 16 * 64, 0, e.stream));
+    e.run(qt_attention_gate(dt, e.at<float>(p->vsub), e.tf(p->att0.w), e.tf(p->att0.b), e.tf(p->att2.w), e.tf(p->att2.b),
+                            e.at<float>(p->att_act), e.at<float>(p->att_alpha), e.at(p->fused), batch, p->fused_ld,
+                            512 + 4 * 128, e.stream));
+    qt_gemm_small_desc g;
+    memset(&g, 0, sizeof(g));
+    g.M = batch; g.N = p->mlp0.out; g.K = p->mlp0.in;
+    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = dt;
+    g.a_row_stride = p->mlp0.in; g.a_k_stride = 1; g.b_row_stride = p->mlp0.in; g.b_k_stride = 1;
+    g.c_row_stride = p->fused_ld; g.relu = 1;
+    unsigned char* z = e.at<unsigned char>(p->fused) + (size_t)p->mlp_col0 * p->esz;
+    e.run(qt_gemm_small(&g, numerical, e.tf(p->mlp0.w), e.tf(p->mlp0.b), z, e.stream));
+    if (tr && p->d.dropout_p > 0.f) e.run(qt_dropout(dt, z, batch, p->mlp0.out, p->fused_ld, seed, p->d.dropout_p, e.stream));
+  };
   if (p->has_image) {
     if (!tr) e.eval_affines();
     // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
@@ -725,11 +796,15 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         }
       }
       x = blk.out;
-      if (&blk == &p->blocks[5] && !p->standard) {  // layer3 is done: start the side branches
+      if (&blk == &p->blocks[p->attention ? 3 : 5] && !p->standard) {  // the heads' input is done: start the side branches
         e.fork();
         e.on_side(p->stats_ds, [&] {
-          quad_branch();
-          if (p->has_numerical) mlp_branch();
+          if (p->attention) {
+            attn_branch();
+          } else {
+            quad_branch();
+            if (p->has_numerical) mlp_branch();
+          }
         });
       }
     }
@@ -881,7 +956,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   bool backbone_grads = false;
   if (p->has_image)
     for (size_t i = 0; i < p->convs.size(); ++i) {
-      if ((int)i == p->quad_conv) continue;
+      if ((int)i == p->quad_conv || (int)i == p->sub_conv) continue;
       if (G[p->convs[i].w]) backbone_grads = true;
     }
   if (backbone_grads && !tr) {
@@ -929,7 +1004,22 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
                nullptr, 0);
     // ---- numerical MLP: seven small dependent kernels that only need dfused; they run on the side
     // stream (behind classifier.0's weight gradient) while the main stream enters the backbone ----
-    if (p->has_numerical) {
+    if (p->attention) {
+      // numerical_mlp = Linear -> ReLU -> Dropout (models.py:43-46), output inside the fused matrix
+      e.fork();
+      void* ms = e.wstream ? e.wstream : stream;
+      e.run(qt_relu_mask_cols(dt, e.at(p->dfused), e.at(p->fused), e.at<float>(p->dh1), B, p->mlp0.out, p->fused_ld,
+                              p->mlp_col0, drop_mul, ms));
+      if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, p->mlp0.out, p->mlp0.out, e.gf(p->mlp0.b), 0, ms));
+      if (e.gf(p->mlp0.w)) {
+        memset(&g, 0, sizeof(g));
+        g.M = p->mlp0.out; g.N = p->mlp0.in; g.K = B;
+        g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+        g.a_row_stride = 1; g.a_k_stride = p->mlp0.out; g.b_row_stride = 1; g.b_k_stride = p->mlp0.in;
+        g.c_row_stride = p->mlp0.in;
+        e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), ms));
+      }
+    } else if (p->has_numerical) {
       e.fork();
       void* ms = e.wstream ? e.wstream : stream;
       const unsigned char* dz = e.at<unsigned char>(p->dfused) + (size_t)p->mlp_col0 * p->esz;
@@ -959,8 +1049,50 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), ms));
       }
     }
+    if (p->attention) {
+      // ---- quadrant vectors: mean-pool backward (+ReLU mask) -> conv bias / weight gradients ----
+      const ConvL& cq = p->convs[p->quad_conv];
+      const ConvL& cs = p->convs[p->sub_conv];
+      e.run(qt_region_avgpool_bwd(dt, e.at(p->dfused), dt, e.at(cq.y), e.at(cq.gy), B, 2, 196, 128, p->fused_ld, 512, stream));
+      if (e.gf(cq.bias)) {
+        e.fork();
+        e.run(qt_col_sum(dt, e.at(cq.gy), (long long)B * 4 * 196, 128, 128, e.gf(cq.bias), 0, e.wstream ? e.wstream : stream));
+      }
+      e.wgrad(cq, e.region_desc(cq, 2, QT_CONV_FWD), e.at(p->blocks[3].out), false);
+      // ---- attention gate (models.py:81-89), then the sub-quadrant vectors ----
+      e.run(qt_attention_gate_bwd(dt, e.at(p->dfused), e.at<float>(p->vsub), e.at<float>(p->att_act),
+                                  e.at<float>(p->att_alpha), e.tf(p->att0.w), e.tf(p->att2.w), e.at<float>(p->att_ds),
+                                  e.at<float>(p->att_dpre), e.at<float>(p->dvsub), B, p->fused_ld, 512 + 4 * 128, stream));
+      {
+        e.fork();
+        void* as = e.wstream ? e.wstream : stream;
+        const int rows = B * 16;
+        if (e.gf(p->att0.w)) {  // [32][64] = dpre^T v
+          memset(&g, 0, sizeof(g));
+          g.M = 32; g.N = 64; g.K = rows;
+          g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+          g.a_row_stride = 1; g.a_k_stride = 32; g.b_row_stride = 1; g.b_k_stride = 64; g.c_row_stride = 64;
+          e.run(qt_gemm_small(&g, e.at(p->att_dpre), e.at(p->vsub), nullptr, e.gf(p->att0.w), as));
+        }
+        if (e.gf(p->att0.b)) e.run(qt_col_sum(QT_F32, e.at(p->att_dpre), rows, 32, 32, e.gf(p->att0.b), 0, as));
+        if (e.gf(p->att2.w)) {  // [1][32] = ds^T act
+          memset(&g, 0, sizeof(g));
+          g.M = 1; g.N = 32; g.K = rows;
+          g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+          g.a_row_stride = 0; g.a_k_stride = 1; g.b_row_stride = 1; g.b_k_stride = 32; g.c_row_stride = 32;
+          e.run(qt_gemm_small(&g, e.at(p->att_ds), e.at(p->att_act), nullptr, e.gf(p->att2.w), as));
+        }
+        if (e.gf(p->att2.b)) e.run(qt_col_sum(QT_F32, e.at(p->att_ds), rows, 1, 1, e.gf(p->att2.b), 0, as));
+      }
+      e.run(qt_region_avgpool_bwd(dt, e.at(p->dvsub), QT_F32, e.at(cs.y), e.at(cs.gy), B, 4, 49, 64, 16 * 64, 0, stream));
+      if (e.gf(cs.bias)) {
+        e.fork();
+        e.run(qt_col_sum(dt, e.at(cs.gy), (long long)B * 16 * 49, 64, 64, e.gf(cs.bias), 0, e.wstream ? e.wstream : stream));
+      }
+      e.wgrad(cs, e.region_desc(cs, 4, QT_CONV_FWD), e.at(p->blocks[3].out), false);
+    }
     // ---- quadrant head (weights are trainable in every variant) ----
-    if (p->has_image && !p->standard) {
+    if (p->has_image && !p->standard && !p->attention) {
       const ConvL& cq = p->convs[p->quad_conv];
       e.run(qt_quad_pool_bwd(dt, e.at(p->dfused), e.at(p->q), e.at(p->dq), B, p->fused_ld, 512, stream));
       if (e.gf(cq.bias)) {
@@ -1016,7 +1148,16 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr);
         resid = e.at(blk.gtmp);
       }
-      if (bi == 6 && !p->standard) {
+      if (bi == 4 && p->attention) {  // layer2's output also feeds the two heads
+        const ConvL& cq = p->convs[p->quad_conv];
+        const ConvL& cs = p->convs[p->sub_conv];
+        e.igemm(e.region_desc(cq, 2, QT_CONV_DGRAD), e.at(cq.gy), e.at(cq.w_dgrad), e.at(p->gbase_tmp), nullptr, nullptr,
+                resid, nullptr, nullptr, 0);
+        e.igemm(e.region_desc(cs, 4, QT_CONV_DGRAD), e.at(cs.gy), e.at(cs.w_dgrad), e.at(p->gbase_tmp2), nullptr, nullptr,
+                e.at(p->gbase_tmp), nullptr, nullptr, 0);
+        resid = e.at(p->gbase_tmp2);
+      }
+      if (bi == 6 && !p->standard && !p->attention) {
         const ConvL& cq = p->convs[p->quad_conv];
         e.igemm(e.quad_desc(QT_CONV_DGRAD), e.at(p->dq), e.at(cq.w_dgrad), e.at(p->gbase_tmp), nullptr, nullptr, resid,
                 nullptr, nullptr, 0);
@@ -1084,8 +1225,9 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
   QT_CHECK_ARG(desc->dtype == QT_F32 || desc->dtype == QT_BF16, "qt_plan_create: bad dtype %d", desc->dtype);
   QT_CHECK_ARG(desc->batch > 0 && desc->batch <= 4096, "qt_plan_create: batch %d out of range", desc->batch);
   QT_CHECK_ARG(desc->num_classes > 0 && desc->num_classes <= 4096, "qt_plan_create: bad num_classes");
-  QT_CHECK_ARG(desc->model == QT_MODEL_QUADTREE || desc->model == QT_MODEL_STANDARD_RESNET, "qt_plan_create: bad model");
-  QT_CHECK_ARG(desc->model == QT_MODEL_STANDARD_RESNET ||
+  QT_CHECK_ARG(desc->model == QT_MODEL_QUADTREE || desc->model == QT_MODEL_STANDARD_RESNET ||
+                   desc->model == QT_MODEL_ATTENTION, "qt_plan_create: bad model");
+  QT_CHECK_ARG(desc->model != QT_MODEL_QUADTREE ||
                    (desc->mode >= QT_MODE_FUSION && desc->mode <= QT_MODE_NUMERICAL_ONLY),
                "qt_plan_create: bad mode %d", desc->mode);
   QT_CHECK_ARG(desc->numerical_dim > 0 && desc->numerical_dim <= 1024, "qt_plan_create: bad numerical_dim");
@@ -1138,6 +1280,8 @@ extern "C" int qt_plan_find_buffer(const qt_plan* p, const char* name, size_t* o
   if (n == "fused") { *offset = p->fused; return QT_OK; }
   if (n == "dfused") { *offset = p->dfused; return QT_OK; }
   if (n == "hidden") { *offset = p->hidden; return QT_OK; }
+  if (p->attention && n == "attention.vectors") { *offset = p->vsub; return QT_OK; }   // f32 [B][16][64]
+  if (p->attention && n == "attention.weights") { *offset = p->att_alpha; return QT_OK; }  // f32 [B][16]
   if (n == "stem.pooled") { *offset = p->p0; return QT_OK; }
   if (n == "stem.gpooled") { *offset = p->g_p0; return QT_OK; }
   int b = blockno("block");

@@ -148,3 +148,6 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
 
 
 static inline int qt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// qt_conv_desc::quad: 0 = whole images, 1 or 2 = 2 x 2 regions per image, 4 = 4 x 4 regions
+static inline int qt_quad_split(int quad) { return quad == 1 ? 2 : quad; }
+static inline int qt_quad_regions(int quad) { return quad ? qt_quad_split(quad) * qt_quad_split(quad) : 1; }

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import QtError
 
-QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET = 0, 1
+QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET, QT_MODEL_ATTENTION = 0, 1, 2
 MODES = {"fusion": 0, "image_only": 1, "numerical_only": 2}
 QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_LAYER32, QT_BWD_LAYER1, QT_BWD_ALL = 1, 2, 4, 8, 15
 
@@ -87,6 +87,8 @@ class PlanEngine:
         self.num_classes = num_classes
         if model_kind == QT_MODEL_STANDARD_RESNET:
             self.fused_ld = 512
+        elif model_kind == QT_MODEL_ATTENTION:
+            self.fused_ld = 512 + 4 * 128 + 64 + 128
         else:
             self.fused_ld = {"fusion": 5376, "image_only": 5120, "numerical_only": 256}.get(mode, 5376)
         desc = PlanDesc(_lib.qt_dtype(dtype), self.max_batch, num_classes, model_kind, MODES.get(mode, 0),

@@ -5,6 +5,7 @@ keys, forward signature, train()/eval() semantics) of
   QuadtreeCNN        /root/reference/Quadtree_from scratch/models.py:214-305
                      /root/reference/resnet/models.py:70-180   (`mode`, frozen backbone)
   StandardResNetCNN  /root/reference/resnet/models.py:7-65
+  AttentionHierarchicalCNN  /root/reference/Quadtree_from scratch/models.py:6-101
 """
 import torch
 import torch.nn as nn
@@ -62,15 +63,19 @@ class _PlanModel(nn.Module):
         self._engine.grad_sync = self._grad_sync
         return self._engine
 
+    def _plan_name(self, name):
+        """state_dict key of this module -> name of the tensor in the plan's table"""
+        return name
+
     def _bind(self, eng):
-        tensors = dict(self.named_parameters())
-        tensors.update(dict(self.named_buffers()))
+        tensors = {self._plan_name(n): t for n, t in self.named_parameters()}
+        tensors.update({self._plan_name(n): t for n, t in self.named_buffers()})
         eng.bind(tensors)
         if self._param_list is None:
             named = list(self.named_parameters())
             self._param_list = [p for _, p in named]
             self._param_plan_index = [
-                -1 if n.startswith("base_cnn.fc.") else eng.index.get(n, -1) for n, _ in named]
+                -1 if n.startswith("base_cnn.fc.") else eng.index.get(self._plan_name(n), -1) for n, _ in named]
         return sum(p._version for p in self._param_list)
 
     # ---- Grad-CAM compatibility (reference: resnet/grad_cam_analysis.py:251-259,286,306-316;
@@ -83,6 +88,8 @@ class _PlanModel(nn.Module):
         return t.float().view(batch, 7, 7, 512).permute(0, 3, 1, 2).contiguous()
 
     def _fire_layer4_forward_hooks(self, engine, batch):
+        if not hasattr(self, "base_cnn"):
+            return
         layer4 = self.base_cnn.layer4
         if not layer4._forward_hooks or self._plan_mode() == "numerical_only":
             return
@@ -96,6 +103,8 @@ class _PlanModel(nn.Module):
         return t.float().view(batch, 14, 14, 256).permute(0, 3, 1, 2).contiguous()
 
     def _fire_layer4_backward_hooks(self, engine, batch):
+        if not hasattr(self, "base_cnn"):
+            return
         layer4 = self.base_cnn.layer4
         if not layer4._backward_hooks or self._plan_mode() == "numerical_only":
             return
@@ -224,3 +233,50 @@ class StandardResNetCNN(_PlanModel):
 
     def forward(self, image_input, numerical_input=None):  # numerical_input is ignored (resnet/models.py:56)
         return self._run(image_input, None)
+
+
+class AttentionHierarchicalCNN(_PlanModel):
+    """/root/reference/Quadtree_from scratch/models.py:6-101: features to layer2 (28x28x128), global branch
+    layer3 + layer4 + avgpool, a conv+ReLU+mean head on the 4 quadrants (14x14) and on the 16 sub-quadrants
+    (7x7), an attention gate (64 -> 32 -> 1, softmax over the 16) that blends the sub-quadrant vectors, a
+    one-layer numerical MLP and a 1216 -> 1024 -> C classifier.  As in the reference the ResNet is a local of
+    __init__ (:11): there is no `base_cnn` attribute and the state_dict has 134 keys under
+    features_extractor.{0,1,4,5}, global_processor.{0,1}, quadrant_processor.0, sub_quadrant_processor.0,
+    attention_gate.{0,2}, numerical_mlp.0, classifier.{0,3}."""
+    _model_kind = _engine.QT_MODEL_ATTENTION
+    _PLAN_PREFIX = (("features_extractor.0.", "base_cnn.conv1."), ("features_extractor.1.", "base_cnn.bn1."),
+                    ("features_extractor.4.", "base_cnn.layer1."), ("features_extractor.5.", "base_cnn.layer2."),
+                    ("global_processor.0.", "base_cnn.layer3."), ("global_processor.1.", "base_cnn.layer4."))
+
+    def __init__(self, num_classes, numerical_feature_dim=47, dropout_rate=0.5, compute_dtype=None, max_batch=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.numerical_feature_dim = numerical_feature_dim
+        self.dropout_rate = dropout_rate
+        base_cnn = M.ResNet18()
+        M.load_pretrained_resnet18(base_cnn)
+        b = base_cnn
+        self.features_extractor = nn.Sequential(b.conv1, b.bn1, b.relu, b.maxpool, b.layer1, b.layer2)
+        base_feature_channels = 128
+        self.global_processor = nn.Sequential(b.layer3, b.layer4, b.avgpool)
+        self.quadrant_processor = nn.Sequential(
+            M.Conv2d(base_feature_channels, 128, 3, padding=1), M.ReLU(inplace=True), M.AdaptiveAvgPool2d((1, 1)))
+        self.sub_quadrant_processor = nn.Sequential(
+            M.Conv2d(base_feature_channels, 64, 3, padding=1), M.ReLU(inplace=True), M.AdaptiveAvgPool2d((1, 1)))
+        self.attention_gate = nn.Sequential(M.Linear(64, 32), M.ReLU(), M.Linear(32, 1))
+        total_image_feature_dim = 512 + 4 * 128 + 64
+        self.numerical_mlp = nn.Sequential(M.Linear(numerical_feature_dim, 128), M.ReLU(inplace=True),
+                                           M.Dropout(dropout_rate))
+        combined_feature_dim = total_image_feature_dim + 128
+        self.classifier = nn.Sequential(M.Linear(combined_feature_dim, 1024), M.ReLU(inplace=True),
+                                        M.Dropout(dropout_rate), M.Linear(1024, num_classes))
+        self._init_plan_state(compute_dtype, max_batch)
+
+    def _plan_name(self, name):
+        for mine, plan in self._PLAN_PREFIX:
+            if name.startswith(mine):
+                return plan + name[len(mine):]
+        return name
+
+    def forward(self, image_input, numerical_input):
+        return self._run(image_input, numerical_input)

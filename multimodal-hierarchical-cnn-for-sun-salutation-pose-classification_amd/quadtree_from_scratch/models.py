@@ -33,10 +33,11 @@ class HierarchicalQuadtreeCNN:
                            "models.py:182,196 -> RuntimeError in forward); not provided")
 
 
-class AttentionHierarchicalCNN:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("AttentionHierarchicalCNN (reference models.py:6-101) is outside the accelerated "
-                                  "hot path of this round (SURVEY.md 8f rank 2)")
+class AttentionHierarchicalCNN(_impl.AttentionHierarchicalCNN):
+    """reference models.py:6-101: same constructor, state_dict keys and forward"""
+
+    def __init__(self, num_classes, numerical_feature_dim=47, dropout_rate=0.5, **kw):
+        super().__init__(num_classes, numerical_feature_dim, dropout_rate, **kw)
 
 
 class StandardMultimodalCNN:
@@ -52,7 +53,7 @@ def get_model(model_name, num_classes, device, print_num_params=True):
     elif model_name == 'hierarchical_quadtree':
         model = HierarchicalQuadtreeCNN(num_classes=num_classes)
     elif model_name == 'attention_hierarchical':
-        model = AttentionHierarchicalCNN(num_classes=num_classes)
+        model = AttentionHierarchicalCNN(num_classes=num_classes).to(device)
     else:
         model = StandardMultimodalCNN(backbone_name=model_name, num_classes=num_classes).to(device)
     if print_num_params:

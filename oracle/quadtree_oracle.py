@@ -24,6 +24,8 @@ What each function follows:
   numerical MLP         Quadtree_from scratch/models.py:255-260,297
   classifier            Quadtree_from scratch/models.py:266-271,303; resnet/models.py:115-129
   StandardResNetCNN     resnet/models.py:7-65
+  AttentionHierarchicalCNN  Quadtree_from scratch/models.py:6-101 (attention_forward; its state_dict has no
+                        base_cnn.* keys, see attention_sd_to_base)
 """
 import torch
 import torch.nn.functional as F
@@ -137,6 +139,62 @@ def standard_resnet_forward(sd, image, train=False, dropout_p=0.5, masks=None, t
     return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
 
 
+_ATTN_PREFIX = (("features_extractor.0.", "base_cnn.conv1."), ("features_extractor.1.", "base_cnn.bn1."),
+                ("features_extractor.4.", "base_cnn.layer1."), ("features_extractor.5.", "base_cnn.layer2."),
+                ("global_processor.0.", "base_cnn.layer3."), ("global_processor.1.", "base_cnn.layer4."))
+
+
+def attention_sd_to_base(sd):
+    """AttentionHierarchicalCNN keeps its ResNet-18 as a local of __init__ (models.py:11), so its state_dict
+    names the layers features_extractor.{0,1,4,5}.* / global_processor.{0,1}.*; rename them to the base_cnn.*
+    names the shared ResNet helpers of this file use.  Tensors are shared, not copied."""
+    out = {}
+    for k, v in sd.items():
+        for mine, base in _ATTN_PREFIX:
+            if k.startswith(mine):
+                k = base + k[len(mine):]
+                break
+        out[k] = v
+    return out
+
+
+def attention_forward(sd, image, numerical, train=False, dropout_p=0.5, masks=None, taps=None):
+    """logits[B,C] of AttentionHierarchicalCNN (Quadtree_from scratch/models.py:57-101); `sd` uses base_cnn.*
+    names (attention_sd_to_base)."""
+    x = F.conv2d(image, sd["base_cnn.conv1.weight"], None, 2, 3)
+    x = F.max_pool2d(F.relu(_bn(sd, "base_cnn.bn1", x, train)), 3, 2, 1)
+    x = _layer(sd, "layer1", x, 1, train)
+    base = _layer(sd, "layer2", x, 2, train)                                  # :58  [B,128,28,28]
+    g = _layer(sd, "layer4", _layer(sd, "layer3", base, 2, train), 2, train)  # :61
+    g = F.adaptive_avg_pool2d(g, (1, 1)).flatten(1)
+
+    def split4(t):                                                            # :63-68, :72-77
+        h, w = t.shape[2] // 2, t.shape[3] // 2
+        return [t[:, :, :h, :w], t[:, :, :h, w:], t[:, :, h:, :w], t[:, :, h:, w:]]
+
+    def head(t, name):                                                        # :21-30
+        y = F.relu(F.conv2d(t, sd[name + ".0.weight"], sd[name + ".0.bias"], 1, 1))
+        return F.adaptive_avg_pool2d(y, (1, 1)).flatten(1)
+
+    quads = split4(base)
+    qf = [head(q, "quadrant_processor") for q in quads]                       # :69
+    subs = [head(sq, "sub_quadrant_processor") for q in quads for sq in split4(q)]  # :72-78
+    stacked = torch.stack(subs, dim=1)                                        # :81  [B,16,64]
+    a = F.relu(F.linear(stacked, sd["attention_gate.0.weight"], sd["attention_gate.0.bias"]))
+    scores = F.linear(a, sd["attention_gate.2.weight"], sd["attention_gate.2.bias"]).squeeze(-1)  # :85
+    weights = F.softmax(scores, dim=1).unsqueeze(-1)                          # :87
+    attended = torch.sum(stacked * weights, dim=1)                            # :89
+    img = torch.cat([g] + qf + [attended], dim=1)                             # :92-93
+    z = F.relu(F.linear(numerical, sd["numerical_mlp.0.weight"], sd["numerical_mlp.0.bias"]))
+    z = _dropout(z, dropout_p, train, masks, "numerical_mlp")                 # :96
+    fused = torch.cat((img, z), dim=1)
+    if taps is not None:
+        taps.update(layer2=base, sub_vectors=stacked, attention_weights=weights.squeeze(-1), fused=fused)
+    hdn = F.relu(F.linear(fused, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
+    return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
 def unique_params(sd, keys):
     """Leaf copies (requires_grad) for `keys`; other entries cloned plain.
     Aliased reference keys (features_extractor.*, global_processor.*) are not
@@ -144,6 +202,7 @@ def unique_params(sd, keys):
     out = {}
     for k, v in sd.items():
         if not (k.startswith("base_cnn.") or k.startswith("quadrant_processor.")
+                or k.startswith("sub_quadrant_processor.") or k.startswith("attention_gate.")
                 or k.startswith("numerical_mlp.") or k.startswith("classifier.")):
             continue
         t = v.detach().clone()
@@ -163,6 +222,7 @@ def trainable_keys(sd, frozen_backbone):
             if frozen_backbone or k.startswith("base_cnn.fc."):
                 continue
             keys.append(k)
-        elif k.split(".")[0] in ("quadrant_processor", "numerical_mlp", "classifier"):
+        elif k.split(".")[0] in ("quadrant_processor", "sub_quadrant_processor", "attention_gate", "numerical_mlp",
+                                 "classifier"):
             keys.append(k)
     return keys

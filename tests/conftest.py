@@ -22,3 +22,9 @@ def golden_eval():
 def golden_train():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "train_b4.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_attn():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "attn_b2.npz"))

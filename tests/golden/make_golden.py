@@ -13,7 +13,9 @@ checksums / strided samples, gradient checksums and the small gradients in
 full.  The 100 MB of weights and the inputs are regenerated from the rule on
 both sides and are not stored.
 
-Usage (from the repo root):  python tests/golden/make_golden.py
+Usage (from the repo root):  python tests/golden/make_golden.py            (eval_b2.npz, train_b4.npz)
+                             python tests/golden/make_golden.py attention  (attn_b2.npz: AttentionHierarchicalCNN,
+                                                                            Quadtree_from scratch/models.py:6-101)
 """
 import importlib
 import importlib.util
@@ -166,5 +168,64 @@ def main():
     print("train_b4.npz:", len(out), "arrays")
 
 
+def main_attention():
+    """AttentionHierarchicalCNN (reference Quadtree_from scratch/models.py:6-101), eval and dropout-free train step, B=2."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    qs = load_ref(os.path.join(REF, "Quadtree_from scratch", "models.py"), "ref_qs_models")
+    C, B = 12, 2
+    out = {}
+    m = qs.AttentionHierarchicalCNN(num_classes=C)
+    m.load_state_dict(synth.synth_state_dict(m))
+    out["meta/state_dict_keys"] = np.array(list(m.state_dict().keys()))
+    out["meta/param_names"] = np.array([n for n, _ in m.named_parameters()])
+    out["meta/trainable"] = np.int64(sum(p.numel() for p in m.parameters() if p.requires_grad))
+    images = synth.synth_images(B, salt=5)
+    feats = synth.synth_pose_features(B, salt=5, realistic=True)
+    labels = synth.synth_labels(B, C, salt=5)
+    taps = {}
+    def tap_layer2(_m, _i, o):
+        taps["layer2"] = o.detach()
+
+    def tap_gate(_m, i, o):
+        taps["sub_vectors"] = i[0].detach()
+        taps["attention_weights"] = torch.softmax(o.detach().squeeze(-1), dim=1)
+
+    def tap_fused(_m, i, _o):
+        taps["fused"] = i[0].detach()
+
+    hs = [m.features_extractor.register_forward_hook(tap_layer2), m.attention_gate.register_forward_hook(tap_gate),
+          m.classifier[0].register_forward_hook(tap_fused)]
+    m.eval()
+    with torch.no_grad():
+        logits = m(images, feats)
+    for h in hs:
+        h.remove()
+    out["eval/logits"] = logits.numpy()
+    for k, v in taps.items():
+        put(out, f"eval/tap/{k}", v)
+    m.train()
+    set_dropout_p(m, 0.0)
+    logits = m(images, feats)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out["train/logits"] = logits.detach().numpy()
+    out["train/loss"] = np.float64(loss.item())
+    names = []
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(name)
+            put(out, f"train/grad/{name}", p.grad)
+    out["train/grad_names"] = np.array(names)
+    for name, b in m.named_buffers():
+        if name.endswith(("running_mean", "running_var")):
+            put(out, f"train/buf/{name}", b, full_below=0)
+    np.savez_compressed(os.path.join(HERE, "attn_b2.npz"), **out)
+    print("attn_b2.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "attention":
+        main_attention()
+    else:
+        main()

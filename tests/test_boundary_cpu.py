@@ -29,6 +29,20 @@ def test_state_dict_layout_matches_reference(golden_eval):
     assert sum(p.numel() for p in m.parameters()) == 26_499_028
 
 
+def test_attention_model_state_dict_matches_reference(golden_attn):
+    """AttentionHierarchicalCNN (reference models.py:6-101): 134 keys, no base_cnn.* (the ResNet is a local)."""
+    P = pkg()
+    m = P.AttentionHierarchicalCNN(12)
+    assert list(m.state_dict().keys()) == list(golden_attn["meta/state_dict_keys"])
+    assert [n for n, _ in m.named_parameters()] == list(golden_attn["meta/param_names"])
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == int(golden_attn["meta/trainable"])
+    assert not hasattr(m, "base_cnn") and len(m.state_dict()) == 134
+    with pytest.raises(P.QtError):
+        m(torch.zeros(1, 3, 224, 224), torch.zeros(1, 47))
+    qs = _load_dropin("quadtree_from_scratch")
+    assert isinstance(qs.get_model("attention_hierarchical", 12, "cpu", print_num_params=False), P.AttentionHierarchicalCNN)
+
+
 def _load_dropin(sub):
     path = os.path.join(ROOT, PKG, sub, "models.py")
     spec = importlib.util.spec_from_file_location(f"dropin_{sub}", path)
@@ -112,12 +126,12 @@ def test_plan_tensor_table_matches_module_tree():
     eng = pkg("engine")
     L = pkg("_lib").lib()
     eng._bind_api(L)
-    for kind, model in ((0, P.QuadtreeCNN(12)), (1, P.StandardResNetCNN(12))):
+    for kind, model in ((0, P.QuadtreeCNN(12)), (1, P.StandardResNetCNN(12)), (2, P.AttentionHierarchicalCNN(12))):
         desc = eng.PlanDesc(1, 8, 12, kind, 0, 47, 0.5, 1e-5, 0.1)
         h = ctypes.c_void_p()
         assert L.qt_plan_create(ctypes.byref(desc), ctypes.byref(h)) == 0
-        tensors = dict(model.named_parameters())
-        tensors.update(dict(model.named_buffers()))
+        tensors = {model._plan_name(n): t for n, t in model.named_parameters()}
+        tensors.update({model._plan_name(n): t for n, t in model.named_buffers()})
         dims = (ctypes.c_int * 4)()
         n = L.qt_plan_num_tensors(h)
         names = set()

@@ -72,6 +72,42 @@ def test_oracle_train_step(case, frozen, golden_train):
             check_summary(sd[n], golden_train, f"{case}/buf/{n}", 1e-5)
 
 
+def test_oracle_attention_model(golden_attn):
+    """attention_forward against the reference's AttentionHierarchicalCNN (models.py:6-101): eval logits and
+    taps, then a dropout-free train step (logits, loss, every gradient, BatchNorm running statistics)."""
+    torch.set_num_threads(8)
+    P, synth = pkg(), pkg("synth")
+    B = 2
+    x, f, y = synth.synth_images(B, salt=5), synth.synth_pose_features(B, salt=5), synth.synth_labels(B, 12, salt=5)
+    sd_model = synth.synth_state_dict(P.AttentionHierarchicalCNN(12))
+    taps = {}
+    with torch.no_grad():
+        logits = o.attention_forward(o.attention_sd_to_base(sd_model), x, f, taps=taps)
+    assert rel_err(logits, golden_attn["eval/logits"]) <= TOL
+    for name in ("layer2", "sub_vectors", "attention_weights", "fused"):
+        check_summary(taps[name], golden_attn, f"eval/tap/{name}", TOL)
+    names = list(golden_attn["train/grad_names"])
+    leaves = {n: sd_model[n].clone().requires_grad_(True) for n in names}
+    sd = o.attention_sd_to_base({k: leaves.get(k, v.clone()) for k, v in sd_model.items()})
+    logits = o.attention_forward(sd, x, f, train=True, dropout_p=0.0)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    assert rel_err(logits.detach(), golden_attn["train/logits"]) <= TOL
+    assert abs(loss.item() - float(golden_attn["train/loss"])) <= 1e-4
+    for n in names:
+        smp, gold = summary(leaves[n].grad)["sample"], golden_attn[f"train/grad/{n}/sample"]
+        head = n.split(".")[0] in ("quadrant_processor", "sub_quadrant_processor", "attention_gate", "numerical_mlp", "classifier")
+        tol = 1e-4 if head else 5e-2  # an isolated ReLU may flip under another summation order (tests/test_model_gpu.py)
+        # attention_gate.2.bias: softmax is shift invariant, the gradient is rounding noise around zero
+        scale = max(float(np.abs(gold).max()), 1e-6 if n == "attention_gate.2.bias" else 1e-30)
+        assert float(np.abs(smp - gold).max()) <= tol * scale, n
+    for k in golden_attn.files:
+        if k.startswith("train/buf/") and k.endswith("/shape"):
+            n = k[len("train/buf/"):-len("/shape")]
+            base = next((b_ + n[len(m_):] for m_, b_ in o._ATTN_PREFIX if n.startswith(m_)), n)
+            check_summary(sd[base], golden_attn, f"train/buf/{n}", 1e-5)
+
+
 def test_numpy_float64_restatement_agrees_with_reference(golden_eval):
     """The torch-independent float64 restatement (oracle/numpy_ops.py) reproduces the reference's
     own logits: operator definitions, BatchNorm constants, pooling semantics and concat order
