@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE config 2: 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="quadtree", choices=["quadtree", "attention"],
+                    help="quadtree = QuadtreeCNN (BASELINE config 2/3, the headline); attention = AttentionHierarchicalCNN "
+                         "(reference models.py:6-101, SURVEY.md 8f rank 2) as a secondary line")
     ap.add_argument("--forward-only", action="store_true", help="time eval-mode forward instead of the train step")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="Adam(lr 1e-4, wd 1e-4) by the package's FusedAdam kernel (default) or torch.optim.Adam(fused=True)")
@@ -71,9 +74,16 @@ def cpu_baseline(args, num_classes=12):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("QTCNN_CPU_THREADS", "16"))))  # a 1-GPU box's CPU share is 16
     torch.set_num_threads(cores)
-    holder = P.QuadtreeCNN(num_classes)  # parameter tree only (CPU tensors), never called
-    sd0 = synth.synth_state_dict(holder)
-    keys = o.trainable_keys(sd0, False)
+    if args.model == "attention":
+        holder = P.AttentionHierarchicalCNN(num_classes)  # parameter tree only (CPU tensors), never called
+        sd0 = o.attention_sd_to_base(synth.synth_state_dict(holder))
+        keys = [k for k in o.trainable_keys(sd0, False)]
+        forward = o.attention_forward
+    else:
+        holder = P.QuadtreeCNN(num_classes)
+        sd0 = synth.synth_state_dict(holder)
+        keys = o.trainable_keys(sd0, False)
+        forward = o.quadtree_forward
     sd = o.unique_params(sd0, keys)
     params = [sd[k] for k in keys]
     opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-4)
@@ -85,7 +95,7 @@ def cpu_baseline(args, num_classes=12):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        logits = o.quadtree_forward(sd, x, f, train=True)
+        logits = forward(sd, x, f, train=True)
         torch.nn.functional.cross_entropy(logits, y).backward()
         opt.step()
 
@@ -130,7 +140,10 @@ def main():
     dp = importlib.import_module(PKG + ".dp")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     C, B = 12, args.batch
-    model = P.QuadtreeCNN(C, compute_dtype=dt, max_batch=B)
+    if args.model == "attention":
+        model = P.AttentionHierarchicalCNN(C, compute_dtype=dt, max_batch=B)
+    else:
+        model = P.QuadtreeCNN(C, compute_dtype=dt, max_batch=B)
     model.load_state_dict(synth.synth_state_dict(model))
     model = model.to(dev)
     if world > 1 or force_dist:
@@ -227,7 +240,7 @@ def main():
     # whole-step HBM traffic from the committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of the same
     # command, see scripts/collect_profiles.sh) against this run's step time
     hbm = None
-    if not args.forward_only and args.batch == 256 and args.dtype == "bf16":
+    if not args.forward_only and args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree":
         try:
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
@@ -246,14 +259,20 @@ def main():
     imgs = B * world * args.steps
     value = imgs / elapsed
     gflop_img = FWD_GFLOP_PER_IMAGE if args.forward_only else FWD_BWD_GFLOP_PER_IMAGE
+    name, what = "QuadtreeCNN", "QuadtreeCNN (ResNet-18 layer3, 2x2 split, 47-feat fusion) "
+    if args.model == "attention":
+        # 2*MAC of the 22 convs + 5 linears: ResNet-18 conv stack 3.6274 - fc, quadrant conv 784 px x 128x128x9,
+        # sub-quadrant conv 784 px x 128x64x9, classifier 1216x1024 + 1024x12; backward = 2 x forward - conv1's dgrad
+        gflop_img = 3.9765 if args.forward_only else 11.6936  # FlopCounterMode on the oracle
+        name, what = "AttentionHierarchicalCNN", "AttentionHierarchicalCNN (ResNet-18 layer2 split 2x2 + 4x4, attention gate) "
     out = {
-        "metric": "images/sec fwd QuadtreeCNN 224x224" if args.forward_only
-        else "images/sec fwd+bwd QuadtreeCNN 224x224 bs256",
+        "metric": f"images/sec fwd {name} 224x224" if args.forward_only
+        else f"images/sec fwd+bwd {name} 224x224 bs256",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic (randn images / pose vectors resident in HBM, deterministic synthetic weights)",
-        "config": {"workload": "QuadtreeCNN (ResNet-18 layer3, 2x2 split, 47-feat fusion) "
+        "config": {"workload": what
                                + ("eval forward" if args.forward_only else
                                   "train step fwd+bwd+Adam, all parameters trainable; Adam(lr 1e-4, wd 1e-4) by "
                                   + ("the package's FusedAdam (csrc/pack.hip)" if args.optimizer == "fused"
