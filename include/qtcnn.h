@@ -290,6 +290,22 @@ int qt_attention_gate_bwd(int dtype, const void* d, const float* v, const float*
                           const float* w2, float* ds, float* dpre, float* dv, int batch, int ld, int col0, void* stream);
 int qt_relu_mask_cols(int dtype, const void* d, const void* act, float* out, long long rows, int cols, int ld, int col0,
                       float mul, void* stream);
+/* nn.LSTM recurrence (cnn+lstm/models.py:43-49,81-86; batch_first, one direction, f32, torch gate order i,f,g,o).
+ * qt_lstm_forward: xproj [B][T][4H] = x_t W_ih^T + b_ih for every step (a thin product done by the caller; b_hh
+ *   [4H], nullable, is added here),
+ *   whh_t = W_hh^T [H][4H] (qt_transpose_f32) -> gates [B][T][4H] (post-activation), cell / hprev / hout [B][T][H]
+ *   (hprev = h_{t-1}, zeros at t = 0).  One launch, one workgroup per sequence; H in {256, 64}.
+ * qt_lstm_backward: dhout [B][T][H] (gradient w.r.t. every h_t, nullable) + dlast [B][H] (w.r.t. h_{T-1}, nullable)
+ *   -> dgates [B][T][4H] w.r.t. the pre-activation gates; then dx = dgates W_ih, dW_ih = dgates^T x,
+ *   dW_hh = dgates^T hprev, db_ih = db_hh = column sums (qt_gemm_small / qt_col_sum).  whh = W_hh [4H][H].
+ * qt_scale_by_nonzero: g = x != 0 ? g*mul : 0 -- backward of the dropout between LSTM layers from the dropped
+ *   activations themselves. */
+int qt_lstm_forward(const float* xproj, const float* whh_t, const float* bhh, float* gates, float* cell, float* hprev,
+                    float* hout, int batch, int T, int H, void* stream);
+int qt_lstm_backward(const float* dhout, const float* dlast, const float* gates, const float* cell, const float* whh,
+                     float* dgates, int batch, int T, int H, void* stream);
+int qt_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
+int qt_scale_by_nonzero(float* g, const float* x, long long n, float mul, void* stream);
 /* nn.Dropout (Quadtree_from scratch/models.py:258,269), in place, counter-hash RNG */
 int qt_dropout(int dtype, void* x, long long rows, int cols, int ld, unsigned long long seed, float p, void* stream);
 /* g = act > 0 ? g*mul : 0 (ReLU / dropout backward from the forward output) */
@@ -333,6 +349,10 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *                             ignored; tensors are listed under base_cnn.* names for the ResNet part (the
  *                             reference keeps it as a local: bind features_extractor.{0,1,4,5} /
  *                             global_processor.{0,1} to base_cnn.{conv1,bn1,layer1,layer2} / {layer3,layer4})
+ *   QT_MODEL_CNN_LSTM         CnnLstm (cnn+lstm/models.py:14-89): `batch` counts FRAMES (sequences x seq_len); the
+ *                             frozen per-frame ResNet-18 (bind cnn_backbone.{0,1,4,5,6,7} to base_cnn.{conv1,bn1,
+ *                             layer1..4}) + Linear-ReLU-Linear on the pose vector feed a 2-layer LSTM over seq_len
+ *                             steps; logits [batch / seq_len][num_classes].  Gradients: MLP, LSTM, classifier.
  * The tensor table lists every parameter / buffer under the reference's
  * state_dict key (first-seen `base_cnn.*` names); the caller
  * passes one device pointer per entry (f32, reference layouts: OIHW conv
@@ -351,7 +371,7 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *                          (lets the caller start the gradient all-reduce of a bucket while the
  *                          next phase runs; the last bucket is 0.6 MB).
  * ------------------------------------------------------------------------ */
-enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1, QT_MODEL_ATTENTION = 2 };
+enum { QT_MODEL_QUADTREE = 0, QT_MODEL_STANDARD_RESNET = 1, QT_MODEL_ATTENTION = 2, QT_MODEL_CNN_LSTM = 3 };
 enum { QT_MODE_FUSION = 0, QT_MODE_IMAGE_ONLY = 1, QT_MODE_NUMERICAL_ONLY = 2 };
 /* call order HEAD, LAYER4, LAYER32, LAYER1 (or any union of consecutive phases in one call);
  * QT_BWD_REST = LAYER32 | LAYER1, QT_BWD_BACKBONE = LAYER4 | REST. */
@@ -368,6 +388,8 @@ typedef struct qt_plan_desc {
   float dropout_p;    /* 0.5 */
   float bn_eps;       /* 1e-5 */
   float bn_momentum;  /* 0.1 */
+  int seq_len;        /* QT_MODEL_CNN_LSTM: frames per sequence (reference default 4) */
+  int lstm_hidden;    /* QT_MODEL_CNN_LSTM: 256 */
 } qt_plan_desc;
 
 typedef struct qt_plan qt_plan;

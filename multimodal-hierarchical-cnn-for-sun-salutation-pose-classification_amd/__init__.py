@@ -8,6 +8,6 @@ reference's `from models import get_model`.
 """
 from ._lib import LIB_PATH, QtError  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
-from .quadtree import AttentionHierarchicalCNN, QuadtreeCNN, StandardResNetCNN  # noqa: F401
+from .quadtree import AttentionHierarchicalCNN, CnnLstm, QuadtreeCNN, StandardResNetCNN  # noqa: F401
 
-__all__ = ["QuadtreeCNN", "StandardResNetCNN", "AttentionHierarchicalCNN", "FusedAdam", "QtError", "LIB_PATH"]
+__all__ = ["QuadtreeCNN", "StandardResNetCNN", "AttentionHierarchicalCNN", "CnnLstm", "FusedAdam", "QtError", "LIB_PATH"]

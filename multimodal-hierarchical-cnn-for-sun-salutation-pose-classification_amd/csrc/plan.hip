@@ -11,6 +11,8 @@
 //   /root/reference/resnet/models.py:7-65,70-180              (StandardResNetCNN, modes)
 //   /root/reference/Quadtree_from scratch/models.py:6-101    (AttentionHierarchicalCNN: split after layer2,
 //                                                             quadrant + sub-quadrant heads, attention gate)
+//   /root/reference/cnn+lstm/models.py:14-89                 (CnnLstm: frozen per-frame ResNet-18, pose MLP,
+//                                                             2-layer LSTM over the sequence, classifier)
 // and torchvision's ResNet-18 BasicBlock wiring.
 #include <stdlib.h>
 #include <string.h>
@@ -75,6 +77,14 @@ struct qt_plan {
   LinL mlp0{}, mlp1{}, cls0{}, cls3{}, att0{}, att2{};
   // attention head (AttentionHierarchicalCNN): sub-quadrant vectors [B][16][64] f32 and what the gate's backward needs
   size_t vsub = 0, dvsub = 0, att_act = 0, att_alpha = 0, att_ds = 0, att_dpre = 0, gbase_tmp2 = 0;
+  // CnnLstm: nn.LSTM layers (all f32); `batch` counts frames, sequences = frames / seq_len
+  bool lstm = false;
+  int seq_len = 0, lstm_h = 0;
+  struct LstmL {
+    int w_ih, w_hh, b_ih, b_hh, in;
+    size_t whh_t, xproj, gates, cell, hprev, hout, dgates;
+  } lstm_l[2];
+  size_t lstm_x1 = 0, lstm_dx1 = 0, lstm_dlast = 0, lstm_hid = 0, lstm_dhid = 0, lstm_dz = 0;
   int fused_ld = 0, img_cols = 0, mlp_col0 = 0, hidden_dim = 0;
   // workspace offsets
   size_t ws_bytes = 0;
@@ -159,8 +169,12 @@ void build_graph(qt_plan* p) {
   const qt_plan_desc& d = p->d;
   p->standard = d.model == QT_MODEL_STANDARD_RESNET;
   p->attention = d.model == QT_MODEL_ATTENTION;
+  p->lstm = d.model == QT_MODEL_CNN_LSTM;
+  if (p->lstm) p->standard = true;  // the per-frame branch is the ResNet-18 up to avgpool, no quadrant head
+  p->seq_len = d.seq_len;
+  p->lstm_h = d.lstm_hidden;
   p->has_image = p->standard || p->attention || d.mode != QT_MODE_NUMERICAL_ONLY;
-  p->has_numerical = p->attention || (!p->standard && d.mode != QT_MODE_IMAGE_ONLY);
+  p->has_numerical = p->attention || p->lstm || (!p->standard && d.mode != QT_MODE_IMAGE_ONLY);
   // ---- backbone (always present in the tensor table: state_dict parity) ----
   {
     const int w = p->add_tensor("base_cnn.conv1.weight", 0, {64, 3, 7, 7});
@@ -206,7 +220,7 @@ void build_graph(qt_plan* p) {
       cin = cout;
     }
   }
-  if (!p->attention) {  // (the attention model keeps its ResNet as a local: no fc in its state_dict, models.py:11)
+  if (!p->attention && !p->lstm) {  // (those models drop / never register the ResNet's fc: models.py:11, cnn+lstm/models.py:23)
     p->add_tensor("base_cnn.fc.weight", 0, {1000, 512});  // present in the state_dict, never used
     p->add_tensor("base_cnn.fc.bias", 0, {1000});
   }
@@ -230,6 +244,27 @@ void build_graph(qt_plan* p) {
     p->img_cols = 512 + 4 * 1152;
     p->fused_ld = (p->has_image ? p->img_cols : 0) + (p->has_numerical ? 256 : 0);
     p->mlp_col0 = p->has_image ? p->img_cols : 0;
+  } else if (p->lstm) {
+    // cnn+lstm/models.py:31-56: MLP 47 -> 128 -> 128, LSTM(640 -> H, 2 layers), classifier H -> 128 -> C
+    const int H = p->lstm_h;
+    p->mlp0 = p->add_linear("numerical_mlp.0", d.numerical_dim, 128);
+    p->mlp1 = p->add_linear("numerical_mlp.2", 128, 128);
+    p->img_cols = 512;
+    p->fused_ld = 512 + 128;
+    p->mlp_col0 = 512;
+    for (int l = 0; l < 2; ++l) {
+      qt_plan::LstmL& L = p->lstm_l[l];
+      const std::string sfx = "_l" + std::to_string(l);
+      L.in = l == 0 ? p->fused_ld : H;
+      L.w_ih = p->add_tensor("lstm.weight_ih" + sfx, 0, {4 * H, L.in});
+      L.w_hh = p->add_tensor("lstm.weight_hh" + sfx, 0, {4 * H, H});
+      L.b_ih = p->add_tensor("lstm.bias_ih" + sfx, 0, {4 * H});
+      L.b_hh = p->add_tensor("lstm.bias_hh" + sfx, 0, {4 * H});
+    }
+    p->hidden_dim = 128;
+    p->cls0 = p->add_linear("classifier.0", H, 128);
+    p->cls3 = p->add_linear("classifier.3", 128, d.num_classes);
+    return;
   } else {
     p->img_cols = 512;
     p->fused_ld = 512;
@@ -335,6 +370,27 @@ void layout_workspace(qt_plan* p) {
     p->dq = p->convs[p->quad_conv].gy;
     p->h1 = ws.take(B * p->mlp0.out * 4);
     p->dh1 = ws.take(B * p->mlp0.out * 4);
+  }
+  if (p->lstm) {
+    const size_t H = (size_t)p->lstm_h;
+    p->h1 = ws.take(B * p->mlp0.out * 4);
+    p->dh1 = ws.take(B * p->mlp0.out * 4);
+    for (int l = 0; l < 2; ++l) {
+      qt_plan::LstmL& L = p->lstm_l[l];
+      L.whh_t = ws.take(H * 4 * H * 4);
+      L.xproj = ws.take(B * 4 * H * 4);
+      L.gates = ws.take(B * 4 * H * 4);
+      L.dgates = ws.take(B * 4 * H * 4);
+      L.cell = ws.take(B * H * 4);
+      L.hprev = ws.take(B * H * 4);
+      L.hout = ws.take(B * H * 4);
+    }
+    p->lstm_x1 = ws.take(B * H * 4);
+    p->lstm_dx1 = ws.take(B * H * 4);
+    p->lstm_dlast = ws.take(B * H * 4);
+    p->lstm_hid = ws.take(B * 128 * 4);
+    p->lstm_dhid = ws.take(B * 128 * 4);
+    p->lstm_dz = ws.take(B * 128 * 4);
   }
   p->fused = ws.take(B * p->fused_ld * es);
   p->dfused = ws.take(B * p->fused_ld * es);
@@ -594,8 +650,9 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
         add(e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2);
     }
   }
-  add(e.tf(p->cls0.w), e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1,
-      false);
+  if (!p->lstm)  // (CnnLstm's classifier is a thin f32 product: no packed copy)
+    add(e.tf(p->cls0.w), e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1,
+        false);
   for (size_t j = 0; j < items.size() && e.ok(); j += 32)
     e.run(qt_pack_weights_batched(e.dt, items.data() + j, (int)std::min<size_t>(32, items.size() - j), stream));
   return e.status;
@@ -636,8 +693,9 @@ int adam_step(qt_plan* p, void* workspace, void* const* T, float* const* G, floa
       const ConvL& c = p->convs[i];
       if (int st = add(c.w, e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2)) return st;
     }
-  if (int st = add(p->cls0.w, e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1, false))
-    return st;
+  if (!p->lstm)
+    if (int st = add(p->cls0.w, e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1, false))
+      return st;
   for (size_t i = 0; i < p->tensors.size(); ++i) {
     if (p->tensors[i].kind != 0 || fused[i] || !G[i]) continue;
     QT_CHECK_ARG(T[i] && M1[i] && M2[i], "qt_plan_adam_step: %s has a gradient but no parameter / optimizer state",
@@ -681,7 +739,7 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     g.a_row_stride = p->mlp0.in; g.a_k_stride = 1; g.b_row_stride = p->mlp0.in; g.b_k_stride = 1;
     g.c_row_stride = p->mlp0.out; g.relu = 1;
     e.run(qt_gemm_small(&g, numerical, e.tf(p->mlp0.w), e.tf(p->mlp0.b), e.at(p->h1), e.stream));
-    if (tr && p->d.dropout_p > 0.f)
+    if (tr && p->d.dropout_p > 0.f && !p->lstm)  // (CnnLstm's MLP has no dropout, cnn+lstm/models.py:32-36)
       e.run(qt_dropout(QT_F32, e.at(p->h1), batch, p->mlp0.out, p->mlp0.out, seed, p->d.dropout_p, e.stream));
     g.N = p->mlp1.out; g.K = p->mlp1.in;
     g.a_row_stride = p->mlp1.in; g.b_row_stride = p->mlp1.in; g.c_dtype = dt; g.c_row_stride = p->fused_ld; g.relu = 0;
@@ -811,8 +869,46 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     // ---- global branch: avgpool(layer4) -> fused[:, 0:512] ----
     e.run(qt_avgpool(dt, e.at(p->blocks[7].out), e.at(p->fused), batch, 49, 512, p->fused_ld, 0, stream));
   }
-  if (p->has_numerical && !p->has_image) mlp_branch();  // numerical_only: nothing to overlap with
+  if (p->has_numerical && (!p->has_image || p->lstm)) mlp_branch();  // numerical_only / CnnLstm: nothing to overlap with
   e.join();  // quadrant + MLP columns of the fused matrix are complete
+  if (p->lstm) {
+    // ---- cnn+lstm/models.py:76-89: [frames][640] -> 2-layer LSTM over seq_len steps -> last step -> classifier ----
+    const int T = p->seq_len, S = batch / T, H = p->lstm_h;
+    qt_gemm_small_desc g;
+    for (int l = 0; l < 2 && e.ok(); ++l) {
+      const qt_plan::LstmL& L = p->lstm_l[l];
+      memset(&g, 0, sizeof(g));
+      g.M = batch; g.N = 4 * H; g.K = L.in;
+      g.a_dtype = l == 0 ? dt : QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+      g.a_row_stride = L.in; g.a_k_stride = 1; g.b_row_stride = L.in; g.b_k_stride = 1; g.c_row_stride = 4 * H;
+      e.run(qt_gemm_small(&g, l == 0 ? e.at(p->fused) : e.at(p->lstm_x1), e.tf(L.w_ih), e.tf(L.b_ih), e.at(L.xproj), stream));
+      e.run(qt_transpose_f32(e.tf(L.w_hh), e.at<float>(L.whh_t), 4 * H, H, stream));
+      e.run(qt_lstm_forward(e.at<float>(L.xproj), e.at<float>(L.whh_t), e.tf(L.b_hh), e.at<float>(L.gates),
+                            e.at<float>(L.cell), e.at<float>(L.hprev), e.at<float>(L.hout), S, T, H, stream));
+      if (l == 0) {  // nn.LSTM's inter-layer dropout acts on layer 0's outputs only as layer 1's input
+        e.hip(hipMemcpyAsync(e.at(p->lstm_x1), e.at(L.hout), (size_t)batch * H * 4, hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+        if (tr && p->d.dropout_p > 0.f)
+          e.run(qt_dropout(QT_F32, e.at(p->lstm_x1), batch, H, H, seed ^ 0x3C3C3C3CC3C3C3C3ull, p->d.dropout_p, stream));
+      }
+    }
+    const float* last = e.at<float>(p->lstm_l[1].hout) + (size_t)(T - 1) * H;  // h_{T-1} of every sequence
+    memset(&g, 0, sizeof(g));
+    g.M = S; g.N = 128; g.K = H;
+    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+    g.a_row_stride = (long long)T * H; g.a_k_stride = 1; g.b_row_stride = H; g.b_k_stride = 1; g.c_row_stride = 128; g.relu = 1;
+    e.run(qt_gemm_small(&g, last, e.tf(p->cls0.w), e.tf(p->cls0.b), e.at(p->lstm_hid), stream));
+    if (tr && p->d.dropout_p > 0.f)
+      e.run(qt_dropout(QT_F32, e.at(p->lstm_hid), S, 128, 128, seed ^ 0xA5A5A5A55A5A5A5Aull, p->d.dropout_p, stream));
+    memset(&g, 0, sizeof(g));
+    g.M = S; g.N = p->cls3.out; g.K = 128;
+    g.a_dtype = QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
+    g.a_row_stride = 128; g.a_k_stride = 1; g.b_row_stride = 128; g.b_k_stride = 1; g.c_row_stride = p->cls3.out;
+    e.run(qt_gemm_small(&g, e.at(p->lstm_hid), e.tf(p->cls3.w), e.tf(p->cls3.b), logits, stream));
+    p->last_batch = batch;
+    p->last_training = training;
+    p->last_seed = seed;
+    return e.status;
+  }
   // ---- classifier: Linear -> ReLU -> Dropout -> Linear ----
   e.linear(e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD), e.at(p->fused), e.at(p->cls0.w_fwd), e.at(p->hidden),
            e.tf(p->cls0.b), 1);
@@ -962,6 +1058,58 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   if (backbone_grads && !tr) {
     qt_set_error("qt_plan_backward: backbone gradients in eval() mode are not implemented");
     return QT_ERR_UNSUPPORTED;
+  }
+  if (p->lstm) {
+    if (backbone_grads) {  // the reference freezes cnn_backbone (cnn+lstm/models.py:26-27)
+      qt_set_error("qt_plan_backward: CnnLstm keeps its ResNet-18 frozen; gradients through the LSTM into the backbone are not implemented");
+      return QT_ERR_UNSUPPORTED;
+    }
+    if (!(phases & QT_BWD_HEAD)) return QT_OK;
+    // ---- classifier -> last step -> LSTM layer 1 -> (dropout) -> LSTM layer 0 -> pose MLP; everything f32 and thin ----
+    const int T = p->seq_len, S = B / T, H = p->lstm_h;
+    qt_gemm_small_desc g;
+    auto gemm = [&](int M, int N, int K, const void* A, int adt, long long ars, long long aks, const void* Bm, int bdt,
+                    long long brs, long long bks, void* C, long long crs) {
+      memset(&g, 0, sizeof(g));
+      g.M = M; g.N = N; g.K = K; g.a_dtype = adt; g.b_dtype = bdt; g.c_dtype = QT_F32;
+      g.a_row_stride = ars; g.a_k_stride = aks; g.b_row_stride = brs; g.b_k_stride = bks; g.c_row_stride = crs;
+      if (C) e.run(qt_gemm_small(&g, A, Bm, nullptr, C, stream));
+    };
+    const float* last = e.at<float>(p->lstm_l[1].hout) + (size_t)(T - 1) * H;
+    float* dhid = e.at<float>(p->lstm_dhid);
+    gemm(S, 128, p->cls3.out, dlogits, QT_F32, p->cls3.out, 1, e.tf(p->cls3.w), QT_F32, 1, 128, dhid, 128);
+    e.run(qt_relu_mask_scale(QT_F32, dhid, e.at(p->lstm_hid), (long long)S * 128, drop_mul, stream));
+    if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, S, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, stream));
+    gemm(p->cls3.out, 128, S, dlogits, QT_F32, 1, p->cls3.out, e.at(p->lstm_hid), QT_F32, 1, 128, e.gf(p->cls3.w), 128);
+    if (e.gf(p->cls0.b)) e.run(qt_col_sum(QT_F32, dhid, S, 128, 128, e.gf(p->cls0.b), 0, stream));
+    gemm(128, H, S, dhid, QT_F32, 1, 128, last, QT_F32, 1, (long long)T * H, e.gf(p->cls0.w), H);
+    gemm(S, H, 128, dhid, QT_F32, 128, 1, e.tf(p->cls0.w), QT_F32, 1, H, e.at(p->lstm_dlast), H);
+    for (int l = 1; l >= 0 && e.ok(); --l) {
+      const qt_plan::LstmL& L = p->lstm_l[l];
+      e.run(qt_lstm_backward(l == 1 ? nullptr : e.at<float>(p->lstm_dx1), l == 1 ? e.at<float>(p->lstm_dlast) : nullptr,
+                             e.at<float>(L.gates), e.at<float>(L.cell), e.tf(L.w_hh), e.at<float>(L.dgates), S, T, H, stream));
+      const float* dG = e.at<float>(L.dgates);
+      const void* X = l == 0 ? e.at(p->fused) : e.at(p->lstm_x1);
+      gemm(4 * H, L.in, B, dG, QT_F32, 1, 4 * H, X, l == 0 ? dt : QT_F32, 1, L.in, e.gf(L.w_ih), L.in);
+      gemm(4 * H, H, B, dG, QT_F32, 1, 4 * H, e.at(L.hprev), QT_F32, 1, H, e.gf(L.w_hh), H);
+      if (e.gf(L.b_ih)) e.run(qt_col_sum(QT_F32, dG, B, 4 * H, 4 * H, e.gf(L.b_ih), 0, stream));
+      if (e.gf(L.b_hh)) e.run(qt_col_sum(QT_F32, dG, B, 4 * H, 4 * H, e.gf(L.b_hh), 0, stream));
+      if (l == 1) {
+        gemm(B, H, 4 * H, dG, QT_F32, 4 * H, 1, e.tf(L.w_ih), QT_F32, 1, H, e.at(p->lstm_dx1), H);
+        if (tr && p->d.dropout_p > 0.f)
+          e.run(qt_scale_by_nonzero(e.at<float>(p->lstm_dx1), e.at<float>(p->lstm_x1), (long long)B * H, drop_mul, stream));
+      } else {  // only the pose-MLP columns of the fused features have trainable producers
+        gemm(B, 128, 4 * H, dG, QT_F32, 4 * H, 1, e.tf(L.w_ih) + p->mlp_col0, QT_F32, 1, L.in, e.at(p->lstm_dz), 128);
+      }
+    }
+    const float* dz = e.at<float>(p->lstm_dz);
+    if (e.gf(p->mlp1.b)) e.run(qt_col_sum(QT_F32, dz, B, 128, 128, e.gf(p->mlp1.b), 0, stream));
+    gemm(128, 128, B, dz, QT_F32, 1, 128, e.at(p->h1), QT_F32, 1, 128, e.gf(p->mlp1.w), 128);
+    gemm(B, 128, 128, dz, QT_F32, 128, 1, e.tf(p->mlp1.w), QT_F32, 1, 128, e.at(p->dh1), 128);
+    e.run(qt_relu_mask_scale(QT_F32, e.at(p->dh1), e.at(p->h1), (long long)B * 128, 1.f, stream));
+    if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, 128, 128, e.gf(p->mlp0.b), 0, stream));
+    gemm(128, p->mlp0.in, B, e.at(p->dh1), QT_F32, 1, 128, numerical, QT_F32, 1, p->mlp0.in, e.gf(p->mlp0.w), p->mlp0.in);
+    return e.status;
   }
 
   if (phases & QT_BWD_HEAD) {
@@ -1226,7 +1374,11 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
   QT_CHECK_ARG(desc->batch > 0 && desc->batch <= 4096, "qt_plan_create: batch %d out of range", desc->batch);
   QT_CHECK_ARG(desc->num_classes > 0 && desc->num_classes <= 4096, "qt_plan_create: bad num_classes");
   QT_CHECK_ARG(desc->model == QT_MODEL_QUADTREE || desc->model == QT_MODEL_STANDARD_RESNET ||
-                   desc->model == QT_MODEL_ATTENTION, "qt_plan_create: bad model");
+                   desc->model == QT_MODEL_ATTENTION || desc->model == QT_MODEL_CNN_LSTM, "qt_plan_create: bad model");
+  QT_CHECK_ARG(desc->model != QT_MODEL_CNN_LSTM ||
+                   (desc->seq_len > 0 && desc->batch % desc->seq_len == 0 && (desc->lstm_hidden == 256 || desc->lstm_hidden == 64)),
+               "qt_plan_create: CnnLstm needs seq_len > 0 dividing batch (frames) and lstm_hidden 256 or 64 (got %d, %d)",
+               desc->seq_len, desc->lstm_hidden);
   QT_CHECK_ARG(desc->model != QT_MODEL_QUADTREE ||
                    (desc->mode >= QT_MODE_FUSION && desc->mode <= QT_MODE_NUMERICAL_ONLY),
                "qt_plan_create: bad mode %d", desc->mode);
@@ -1378,6 +1530,7 @@ extern "C" int qt_plan_forward(qt_plan* p, void* workspace, void* const* tensors
                                unsigned long long seed, void* stream) {
   QT_CHECK_ARG(p && workspace && tensors && logits, "qt_plan_forward: null argument");
   QT_CHECK_ARG(batch > 0 && batch <= p->d.batch, "qt_plan_forward: batch %d exceeds the plan's %d", batch, p->d.batch);
+  QT_CHECK_ARG(!p->lstm || batch % p->seq_len == 0, "qt_plan_forward: %d frames are not whole sequences of %d", batch, p->seq_len);
   QT_CHECK_ARG(!p->has_image || image, "qt_plan_forward: image required");
   QT_CHECK_ARG(!p->has_numerical || numerical, "qt_plan_forward: numerical input required");
   QT_CHECK_ARG(((uintptr_t)workspace % 256) == 0, "qt_plan_forward: workspace must be 256-byte aligned");

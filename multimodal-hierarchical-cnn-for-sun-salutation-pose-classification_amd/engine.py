@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import QtError
 
-QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET, QT_MODEL_ATTENTION = 0, 1, 2
+QT_MODEL_QUADTREE, QT_MODEL_STANDARD_RESNET, QT_MODEL_ATTENTION, QT_MODEL_CNN_LSTM = 0, 1, 2, 3
 MODES = {"fusion": 0, "image_only": 1, "numerical_only": 2}
 QT_BWD_HEAD, QT_BWD_LAYER4, QT_BWD_LAYER32, QT_BWD_LAYER1, QT_BWD_ALL = 1, 2, 4, 8, 15
 
@@ -23,6 +23,7 @@ class PlanDesc(ctypes.Structure):
         ("dtype", ctypes.c_int), ("batch", ctypes.c_int), ("num_classes", ctypes.c_int),
         ("model", ctypes.c_int), ("mode", ctypes.c_int), ("numerical_dim", ctypes.c_int),
         ("dropout_p", ctypes.c_float), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float),
+        ("seq_len", ctypes.c_int), ("lstm_hidden", ctypes.c_int),
     ]
 
 
@@ -76,7 +77,8 @@ def _bind_api(L):
 class PlanEngine:
     """One qt_plan + its workspace for one (model variant, device, dtype, max batch)."""
 
-    def __init__(self, model_kind, mode, num_classes, numerical_dim, dropout_p, batch, dtype, device):
+    def __init__(self, model_kind, mode, num_classes, numerical_dim, dropout_p, batch, dtype, device, seq_len=0,
+                 lstm_hidden=0):
         self.L = _lib.lib()
         _bind_api(self.L)
         self.device = torch.device(device)
@@ -89,10 +91,13 @@ class PlanEngine:
             self.fused_ld = 512
         elif model_kind == QT_MODEL_ATTENTION:
             self.fused_ld = 512 + 4 * 128 + 64 + 128
+        elif model_kind == QT_MODEL_CNN_LSTM:
+            self.fused_ld = 512 + 128
         else:
             self.fused_ld = {"fusion": 5376, "image_only": 5120, "numerical_only": 256}.get(mode, 5376)
+        self.rows_per_logit = int(seq_len) if model_kind == QT_MODEL_CNN_LSTM else 1
         desc = PlanDesc(_lib.qt_dtype(dtype), self.max_batch, num_classes, model_kind, MODES.get(mode, 0),
-                        numerical_dim, float(dropout_p), 1e-5, 0.1)
+                        numerical_dim, float(dropout_p), 1e-5, 0.1, int(seq_len), int(lstm_hidden))
         handle = ctypes.c_void_p()
         _lib.check(self.L.qt_plan_create(ctypes.byref(desc), ctypes.byref(handle)), "qt_plan_create")
         self.handle = handle
@@ -202,7 +207,7 @@ class PlanEngine:
     # -- execution --------------------------------------------------------------
     def forward(self, image, numerical, training, seed):
         batch = int(image.shape[0]) if image is not None else int(numerical.shape[0])
-        logits = torch.empty(batch, self.num_classes, dtype=torch.float32, device=self.device)
+        logits = torch.empty(batch // self.rows_per_logit, self.num_classes, dtype=torch.float32, device=self.device)
         _lib.check(self.L.qt_plan_forward(self.handle, self.ws_ptr, self._tensor_ptrs,
                                           _lib.ptr(image), _lib.ptr(numerical), _lib.ptr(logits), batch,
                                           int(training), ctypes.c_ulonglong(seed), _lib.stream_ptr()),

@@ -74,6 +74,28 @@ class Linear(_Leaf):
         return f"in_features={self.in_features}, out_features={self.out_features}"
 
 
+class LSTM(_Leaf):
+    """Parameter holder with torch.nn.LSTM's names and order: weight_ih_l{k}, weight_hh_l{k}, bias_ih_l{k},
+    bias_hh_l{k} per layer; gate rows i, f, g, o; uniform(-1/sqrt(hidden), 1/sqrt(hidden)) initialisation."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, batch_first=False, dropout=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.batch_first, self.dropout = batch_first, dropout
+        bound = 1.0 / math.sqrt(hidden_size)
+        for k in range(num_layers):
+            shapes = (("weight_ih", (4 * hidden_size, input_size if k == 0 else hidden_size)),
+                      ("weight_hh", (4 * hidden_size, hidden_size)), ("bias_ih", (4 * hidden_size,)),
+                      ("bias_hh", (4 * hidden_size,)))
+            for name, shape in shapes:
+                p = nn.Parameter(torch.empty(*shape))
+                nn.init.uniform_(p, -bound, bound)
+                setattr(self, f"{name}_l{k}", p)
+
+    def extra_repr(self):
+        return f"{self.input_size}, {self.hidden_size}, num_layers={self.num_layers}, batch_first={self.batch_first}"
+
+
 class ReLU(_Leaf):
     def __init__(self, inplace=False):
         super().__init__()

@@ -6,6 +6,7 @@ keys, forward signature, train()/eval() semantics) of
                      /root/reference/resnet/models.py:70-180   (`mode`, frozen backbone)
   StandardResNetCNN  /root/reference/resnet/models.py:7-65
   AttentionHierarchicalCNN  /root/reference/Quadtree_from scratch/models.py:6-101
+  CnnLstm            /root/reference/cnn+lstm/models.py:14-89
 """
 import torch
 import torch.nn as nn
@@ -57,7 +58,7 @@ class _PlanModel(nn.Module):
         self._engine = None  # free the old workspace first
         self._engine = _engine.PlanEngine(self._model_kind, self._plan_mode(), self.num_classes,
                                           self.numerical_feature_dim, self.dropout_rate, cap,
-                                          self.compute_dtype, device)
+                                          self.compute_dtype, device, **self._plan_extra())
         self._engine_key = key
         self._param_list = None
         self._engine.grad_sync = self._grad_sync
@@ -66,6 +67,9 @@ class _PlanModel(nn.Module):
     def _plan_name(self, name):
         """state_dict key of this module -> name of the tensor in the plan's table"""
         return name
+
+    def _plan_extra(self):
+        return {}
 
     def _bind(self, eng):
         tensors = {self._plan_name(n): t for n, t in self.named_parameters()}
@@ -280,3 +284,63 @@ class AttentionHierarchicalCNN(_PlanModel):
 
     def forward(self, image_input, numerical_input):
         return self._run(image_input, numerical_input)
+
+
+class CnnLstm(_PlanModel):
+    """/root/reference/cnn+lstm/models.py:14-89: a frozen ResNet-18 (children()[:-1], i.e. up to avgpool) on every
+    frame, Linear(47,128)-ReLU-Linear(128,128) on every pose vector, the two concatenated per time step into a
+    2-layer LSTM (640 -> hidden, batch_first, dropout between layers), the last step's output into
+    Linear(hidden,128)-ReLU-Dropout-Linear(128,C).  forward(image_sequence [B,T,3,224,224],
+    numerical_sequence [B,T,47]) -> logits [B,C].  state_dict: cnn_backbone.{0,1,4,5,6,7}.*, numerical_mlp.{0,2}.*,
+    lstm.{weight,bias}_{ih,hh}_l{0,1}, classifier.{0,3}.*."""
+    _model_kind = _engine.QT_MODEL_CNN_LSTM
+    _PLAN_PREFIX = (("cnn_backbone.0.", "base_cnn.conv1."), ("cnn_backbone.1.", "base_cnn.bn1."),
+                    ("cnn_backbone.4.", "base_cnn.layer1."), ("cnn_backbone.5.", "base_cnn.layer2."),
+                    ("cnn_backbone.6.", "base_cnn.layer3."), ("cnn_backbone.7.", "base_cnn.layer4."))
+
+    def __init__(self, num_classes, sequence_length=4, numerical_feature_dim=47, dropout_rate=0.5, lstm_hidden_size=256,
+                 compute_dtype=None, max_batch=None):
+        super().__init__()
+        if lstm_hidden_size not in (256, 64):
+            raise ValueError("the gfx950 LSTM kernel is instantiated for lstm_hidden_size 256 (reference default) and 64")
+        self.sequence_length = sequence_length
+        self.num_classes = num_classes
+        self.numerical_feature_dim = numerical_feature_dim
+        self.dropout_rate = dropout_rate
+        self.lstm_hidden_size = lstm_hidden_size
+        resnet = M.ResNet18()
+        M.load_pretrained_resnet18(resnet)
+        self.cnn_backbone = nn.Sequential(*list(resnet.children())[:-1])
+        for param in self.cnn_backbone.parameters():
+            param.requires_grad = False
+        self.numerical_mlp = nn.Sequential(M.Linear(numerical_feature_dim, 128), M.ReLU(), M.Linear(128, 128))
+        self.lstm = M.LSTM(512 + 128, lstm_hidden_size, num_layers=2, batch_first=True, dropout=dropout_rate)
+        self.classifier = nn.Sequential(M.Linear(lstm_hidden_size, 128), M.ReLU(), M.Dropout(dropout_rate),
+                                        M.Linear(128, num_classes))
+        self._seq_len_bound = None
+        self._init_plan_state(compute_dtype, max_batch)
+
+    def _plan_name(self, name):
+        for mine, plan in self._PLAN_PREFIX:
+            if name.startswith(mine):
+                return plan + name[len(mine):]
+        return name
+
+    def _plan_extra(self):
+        return {"seq_len": self._seq_len_bound, "lstm_hidden": self.lstm_hidden_size}
+
+    def forward(self, image_sequence, numerical_sequence):
+        if image_sequence.dim() != 5 or numerical_sequence.dim() != 3:
+            raise ValueError("expected image_sequence [B,T,3,224,224] and numerical_sequence [B,T,F], got "
+                             f"{tuple(image_sequence.shape)} and {tuple(numerical_sequence.shape)}")
+        batch_size, seq_len = int(image_sequence.shape[0]), int(image_sequence.shape[1])
+        if tuple(numerical_sequence.shape[:2]) != (batch_size, seq_len):
+            raise ValueError("image_sequence and numerical_sequence disagree on [B,T]")
+        if self._seq_len_bound != seq_len:  # the plan is laid out for whole sequences of one length
+            self._seq_len_bound = seq_len
+            self._engine = None
+        if self._max_batch_hint and self._max_batch_hint % seq_len:
+            self._max_batch_hint = (self._max_batch_hint // seq_len + 1) * seq_len
+        frames = image_sequence.reshape(batch_size * seq_len, *image_sequence.shape[2:])
+        poses = numerical_sequence.reshape(batch_size * seq_len, numerical_sequence.shape[2])
+        return self._run(frames, poses)

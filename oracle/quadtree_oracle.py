@@ -26,6 +26,9 @@ What each function follows:
   StandardResNetCNN     resnet/models.py:7-65
   AttentionHierarchicalCNN  Quadtree_from scratch/models.py:6-101 (attention_forward; its state_dict has no
                         base_cnn.* keys, see attention_sd_to_base)
+  CnnLstm               cnn+lstm/models.py:14-89 (cnn_lstm_forward; keys via cnn_lstm_sd_to_base); the LSTM
+                        cell is written out gate by gate (torch.nn.LSTM semantics: gate rows i,f,g,o,
+                        c' = f*c + i*g, h' = o*tanh(c'), dropout on layer 0's outputs as layer 1's input)
 """
 import torch
 import torch.nn.functional as F
@@ -195,6 +198,62 @@ def attention_forward(sd, image, numerical, train=False, dropout_p=0.5, masks=No
     return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
 
 
+_LSTM_PREFIX = (("cnn_backbone.0.", "base_cnn.conv1."), ("cnn_backbone.1.", "base_cnn.bn1."),
+                ("cnn_backbone.4.", "base_cnn.layer1."), ("cnn_backbone.5.", "base_cnn.layer2."),
+                ("cnn_backbone.6.", "base_cnn.layer3."), ("cnn_backbone.7.", "base_cnn.layer4."))
+
+
+def cnn_lstm_sd_to_base(sd):
+    """CnnLstm names its ResNet-18 layers cnn_backbone.{0,1,4,5,6,7}.* (nn.Sequential of resnet.children()[:-1],
+    cnn+lstm/models.py:23); rename to the base_cnn.* names used by the shared helpers."""
+    out = {}
+    for k, v in sd.items():
+        for mine, base in _LSTM_PREFIX:
+            if k.startswith(mine):
+                k = base + k[len(mine):]
+                break
+        out[k] = v
+    return out
+
+
+def _lstm_layer(sd, layer, x):
+    """one nn.LSTM layer, batch_first, zero initial state: x [B,T,I] -> [B,T,H]"""
+    w_ih, w_hh = sd[f"lstm.weight_ih_l{layer}"], sd[f"lstm.weight_hh_l{layer}"]
+    b_ih, b_hh = sd[f"lstm.bias_ih_l{layer}"], sd[f"lstm.bias_hh_l{layer}"]
+    B, T, H = x.shape[0], x.shape[1], w_hh.shape[1]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    outs = []
+    for t in range(T):
+        gates = F.linear(x[:, t], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+        i, f, g, o = gates.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def cnn_lstm_forward(sd, image_sequence, numerical_sequence, train=False, dropout_p=0.5, masks=None, taps=None):
+    """logits[B,C] of CnnLstm (cnn+lstm/models.py:58-89); `sd` uses base_cnn.* names (cnn_lstm_sd_to_base).
+    train=True: the frozen backbone's BatchNorms still use (and update) batch statistics, as model.train() does."""
+    B, T = image_sequence.shape[0], image_sequence.shape[1]
+    frames = image_sequence.reshape(B * T, *image_sequence.shape[2:])                     # :65
+    base = features_to_layer3(sd, frames, train)
+    g = _layer(sd, "layer4", base, 2, train)
+    c_out = F.adaptive_avg_pool2d(g, (1, 1)).flatten(1).view(B, T, -1)                   # :68-69
+    z = F.relu(F.linear(numerical_sequence, sd["numerical_mlp.0.weight"], sd["numerical_mlp.0.bias"]))
+    n_out = F.linear(z, sd["numerical_mlp.2.weight"], sd["numerical_mlp.2.bias"])        # :73
+    fused = torch.cat((c_out, n_out), dim=2)                                              # :77
+    h0 = _lstm_layer(sd, 0, fused)
+    h1 = _lstm_layer(sd, 1, _dropout(h0, dropout_p, train, masks, "lstm"))                # :81 (nn.LSTM dropout=)
+    final = h1[:, -1, :]                                                                  # :84
+    if taps is not None:
+        taps.update(fused=fused, lstm_out=h1)
+    hdn = F.relu(F.linear(final, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
+    return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
 def unique_params(sd, keys):
     """Leaf copies (requires_grad) for `keys`; other entries cloned plain.
     Aliased reference keys (features_extractor.*, global_processor.*) are not
@@ -202,7 +261,7 @@ def unique_params(sd, keys):
     out = {}
     for k, v in sd.items():
         if not (k.startswith("base_cnn.") or k.startswith("quadrant_processor.")
-                or k.startswith("sub_quadrant_processor.") or k.startswith("attention_gate.")
+                or k.startswith("sub_quadrant_processor.") or k.startswith("attention_gate.") or k.startswith("lstm.")
                 or k.startswith("numerical_mlp.") or k.startswith("classifier.")):
             continue
         t = v.detach().clone()

@@ -28,3 +28,9 @@ def golden_train():
 def golden_attn():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "attn_b2.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_cnn_lstm():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "cnn_lstm_b2t3.npz"))

@@ -16,6 +16,8 @@ both sides and are not stored.
 Usage (from the repo root):  python tests/golden/make_golden.py            (eval_b2.npz, train_b4.npz)
                              python tests/golden/make_golden.py attention  (attn_b2.npz: AttentionHierarchicalCNN,
                                                                             Quadtree_from scratch/models.py:6-101)
+                             python tests/golden/make_golden.py cnn_lstm   (cnn_lstm_b2t3.npz: CnnLstm,
+                                                                            cnn+lstm/models.py:14-89)
 """
 import importlib
 import importlib.util
@@ -224,8 +226,60 @@ def main_attention():
     print("attn_b2.npz:", len(out), "arrays")
 
 
+def main_cnn_lstm():
+    """CnnLstm (reference cnn+lstm/models.py:14-89): 2 sequences of 3 frames, eval and dropout-free train step."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cl = load_ref(os.path.join(REF, "cnn+lstm", "models.py"), "ref_cl_models")
+    C, B, T = 12, 2, 3
+    out = {}
+    m = cl.CnnLstm(num_classes=C, sequence_length=T)
+    m.load_state_dict(synth.synth_state_dict(m))
+    out["meta/state_dict_keys"] = np.array(list(m.state_dict().keys()))
+    out["meta/param_names"] = np.array([n for n, _ in m.named_parameters()])
+    out["meta/trainable"] = np.int64(sum(p.numel() for p in m.parameters() if p.requires_grad))
+    images = synth.synth_images(B * T, salt=7).view(B, T, 3, 224, 224)
+    feats = synth.synth_pose_features(B * T, salt=7, realistic=True).view(B, T, 47)
+    labels = synth.synth_labels(B, C, salt=7)
+    taps = {}
+
+    def tap_lstm(_m, i, o):
+        taps["fused"] = i[0].detach()
+        taps["lstm_out"] = o[0].detach()
+
+    h = m.lstm.register_forward_hook(tap_lstm)
+    m.eval()
+    with torch.no_grad():
+        logits = m(images, feats)
+    h.remove()
+    out["eval/logits"] = logits.numpy()
+    for k, v in taps.items():
+        put(out, f"eval/tap/{k}", v)
+    m.train()
+    set_dropout_p(m, 0.0)
+    m.lstm.dropout = 0.0
+    logits = m(images, feats)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out["train/logits"] = logits.detach().numpy()
+    out["train/loss"] = np.float64(loss.item())
+    names = []
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(name)
+            put(out, f"train/grad/{name}", p.grad)
+    out["train/grad_names"] = np.array(names)
+    for name, b in m.named_buffers():
+        if name.endswith(("running_mean", "running_var")):
+            put(out, f"train/buf/{name}", b, full_below=0)
+    np.savez_compressed(os.path.join(HERE, "cnn_lstm_b2t3.npz"), **out)
+    print("cnn_lstm_b2t3.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "attention":
         main_attention()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cnn_lstm":
+        main_cnn_lstm()
     else:
         main()

@@ -43,6 +43,24 @@ def test_attention_model_state_dict_matches_reference(golden_attn):
     assert isinstance(qs.get_model("attention_hierarchical", 12, "cpu", print_num_params=False), P.AttentionHierarchicalCNN)
 
 
+def test_cnn_lstm_state_dict_matches_reference(golden_cnn_lstm):
+    """CnnLstm (reference cnn+lstm/models.py:14-89): cnn_backbone.* / numerical_mlp / lstm.* / classifier keys."""
+    P = pkg()
+    m = P.CnnLstm(12, sequence_length=3)
+    assert list(m.state_dict().keys()) == list(golden_cnn_lstm["meta/state_dict_keys"])
+    assert [n for n, _ in m.named_parameters()] == list(golden_cnn_lstm["meta/param_names"])
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == int(golden_cnn_lstm["meta/trainable"])
+    assert not any(p.requires_grad for p in m.cnn_backbone.parameters())
+    with pytest.raises(P.QtError):
+        m(torch.zeros(1, 3, 3, 224, 224), torch.zeros(1, 3, 47))
+    with pytest.raises(ValueError):
+        m(torch.zeros(3, 3, 224, 224), torch.zeros(3, 47))
+    cl = _load_dropin("cnn_lstm")
+    assert isinstance(cl.get_model("cnn_lstm", 12, "cpu", seq_len=4), P.CnnLstm)
+    with pytest.raises(ValueError):
+        cl.get_model("bogus", 12, "cpu")
+
+
 def _load_dropin(sub):
     path = os.path.join(ROOT, PKG, sub, "models.py")
     spec = importlib.util.spec_from_file_location(f"dropin_{sub}", path)
@@ -126,8 +144,9 @@ def test_plan_tensor_table_matches_module_tree():
     eng = pkg("engine")
     L = pkg("_lib").lib()
     eng._bind_api(L)
-    for kind, model in ((0, P.QuadtreeCNN(12)), (1, P.StandardResNetCNN(12)), (2, P.AttentionHierarchicalCNN(12))):
-        desc = eng.PlanDesc(1, 8, 12, kind, 0, 47, 0.5, 1e-5, 0.1)
+    for kind, model in ((0, P.QuadtreeCNN(12)), (1, P.StandardResNetCNN(12)), (2, P.AttentionHierarchicalCNN(12)),
+                        (3, P.CnnLstm(12))):
+        desc = eng.PlanDesc(1, 8, 12, kind, 0, 47, 0.5, 1e-5, 0.1, 4, 256)
         h = ctypes.c_void_p()
         assert L.qt_plan_create(ctypes.byref(desc), ctypes.byref(h)) == 0
         tensors = {model._plan_name(n): t for n, t in model.named_parameters()}

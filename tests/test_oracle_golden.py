@@ -108,6 +108,42 @@ def test_oracle_attention_model(golden_attn):
             check_summary(sd[base], golden_attn, f"train/buf/{n}", 1e-5)
 
 
+def test_oracle_cnn_lstm(golden_cnn_lstm):
+    """cnn_lstm_forward (LSTM cell written out gate by gate) against the reference's CnnLstm with torch's nn.LSTM
+    (cnn+lstm/models.py:14-89): eval logits and taps, then a dropout-free train step with every gradient."""
+    torch.set_num_threads(8)
+    P, synth = pkg(), pkg("synth")
+    g = golden_cnn_lstm
+    B, T = 2, 3
+    x = synth.synth_images(B * T, salt=7).view(B, T, 3, 224, 224)
+    f = synth.synth_pose_features(B * T, salt=7).view(B, T, 47)
+    y = synth.synth_labels(B, 12, salt=7)
+    sd_model = synth.synth_state_dict(P.CnnLstm(12, sequence_length=T))
+    taps = {}
+    with torch.no_grad():
+        logits = o.cnn_lstm_forward(o.cnn_lstm_sd_to_base(sd_model), x, f, taps=taps)
+    assert rel_err(logits, g["eval/logits"]) <= TOL
+    for name in ("fused", "lstm_out"):
+        check_summary(taps[name], g, f"eval/tap/{name}", TOL)
+    names = list(g["train/grad_names"])
+    leaves = {n: sd_model[n].clone().requires_grad_(True) for n in names}
+    sd = o.cnn_lstm_sd_to_base({k: leaves.get(k, v.clone()) for k, v in sd_model.items()})
+    logits = o.cnn_lstm_forward(sd, x, f, train=True, dropout_p=0.0)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    assert rel_err(logits.detach(), g["train/logits"]) <= TOL
+    assert abs(loss.item() - float(g["train/loss"])) <= 1e-4
+    assert sorted(names) == sorted(n for n in sd_model if n.split(".")[0] in ("numerical_mlp", "lstm", "classifier"))
+    for n in names:
+        smp, gold = summary(leaves[n].grad)["sample"], g[f"train/grad/{n}/sample"]
+        assert float(np.abs(smp - gold).max()) <= 1e-4 * max(float(np.abs(gold).max()), 1e-30), n
+    for k in g.files:
+        if k.startswith("train/buf/") and k.endswith("/shape"):
+            n = k[len("train/buf/"):-len("/shape")]
+            base = next((b_ + n[len(m_):] for m_, b_ in o._LSTM_PREFIX if n.startswith(m_)), n)
+            check_summary(sd[base], g, f"train/buf/{n}", 1e-5)
+
+
 def test_numpy_float64_restatement_agrees_with_reference(golden_eval):
     """The torch-independent float64 restatement (oracle/numpy_ops.py) reproduces the reference's
     own logits: operator definitions, BatchNorm constants, pooling semantics and concat order
