@@ -51,9 +51,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE config 2: 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--model", default="quadtree", choices=["quadtree", "attention"],
+    ap.add_argument("--seq-len", type=int, default=16, help="--model cnn_lstm: frames per sequence (BASELINE config 5: 16)")
+    ap.add_argument("--model", default="quadtree", choices=["quadtree", "attention", "cnn_lstm"],
                     help="quadtree = QuadtreeCNN (BASELINE config 2/3, the headline); attention = AttentionHierarchicalCNN "
-                         "(reference models.py:6-101, SURVEY.md 8f rank 2) as a secondary line")
+                         "(reference models.py:6-101, SURVEY.md 8f rank 2), cnn_lstm = CnnLstm (cnn+lstm/models.py:14-89, "
+                         "rank 3; --batch counts FRAMES per GPU) as secondary lines")
     ap.add_argument("--forward-only", action="store_true", help="time eval-mode forward instead of the train step")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="Adam(lr 1e-4, wd 1e-4) by the package's FusedAdam kernel (default) or torch.optim.Adam(fused=True)")
@@ -74,6 +76,27 @@ def cpu_baseline(args, num_classes=12):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("QTCNN_CPU_THREADS", "16"))))  # a 1-GPU box's CPU share is 16
     torch.set_num_threads(cores)
+    if args.model == "cnn_lstm":
+        T = args.seq_len
+        holder = P.CnnLstm(num_classes, sequence_length=T)
+        sd0 = o.cnn_lstm_sd_to_base(synth.synth_state_dict(holder))
+        keys = [k for k in sd0 if k.split(".")[0] in ("numerical_mlp", "lstm", "classifier")]  # frozen backbone
+        sd = o.unique_params(sd0, keys)
+        opt = torch.optim.Adam([sd[k] for k in keys], lr=1e-4)
+        S = max(1, args.cpu_batch // T)
+        g = torch.Generator().manual_seed(1234)
+        x, f = torch.randn(S, T, 3, 224, 224, generator=g), torch.randn(S, T, 47, generator=g)
+        y = torch.randint(0, num_classes, (S,), generator=g)
+        iters, t0 = 0, time.perf_counter()
+        while iters < 2 or (time.perf_counter() - t0 < 8.0 and iters < 20):
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(o.cnn_lstm_forward(sd, x, f, train=True), y).backward()
+            opt.step()
+            iters += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(S * T * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"{iters} train steps of {S} sequences x {T} frames, torch {torch.__version__} CPU fp32, "
+                          f"oracle/quadtree_oracle.py::cnn_lstm_forward"}
     if args.model == "attention":
         holder = P.AttentionHierarchicalCNN(num_classes)  # parameter tree only (CPU tensors), never called
         sd0 = o.attention_sd_to_base(synth.synth_state_dict(holder))
@@ -140,7 +163,11 @@ def main():
     dp = importlib.import_module(PKG + ".dp")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     C, B = 12, args.batch
-    if args.model == "attention":
+    if args.model == "cnn_lstm":
+        if B % args.seq_len:
+            raise SystemExit("--batch (frames) must be a multiple of --seq-len")
+        model = P.CnnLstm(C, sequence_length=args.seq_len, compute_dtype=dt, max_batch=B)
+    elif args.model == "attention":
         model = P.AttentionHierarchicalCNN(C, compute_dtype=dt, max_batch=B)
     else:
         model = P.QuadtreeCNN(C, compute_dtype=dt, max_batch=B)
@@ -148,7 +175,10 @@ def main():
     model = model.to(dev)
     if world > 1 or force_dist:
         dp.attach_data_parallel(model)
-    if args.optimizer == "fused":
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    if args.model == "cnn_lstm":
+        opt = P.FusedAdam(trainable, lr=1e-4, model=model)  # cnn+lstm/training.py:93: Adam(lr 1e-4), no weight decay
+    elif args.optimizer == "fused":
         # the package's Adam: same update rule, run inside the one-launch weight re-packing (csrc/pack.hip)
         opt = P.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-4, model=model)
     else:
@@ -158,6 +188,9 @@ def main():
     images = torch.randn(B, 3, 224, 224, device=dev, generator=g)
     feats = torch.randn(B, 47, device=dev, generator=g)
     labels = torch.randint(0, C, (B,), device=dev, generator=g)
+    if args.model == "cnn_lstm":
+        S, T = B // args.seq_len, args.seq_len
+        images, feats, labels = images.view(S, T, 3, 224, 224), feats.view(S, T, 47), labels[:S].contiguous()
 
     if args.forward_only:
         model.eval()
@@ -265,6 +298,13 @@ def main():
         # sub-quadrant conv 784 px x 128x64x9, classifier 1216x1024 + 1024x12; backward = 2 x forward - conv1's dgrad
         gflop_img = 3.9765 if args.forward_only else 11.6936  # FlopCounterMode on the oracle
         name, what = "AttentionHierarchicalCNN", "AttentionHierarchicalCNN (ResNet-18 layer2 split 2x2 + 4x4, attention gate) "
+    if args.model == "cnn_lstm":
+        # per frame: ResNet-18 conv stack 3.6269 (forward only: the backbone is frozen) + LSTM / MLP / head ~0.004 forward,
+        # x3 with their backward
+        gflop_img = 3.6311 if args.forward_only else 3.6395
+        name = "CnnLstm"
+        what = (f"CnnLstm ({B // args.seq_len} sequences x {args.seq_len} frames per GPU, frozen per-frame ResNet-18 + pose MLP "
+                "+ 2-layer LSTM(640->256) + classifier), images = frames; ")
     out = {
         "metric": f"images/sec fwd {name} 224x224" if args.forward_only
         else f"images/sec fwd+bwd {name} 224x224 bs256",

@@ -306,6 +306,8 @@ int qt_lstm_backward(const float* dhout, const float* dlast, const float* gates,
                      float* dgates, int batch, int T, int H, void* stream);
 int qt_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
 int qt_scale_by_nonzero(float* g, const float* x, long long n, float mul, void* stream);
+/* dst[i] = (float)src[i] (src of type `dtype`): f32 copy of the fused per-frame features for the f32 LSTM products */
+int qt_cast_f32(int dtype, const void* src, float* dst, long long n, void* stream);
 /* nn.Dropout (Quadtree_from scratch/models.py:258,269), in place, counter-hash RNG */
 int qt_dropout(int dtype, void* x, long long rows, int cols, int ld, unsigned long long seed, float p, void* stream);
 /* g = act > 0 ? g*mul : 0 (ReLU / dropout backward from the forward output) */

@@ -82,8 +82,9 @@ struct qt_plan {
   int seq_len = 0, lstm_h = 0;
   struct LstmL {
     int w_ih, w_hh, b_ih, b_hh, in;
-    size_t whh_t, xproj, gates, cell, hprev, hout, dgates;
+    size_t whh_t, wih_t, xproj, gates, cell, hprev, hout, dgates;
   } lstm_l[2];
+  size_t lstm_x0 = 0;  // f32 copy of the fused features (bf16 build)
   size_t lstm_x1 = 0, lstm_dx1 = 0, lstm_dlast = 0, lstm_hid = 0, lstm_dhid = 0, lstm_dz = 0;
   int fused_ld = 0, img_cols = 0, mlp_col0 = 0, hidden_dim = 0;
   // workspace offsets
@@ -378,6 +379,7 @@ void layout_workspace(qt_plan* p) {
     for (int l = 0; l < 2; ++l) {
       qt_plan::LstmL& L = p->lstm_l[l];
       L.whh_t = ws.take(H * 4 * H * 4);
+      L.wih_t = ws.take((size_t)L.in * 4 * H * 4);
       L.xproj = ws.take(B * 4 * H * 4);
       L.gates = ws.take(B * 4 * H * 4);
       L.dgates = ws.take(B * 4 * H * 4);
@@ -385,6 +387,7 @@ void layout_workspace(qt_plan* p) {
       L.hprev = ws.take(B * H * 4);
       L.hout = ws.take(B * H * 4);
     }
+    p->lstm_x0 = ws.take(B * p->fused_ld * 4);
     p->lstm_x1 = ws.take(B * H * 4);
     p->lstm_dx1 = ws.take(B * H * 4);
     p->lstm_dlast = ws.take(B * H * 4);
@@ -524,6 +527,15 @@ struct Exec {
       d.out_h = d.out_w = S * c.hin; d.k_per_tap = c.cout; d.n_out = c.cin;
       d.src_pix_stride = c.cout; d.src_row_stride = c.hin * c.cout; d.src_img_stride = (long long)c.hin * c.hin * c.cout;
     }
+    return d;
+  }
+  // y [rows][out] = x [rows][in] W^T (W [out][in]) as a 1x1 convolution on 1x1 images, f32 MFMA whatever the plan's dtype
+  qt_conv_desc dense_f32(int rows, int in, int out) const {
+    qt_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = QT_F32; d.mode = QT_CONV_FWD; d.batch = rows; d.in_h = d.in_w = d.out_h = d.out_w = 1;
+    d.kh = d.kw = 1; d.stride = 1; d.pad = 0;
+    d.k_per_tap = in; d.n_out = out; d.src_pix_stride = in; d.src_row_stride = in; d.src_img_stride = in;
     return d;
   }
   qt_conv_desc linear_desc(int in, int out, int mode) const {
@@ -877,11 +889,10 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     qt_gemm_small_desc g;
     for (int l = 0; l < 2 && e.ok(); ++l) {
       const qt_plan::LstmL& L = p->lstm_l[l];
-      memset(&g, 0, sizeof(g));
-      g.M = batch; g.N = 4 * H; g.K = L.in;
-      g.a_dtype = l == 0 ? dt : QT_F32; g.b_dtype = QT_F32; g.c_dtype = QT_F32;
-      g.a_row_stride = L.in; g.a_k_stride = 1; g.b_row_stride = L.in; g.b_k_stride = 1; g.c_row_stride = 4 * H;
-      e.run(qt_gemm_small(&g, l == 0 ? e.at(p->fused) : e.at(p->lstm_x1), e.tf(L.w_ih), e.tf(L.b_ih), e.at(L.xproj), stream));
+      // x W_ih^T + b_ih for all frames at once on the f32 MFMA path (W_ih [4H][in] is already the operand layout)
+      if (l == 0) e.run(qt_cast_f32(dt, e.at(p->fused), e.at<float>(p->lstm_x0), (long long)batch * L.in, stream));
+      e.igemm(e.dense_f32(batch, L.in, 4 * H), l == 0 ? e.at(p->lstm_x0) : e.at(p->lstm_x1), e.tf(L.w_ih), e.at(L.xproj),
+              nullptr, e.tf(L.b_ih), nullptr, nullptr, nullptr, 0);
       e.run(qt_transpose_f32(e.tf(L.w_hh), e.at<float>(L.whh_t), 4 * H, H, stream));
       e.run(qt_lstm_forward(e.at<float>(L.xproj), e.at<float>(L.whh_t), e.tf(L.b_hh), e.at<float>(L.gates),
                             e.at<float>(L.cell), e.at<float>(L.hprev), e.at<float>(L.hout), S, T, H, stream));
@@ -1089,17 +1100,25 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       e.run(qt_lstm_backward(l == 1 ? nullptr : e.at<float>(p->lstm_dx1), l == 1 ? e.at<float>(p->lstm_dlast) : nullptr,
                              e.at<float>(L.gates), e.at<float>(L.cell), e.tf(L.w_hh), e.at<float>(L.dgates), S, T, H, stream));
       const float* dG = e.at<float>(L.dgates);
-      const void* X = l == 0 ? e.at(p->fused) : e.at(p->lstm_x1);
-      gemm(4 * H, L.in, B, dG, QT_F32, 1, 4 * H, X, l == 0 ? dt : QT_F32, 1, L.in, e.gf(L.w_ih), L.in);
-      gemm(4 * H, H, B, dG, QT_F32, 1, 4 * H, e.at(L.hprev), QT_F32, 1, H, e.gf(L.w_hh), H);
+      // dW_ih = dgates^T x, dW_hh = dgates^T h_prev: weight-gradient kernel (f32 MFMA), contraction over the frames
+      auto wgrad_dense = [&](const void* X, int in, float* dw) {
+        if (!dw || !e.ok()) return;
+        const qt_conv_desc wd = e.dense_f32(B, in, 4 * H);
+        e.run(zero(dw, (size_t)4 * H * in * 4, stream));
+        e.run(qt_conv2d_wgrad(&wd, dG, X, dw, stream));
+      };
+      wgrad_dense(l == 0 ? e.at(p->lstm_x0) : e.at(p->lstm_x1), L.in, e.gf(L.w_ih));
+      wgrad_dense(e.at(L.hprev), H, e.gf(L.w_hh));
+      e.run(qt_transpose_f32(e.tf(L.w_ih), e.at<float>(L.wih_t), 4 * H, L.in, stream));  // [in][4H]: operand of dx
       if (e.gf(L.b_ih)) e.run(qt_col_sum(QT_F32, dG, B, 4 * H, 4 * H, e.gf(L.b_ih), 0, stream));
       if (e.gf(L.b_hh)) e.run(qt_col_sum(QT_F32, dG, B, 4 * H, 4 * H, e.gf(L.b_hh), 0, stream));
       if (l == 1) {
-        gemm(B, H, 4 * H, dG, QT_F32, 4 * H, 1, e.tf(L.w_ih), QT_F32, 1, H, e.at(p->lstm_dx1), H);
+        e.igemm(e.dense_f32(B, 4 * H, H), dG, e.at(L.wih_t), e.at(p->lstm_dx1), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         if (tr && p->d.dropout_p > 0.f)
           e.run(qt_scale_by_nonzero(e.at<float>(p->lstm_dx1), e.at<float>(p->lstm_x1), (long long)B * H, drop_mul, stream));
       } else {  // only the pose-MLP columns of the fused features have trainable producers
-        gemm(B, 128, 4 * H, dG, QT_F32, 4 * H, 1, e.tf(L.w_ih) + p->mlp_col0, QT_F32, 1, L.in, e.at(p->lstm_dz), 128);
+        e.igemm(e.dense_f32(B, 4 * H, 128), dG, e.at<float>(L.wih_t) + (size_t)p->mlp_col0 * 4 * H, e.at(p->lstm_dz), nullptr,
+                nullptr, nullptr, nullptr, nullptr, 0);
       }
     }
     const float* dz = e.at<float>(p->lstm_dz);
