@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE config 2: 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--freeze-backbone", action="store_true",
+                    help="--model quadtree: the resnet/ variant of the reference (resnet/models.py:77-78: base_cnn frozen, "
+                         "train-mode BatchNorm statistics still updated); a secondary line, 3.9454 GFLOP/image")
     ap.add_argument("--seq-len", type=int, default=16, help="--model cnn_lstm: frames per sequence (BASELINE config 5: 16)")
     ap.add_argument("--model", default="quadtree", choices=["quadtree", "attention", "cnn_lstm"],
                     help="quadtree = QuadtreeCNN (BASELINE config 2/3, the headline); attention = AttentionHierarchicalCNN "
@@ -170,13 +173,16 @@ def main():
     elif args.model == "attention":
         model = P.AttentionHierarchicalCNN(C, compute_dtype=dt, max_batch=B)
     else:
-        model = P.QuadtreeCNN(C, compute_dtype=dt, max_batch=B)
+        model = P.QuadtreeCNN(C, compute_dtype=dt, max_batch=B, freeze_backbone=args.freeze_backbone)
     model.load_state_dict(synth.synth_state_dict(model))
     model = model.to(dev)
     if world > 1 or force_dist:
         dp.attach_data_parallel(model)
     trainable = [p for p in model.parameters() if p.requires_grad]
-    if args.model == "cnn_lstm":
+    if args.model == "quadtree" and args.freeze_backbone:
+        # resnet/train_cnn_model.py:65 hands every parameter to Adam (lr 1e-4, wd 1e-4); the frozen ones have no gradient
+        opt = P.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-4, model=model)
+    elif args.model == "cnn_lstm":
         opt = P.FusedAdam(trainable, lr=1e-4, model=model)  # cnn+lstm/training.py:93: Adam(lr 1e-4), no weight decay
     elif args.optimizer == "fused":
         # the package's Adam: same update rule, run inside the one-launch weight re-packing (csrc/pack.hip)
@@ -273,7 +279,8 @@ def main():
     # whole-step HBM traffic from the committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of the same
     # command, see scripts/collect_profiles.sh) against this run's step time
     hbm = None
-    if not args.forward_only and args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree":
+    if not args.forward_only and args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree" and \
+            not args.freeze_backbone:
         try:
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
@@ -293,6 +300,9 @@ def main():
     value = imgs / elapsed
     gflop_img = FWD_GFLOP_PER_IMAGE if args.forward_only else FWD_BWD_GFLOP_PER_IMAGE
     name, what = "QuadtreeCNN", "QuadtreeCNN (ResNet-18 layer3, 2x2 split, 47-feat fusion) "
+    if args.model == "quadtree" and args.freeze_backbone and not args.forward_only:
+        gflop_img = 3.9454  # forward + backward of the heads only
+        what = "QuadtreeCNN, resnet/ variant (frozen ResNet-18 backbone, fusion mode); "
     if args.model == "attention":
         # 2*MAC of the 22 convs + 5 linears: ResNet-18 conv stack 3.6274 - fc, quadrant conv 784 px x 128x128x9,
         # sub-quadrant conv 784 px x 128x64x9, classifier 1216x1024 + 1024x12; backward = 2 x forward - conv1's dgrad
@@ -314,7 +324,8 @@ def main():
         "data": "synthetic (randn images / pose vectors resident in HBM, deterministic synthetic weights)",
         "config": {"workload": what
                                + ("eval forward" if args.forward_only else
-                                  "train step fwd+bwd+Adam, all parameters trainable; Adam(lr 1e-4, wd 1e-4) by "
+                                  ("train step fwd+bwd+Adam; " if (args.freeze_backbone or args.model == "cnn_lstm") else
+                                   "train step fwd+bwd+Adam, all parameters trainable; ") + "Adam(lr 1e-4, wd 1e-4) by "
                                   + ("the package's FusedAdam (csrc/pack.hip)" if args.optimizer == "fused"
                                      else "torch.optim.Adam(fused=True)")),
                    "global_batch": B * world, "per_gpu_batch": B, "image": "3x224x224", "num_classes": C,

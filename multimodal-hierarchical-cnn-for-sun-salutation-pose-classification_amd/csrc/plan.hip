@@ -96,6 +96,11 @@ struct qt_plan {
   size_t dw_begin = 0, dw_end = 0;
   size_t lin_ws = 0, lin_ws_bytes = 0;          // split-K partials of classifier.0 (forward / backward-input)
   size_t wgrad_part = 0, wgrad_part_bytes = 0;  // partial filters of the streaming weight-gradient kernel
+  // The packed operand copies of every conv / linear weight are current (forward copies; data-gradient copies) for the
+  // master tensors at these addresses: lets qt_plan_adam_step leave FROZEN weights alone (resnet/ variant, CnnLstm: 11 M
+  // backbone weights that used to be re-packed every step).  Any qt_plan_pack_weights call re-establishes it.
+  bool packed_fwd = false, packed_bwd = false;
+  unsigned long long packed_sig = 0;
   bool dw_dirty = true;  // weight-gradient scratch holds sums of an earlier backward
   int bwd_rows_bn2 = 0;  // carried from the layer4 phase to the rest-of-backbone phase  // BatchNorm-backward partials emitted by dgrad epilogues
   // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
@@ -644,6 +649,14 @@ struct Exec {
   }
 };
 
+unsigned long long weight_sig(const qt_plan* p, void* const* T) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](const void* ptr) { h = (h ^ (unsigned long long)(uintptr_t)ptr) * 1099511628211ull; };
+  for (const ConvL& c : p->convs) mix(T[c.w]);
+  mix(T[p->cls0.w]);
+  return h;
+}
+
 int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, void* stream) {
   Exec e{p, static_cast<unsigned char*>(workspace), T, stream, p->d.batch, p->d.dtype};
   // one launch for every conv / linear operand (plus the 9 K-element stem filter)
@@ -667,6 +680,9 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
         false);
   for (size_t j = 0; j < items.size() && e.ok(); j += 32)
     e.run(qt_pack_weights_batched(e.dt, items.data() + j, (int)std::min<size_t>(32, items.size() - j), stream));
+  p->packed_fwd = e.ok();
+  p->packed_bwd = e.ok() && for_backward != 0;
+  p->packed_sig = weight_sig(p, T);
   return e.status;
 }
 
@@ -723,8 +739,15 @@ int adam_step(qt_plan* p, void* workspace, void* const* T, float* const* G, floa
     const int cnt = (int)std::min<size_t>(32, upd_items.size() - j);
     e.run(qt_adam_pack_weights_batched(e.dt, upd_items.data() + j, upd_state.data() + j, adam, cnt, stream));
   }
-  for (size_t j = 0; j < pack_items.size() && e.ok(); j += 32)
-    e.run(qt_pack_weights_batched(e.dt, pack_items.data() + j, (int)std::min<size_t>(32, pack_items.size() - j), stream));
+  // weights without a gradient did not change: their copies are re-packed only if they are not known to be current
+  const unsigned long long sig = weight_sig(p, T);
+  const bool frozen_current = p->packed_fwd && (!for_backward || p->packed_bwd) && p->packed_sig == sig;
+  if (!frozen_current)
+    for (size_t j = 0; j < pack_items.size() && e.ok(); j += 32)
+      e.run(qt_pack_weights_batched(e.dt, pack_items.data() + j, (int)std::min<size_t>(32, pack_items.size() - j), stream));
+  p->packed_fwd = e.ok();
+  p->packed_bwd = e.ok() && (for_backward != 0);
+  p->packed_sig = sig;
   return e.status;
 }
 

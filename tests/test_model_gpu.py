@@ -409,3 +409,48 @@ def test_frozen_backbone_modes_train_step_matches_oracle(mode):
     for k, p in got.items():   # the frozen backbone hands out no gradients
         if k.startswith("base_cnn.") or k.startswith("features_extractor.") or k.startswith("global_processor."):
             assert p.grad is None, k
+
+
+def test_frozen_weights_are_not_repacked_by_adam_step_but_follow_external_changes():
+    """qt_plan_adam_step leaves the packed copies of FROZEN weights alone (they did not change); when the user replaces
+    them (load_state_dict bumps the version counters) the next forward must run on the new values."""
+    dev = _dev()
+    P, synth = pkg(), pkg("synth")
+    B = 4
+    m = build("quadtree", torch.bfloat16, dropout=0.0, frozen=True).to(dev).train()
+    opt = P.FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-4, model=m)
+    x, f = synth.synth_images(B, salt=70).to(dev), synth.synth_pose_features(B, salt=70).to(dev)
+    y = synth.synth_labels(B, 12, salt=70).to(dev)
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x, f), y).backward()
+        opt.step()
+    assert m.base_cnn.conv1.weight.grad is None
+    # after two steps the model equals a fresh one loaded with its state: frozen copies current, trained ones re-packed
+    m.eval()
+    with torch.no_grad():
+        got = m(x, f).clone()
+    fresh = build("quadtree", torch.bfloat16, dropout=0.0, frozen=True)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    fresh = fresh.to(dev).eval()
+    with torch.no_grad():
+        want = fresh(x, f)
+    assert torch.equal(got, want)
+    # replace the frozen backbone's weights behind the optimizer's back
+    new = synth.synth_state_dict(m, salt=1)
+    m.load_state_dict(new)
+    other = build("quadtree", torch.bfloat16, dropout=0.0, frozen=True)
+    other.load_state_dict(new)
+    other = other.to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(m(x, f), other(x, f))
+    m.train()
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x, f), y).backward()
+    opt.step()
+    m.eval()
+    again = build("quadtree", torch.bfloat16, dropout=0.0, frozen=True)
+    again.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    again = again.to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(m(x, f), again(x, f))
