@@ -216,12 +216,14 @@ typedef struct qt_bn_eval_item {
   const float *gamma, *beta, *running_mean, *running_var;
   float *scale, *shift;
   int C;
+  float *mean, *invstd; /* optional pair: running_mean and 1/sqrt(running_var + eps), what the backward kernels read */
 } qt_bn_eval_item;
 int qt_bn_eval_affine_batched(const qt_bn_eval_item* items, int n, float eps, void* stream);
 /* out = relu?( y*scale+shift + (residual ? residual*res_scale+res_shift : 0) ), [M][C] */
 int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
               const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C, void* stream);
-/* backward: g = d(loss)/d(BN output) (masked by `mask` > 0 if given) */
+/* backward: g = d(loss)/d(BN output) (masked by `mask` > 0 if given).  qt_bn_bwd_finalize with count == 0 is the backward of
+ * an eval-mode BatchNorm (running statistics in mean / invstd): dx = g*gamma*invstd without the batch-mean terms. */
 int qt_bn_bwd_partial_rows(long long M, int C);
 int qt_bn_bwd_reduce(int dtype, const void* g, const void* mask, const void* y, const float* mean, const float* invstd,
                      float* partial, long long M, int C, void* stream);
@@ -363,8 +365,12 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  *                          operands (call after every optimizer step)
  *   qt_plan_forward      : model(image[B,3,224,224] f32 NCHW, numerical[B,47] f32)
  *                          -> logits[B,num_classes] f32   (forward of models.py:273-305);
- *                          training != 0: BatchNorm batch statistics + running-stat
- *                          update, dropout with `seed`
+ *                          training == 1: BatchNorm batch statistics + running-stat update, dropout with `seed`;
+ *                          training == 0: eval mode, BatchNorm / ReLU / residual fused into the conv epilogues, nothing
+ *                          kept for a backbone backward; training == 2: eval-mode arithmetic (running statistics, no
+ *                          dropout) but every tensor qt_plan_backward needs is kept, so that model.eval() followed by
+ *                          logits.backward() with trainable backbone parameters works (Grad-CAM on the all-trainable
+ *                          variant, Quadtree_from scratch/grad_cam.py:72-83)
  *   qt_plan_backward     : loss.backward() of Quadtree_train.py:65 given dlogits;
  *                          grads[i] (f32, same layout as tensors[i]) is written
  *                          (not accumulated) when non-NULL; QT_BWD_HEAD = classifier,

@@ -134,6 +134,8 @@ struct BnEvalBatchArgs {
   const float* rvar[BN_MAX_ITEMS];
   float* scale[BN_MAX_ITEMS];
   float* shift[BN_MAX_ITEMS];
+  float* mean[BN_MAX_ITEMS];    // nullable: running statistics in the form the backward kernels take
+  float* invstd[BN_MAX_ITEMS];
   int C[BN_MAX_ITEMS];
   float eps;
 };
@@ -144,6 +146,10 @@ __global__ void bn_eval_affine_batched_kernel(BnEvalBatchArgs a) {
     const float s = a.gamma[j][c] * is;
     a.scale[j][c] = s;
     a.shift[j][c] = a.beta[j][c] - a.rmean[j][c] * s;
+    if (a.mean[j]) {
+      a.mean[j][c] = a.rmean[j][c];
+      a.invstd[j][c] = is;
+    }
   }
 }
 
@@ -269,8 +275,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
-    coef[C + c] = (float)(s1 / count);
-    coef[2 * C + c] = (float)(s2 / count);
+    // count == 0: BatchNorm ran on running statistics (eval mode): no batch-mean terms in dx
+    coef[C + c] = count > 0.0 ? (float)(s1 / count) : 0.f;
+    coef[2 * C + c] = count > 0.0 ? (float)(s2 / count) : 0.f;
   }
 }
 
@@ -818,6 +825,8 @@ extern "C" int qt_bn_eval_affine_batched(const qt_bn_eval_item* items, int n, fl
                  "qt_bn_eval_affine_batched: item %d incomplete", j);
     a.gamma[j] = q.gamma; a.beta[j] = q.beta; a.rmean[j] = q.running_mean; a.rvar[j] = q.running_var;
     a.scale[j] = q.scale; a.shift[j] = q.shift; a.C[j] = q.C;
+    QT_CHECK_ARG((q.mean == nullptr) == (q.invstd == nullptr), "qt_bn_eval_affine_batched: item %d: mean / invstd come in pairs", j);
+    a.mean[j] = q.mean; a.invstd[j] = q.invstd;
   }
   a.eps = eps;
   hipLaunchKernelGGL(bn_eval_affine_batched_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
@@ -879,7 +888,7 @@ extern "C" int qt_bn_bwd_reduce(int dtype, const void* g, const void* mask, cons
 extern "C" int qt_bn_bwd_finalize(float* partial, int rows, int C, long long count, const float* gamma,
                                   const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef,
                                   void* stream) {
-  QT_CHECK_ARG(partial && rows > 0 && C > 0 && count > 0 && invstd && coef, "qt_bn_bwd_finalize: bad argument");
+  QT_CHECK_ARG(partial && rows > 0 && C > 0 && count >= 0 && invstd && coef, "qt_bn_bwd_finalize: bad argument");
   if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      partial, rows, C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);

@@ -622,9 +622,14 @@ struct Exec {
   long long rows_of(const ConvL& c) const { return (long long)B * c.hout * c.hout; }
 
   // conv (+ train-mode statistics -> scale/shift of its BatchNorm)
-  void conv_bn_stats(const ConvL& c, const qt_conv_desc& d, const void* src, bool training) {
+  // training: 1 = batch statistics, 2 = eval statistics but the raw conv output is kept for backward, 0 = nothing here
+  void conv_bn_stats(const ConvL& c, const qt_conv_desc& d, const void* src, int training) {
     BnL& bn = p->bns[c.bn];
-    if (training) {
+    if (training == 2) {
+      igemm(d, src, at(c.w_fwd), at(c.y), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+      return;
+    }
+    if (training == 1) {
       float* part = at<float>(stats_off == (size_t)-1 ? p->stats : stats_off);
       igemm(d, src, at(c.w_fwd), at(c.y), nullptr, nullptr, nullptr, nullptr, part, 0);
       if (!ok()) return;
@@ -636,12 +641,14 @@ struct Exec {
     // eval: scale / shift of every BatchNorm were set by eval_affines() at the start of the forward
   }
   // eval mode: running statistics -> scale / shift of all BatchNorms in one launch
-  void eval_affines() {
+  void eval_affines(bool for_backward) {
     std::vector<qt_bn_eval_item> items;
     for (const BnL& bn : p->bns) {
       qt_bn_eval_item q;
       q.gamma = tf(bn.gamma); q.beta = tf(bn.beta); q.running_mean = tf(bn.rmean); q.running_var = tf(bn.rvar);
       q.scale = at<float>(bn.scale); q.shift = at<float>(bn.shift); q.C = bn.C;
+      q.mean = for_backward ? at<float>(bn.mean) : nullptr;
+      q.invstd = for_backward ? at<float>(bn.invstd) : nullptr;
       items.push_back(q);
     }
     for (size_t j = 0; j < items.size() && ok(); j += 32)
@@ -756,7 +763,8 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
   Exec e{p, static_cast<unsigned char*>(workspace), T, stream, batch, p->d.dtype};
   e.setup_side();
   const int dt = e.dt;
-  const bool tr = training != 0;
+  const bool tr = training == 1;   // batch statistics, running-stat update, dropout
+  const bool unf = training != 0;  // unfused: raw conv outputs, pooling argmax ... are kept for qt_plan_backward
   hipStream_t hs = static_cast<hipStream_t>(stream);
   // The quadrant head (needs layer3's output) and the numerical MLP (needs nothing) are independent
   // of layer4: they run on the side stream and are joined before the classifier.
@@ -807,14 +815,14 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     if (tr && p->d.dropout_p > 0.f) e.run(qt_dropout(dt, z, batch, p->mlp0.out, p->fused_ld, seed, p->d.dropout_p, e.stream));
   };
   if (p->has_image) {
-    if (!tr) e.eval_affines();
+    if (!tr) e.eval_affines(unf);
     // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
     e.run(qt_pack_stem_input(dt, image, e.at(p->xpad), batch, stream));
     const ConvL& c0 = p->convs[0];
     const BnL& bn0 = p->bns[c0.bn];
     const qt_conv_desc sd = e.stem_desc();
-    e.conv_bn_stats(c0, sd, e.at(p->xpad), tr);
-    if (tr) {
+    e.conv_bn_stats(c0, sd, e.at(p->xpad), training);
+    if (unf) {
       e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), e.at(p->p0),
                          e.at<unsigned char>(p->argmax), e.at(p->ymax), batch, stream));
     } else {
@@ -847,14 +855,14 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
         e.fork();
         e.on_side(p->stats_ds, [&] {
-          e.conv_bn_stats(cd, dd, e.at(x), tr);
-          if (!tr)
+          e.conv_bn_stats(cd, dd, e.at(x), training);
+          if (!unf)
             e.igemm(dd, e.at(x), e.at(cd.w_fwd), e.at(cd.y), e.at<float>(bd.scale), e.at<float>(bd.shift), nullptr,
                     nullptr, nullptr, 0);
         });
       }
-      e.conv_bn_stats(c1, d1, e.at(x), tr);
-      if (tr) {
+      e.conv_bn_stats(c1, d1, e.at(x), training);
+      if (unf) {
         e.run(qt_bn_act(dt, e.at(c1.y), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr, nullptr, nullptr, 1,
                         e.at(blk.a1), M, c1.cout, stream));
       } else {
@@ -868,9 +876,9 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         const BnL& bd = p->bns[cd.bn];
         const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
         // (fork happened before conv1, see below)
-        e.conv_bn_stats(c2, d2, e.at(blk.a1), tr);
+        e.conv_bn_stats(c2, d2, e.at(blk.a1), training);
         e.join();
-        if (tr) {
+        if (unf) {
           e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(cd.y),
                           e.at<float>(bd.scale), e.at<float>(bd.shift), 1, e.at(blk.out), M, c2.cout, stream));
         } else {
@@ -879,8 +887,8 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         }
         (void)dd;
       } else {
-        e.conv_bn_stats(c2, d2, e.at(blk.a1), tr);
-        if (tr) {
+        e.conv_bn_stats(c2, d2, e.at(blk.a1), training);
+        if (unf) {
           e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(x), nullptr, nullptr, 1,
                           e.at(blk.out), M, c2.cout, stream));
         } else {
@@ -978,6 +986,8 @@ int zero(void* ptr, size_t bytes, void* stream) {
 struct Bwd : Exec {
   float* const* G;  // gradient pointers (same indexing as T), NULL = not wanted
   float* gf(int idx) const { return idx < 0 ? nullptr : G[idx]; }
+  bool evalbn = false;  // the forward ran BatchNorm on running statistics (training == 2): no batch-mean terms
+  long long bn_count(long long M) const { return evalbn ? 0 : M; }
 
   // BatchNorm backward for conv c given g (in gy or external): dy -> c.gy
   void bn_backward(const ConvL& c, const void* g, void* g_out, float* pre_partial = nullptr, int pre_rows = 0) {
@@ -991,7 +1001,7 @@ struct Bwd : Exec {
       if (!ok()) return;
       rows = qt_bn_bwd_partial_rows(M, bn.C);
     }
-    run(qt_bn_bwd_finalize(part, rows, bn.C, M, tf(bn.gamma), at<float>(bn.invstd), gf(bn.gamma), gf(bn.beta), 0,
+    run(qt_bn_bwd_finalize(part, rows, bn.C, bn_count(M), tf(bn.gamma), at<float>(bn.invstd), gf(bn.gamma), gf(bn.beta), 0,
                            at<float>(bn.coef), stream));
     run(qt_bn_bwd_apply(dt, g, nullptr, at(c.y), at<float>(bn.mean), at<float>(bn.invstd), at<float>(bn.coef),
                         at(c.gy), g_out, M, bn.C, stream));
@@ -1081,7 +1091,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   if (phases & QT_BWD_LAYER1) p->dw_dirty = true;
   const int dt = e.dt;
   const int B = e.B;
-  const bool tr = p->last_training != 0;
+  const bool tr = p->last_training == 1;
+  e.evalbn = p->last_training == 2;
   const float drop_mul = (tr && p->d.dropout_p > 0.f) ? 1.f / (1.f - p->d.dropout_p) : 1.f;
   bool backbone_grads = false;
   if (p->has_image)
@@ -1089,8 +1100,9 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       if ((int)i == p->quad_conv || (int)i == p->sub_conv) continue;
       if (G[p->convs[i].w]) backbone_grads = true;
     }
-  if (backbone_grads && !tr) {
-    qt_set_error("qt_plan_backward: backbone gradients in eval() mode are not implemented");
+  if (backbone_grads && p->last_training == 0) {
+    qt_set_error("qt_plan_backward: the last forward ran fused eval kernels (training = 0) and kept nothing for a backbone "
+                 "backward; run it with training = 2 (eval statistics, tensors kept)");
     return QT_ERR_UNSUPPORTED;
   }
   if (p->lstm) {
@@ -1386,7 +1398,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       const int rows = qt_stem_bn_bwd_sums_rows(B);
       e.run(qt_stem_bn_bwd_sums(dt, e.at(p->g_p0), e.at(p->ymax), e.at<float>(bn0.scale), e.at<float>(bn0.shift),
                                 e.at<float>(bn0.mean), e.at<float>(bn0.invstd), e.at<float>(p->stats), B, stream));
-      e.run(qt_bn_bwd_finalize(e.at<float>(p->stats), rows, bn0.C, (long long)B * 112 * 112, e.tf(bn0.gamma),
+      e.run(qt_bn_bwd_finalize(e.at<float>(p->stats), rows, bn0.C, e.bn_count((long long)B * 112 * 112), e.tf(bn0.gamma),
                                e.at<float>(bn0.invstd), e.gf(bn0.gamma), e.gf(bn0.beta), 0, e.at<float>(bn0.coef), stream));
       e.run(qt_stem_bn_bwd_apply(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
                                  e.at<float>(bn0.shift), e.at<float>(bn0.mean), e.at<float>(bn0.invstd),

@@ -273,8 +273,12 @@ class PlanFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, image, numerical, *params):
         engine = owner._engine
-        training = owner.training
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
+        # 1 train; 0 eval (fused epilogues, nothing kept); 2 eval statistics with everything kept for a backward through
+        # the backbone (model.eval() + logits.backward() with trainable backbone parameters: Grad-CAM on the reference's
+        # all-trainable variant, Quadtree_from scratch/grad_cam.py:72-83)
+        # (decided in _PlanModel._run: grad mode is switched off inside Function.forward)
+        training = 1 if owner.training else (2 if owner._eval_keep_for_backward else 0)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training == 1 else 0
         logits = engine.forward(image, numerical, training, seed)
         ctx.owner = owner
         ctx.engine = engine

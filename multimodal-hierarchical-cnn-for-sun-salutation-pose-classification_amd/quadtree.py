@@ -33,6 +33,7 @@ class _PlanModel(nn.Module):
         self._param_list = None
         self._param_plan_index = None
         self._grad_sync = None  # set by dp.attach_data_parallel
+        self._eval_keep_for_backward = False
 
     # engines hold device memory and ctypes handles: keep them out of pickles / deepcopy
     def __getstate__(self):
@@ -70,6 +71,15 @@ class _PlanModel(nn.Module):
 
     def _plan_extra(self):
         return {}
+
+    def _eval_needs_backbone_backward(self):
+        """eval() forward under autograd with a trainable ResNet parameter: the plan must keep what backward needs"""
+        if not torch.is_grad_enabled() or self._param_list is None:
+            return False
+        for (name, _), p, idx in zip(self.named_parameters(), self._param_list, self._param_plan_index):
+            if idx >= 0 and p.requires_grad and self._plan_name(name).startswith("base_cnn."):
+                return True
+        return False
 
     def _bind(self, eng):
         tensors = {self._plan_name(n): t for n, t in self.named_parameters()}
@@ -142,6 +152,7 @@ class _PlanModel(nn.Module):
             version = self._bind(eng)
             need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
             eng.pack_weights(version, need_bwd)
+            self._eval_keep_for_backward = (not self.training) and self._eval_needs_backbone_backward()
             return _engine.PlanFunction.apply(self, image_input, numerical_input, *self._param_list)
 
 

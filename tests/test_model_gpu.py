@@ -454,3 +454,73 @@ def test_frozen_weights_are_not_repacked_by_adam_step_but_follow_external_change
     again = again.to(dev).eval()
     with torch.no_grad():
         assert torch.equal(m(x, f), again(x, f))
+
+
+@pytest.mark.parametrize("kind", ["quadtree", "attention"])
+def test_eval_mode_backward_through_trainable_backbone(kind):
+    """model.eval() + logits.backward() with every parameter trainable: the Grad-CAM recipe on the reference's all-trainable
+    variant (Quadtree_from scratch/grad_cam.py:72-83).  The forward then runs eval arithmetic (running statistics, no dropout)
+    but keeps what backward needs (qt_plan_forward training = 2); BatchNorm backward has no batch-mean terms.  Logits must
+    equal the fused eval forward; hooks and every parameter gradient are checked against the oracle in eval mode."""
+    dev = _dev()
+    o = _oracle()
+    P, synth = pkg(), pkg("synth")
+    B = 3
+    x, f = synth.synth_images(B, salt=15), synth.synth_pose_features(B, salt=15)
+    if kind == "quadtree":
+        m = build("quadtree", torch.float32, dropout=0.5)
+    else:
+        m = P.AttentionHierarchicalCNN(12, dropout_rate=0.5, compute_dtype=torch.float32)
+        m.load_state_dict(synth.synth_state_dict(m))
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        fused = m(x.to(dev), f.to(dev)).clone()
+    if kind == "quadtree":
+        h1 = m.base_cnn.layer4.register_forward_hook(m.save_activation_hook)
+        h2 = m.base_cnn.layer4.register_full_backward_hook(m.save_gradient_hook)
+    logits = m(x.to(dev), f.to(dev))
+    assert rel_err(logits.detach().cpu(), fused.cpu()) <= 1e-5
+    one_hot = torch.zeros_like(logits)
+    one_hot[:, 5] = 1.0
+    m.zero_grad()
+    logits.backward(gradient=one_hot)
+    torch.cuda.synchronize()
+    # running statistics are untouched by an eval forward
+    bn_key = "base_cnn.bn1.running_mean" if kind == "quadtree" else "features_extractor.1.running_mean"
+    assert torch.equal(m.state_dict()[bn_key].cpu(), sd0[bn_key])
+    if kind == "quadtree":
+        keys = o.trainable_keys(sd0, False)
+        sd = o.unique_params(sd0, keys)
+        taps = {}
+        ref = o.quadtree_forward(sd, x, f, train=False, taps=taps)
+        taps["layer4"].retain_grad()
+        ref.backward(gradient=one_hot.cpu())
+        want = {k: sd[k].grad for k in keys}
+        h1.remove()
+        h2.remove()
+        assert rel_err(m.activations.cpu(), taps["layer4"].detach()) <= 1e-4
+        assert rel_err(m.gradients.cpu(), taps["layer4"].grad) <= 1e-4
+    else:
+        names = [n for n, _ in m.named_parameters()]
+        leaves = {n: sd0[n].clone().requires_grad_(True) for n in names}
+        sdb = o.attention_sd_to_base({k: leaves.get(k, v.clone()) for k, v in sd0.items()})
+        ref = o.attention_forward(sdb, x, f, train=False)
+        ref.backward(gradient=one_hot.cpu())
+        want = {n: leaves[n].grad for n in names}
+    assert rel_err(logits.detach().cpu(), ref.detach()) <= 1e-3
+    params = dict(m.named_parameters())
+    from _util import summary
+    for n, gref in want.items():
+        assert params[n].grad is not None, n
+        got, ref_s = summary(params[n].grad.detach().cpu(), 2048)["sample"], summary(gref, 2048)["sample"]
+        if n == "attention_gate.2.bias":
+            assert float(np.abs(got).max()) <= 1e-5
+            continue
+        err = float(np.abs(got - ref_s).max()) / max(float(np.abs(ref_s).max()), 1e-30)
+        body = n.startswith(("base_cnn.", "features_extractor.", "global_processor.", "quadrant_processor.",
+                             "sub_quadrant_processor."))
+        if body:   # ReLU decisions at rounding distance from zero (see HEAD_TOL / BODY_TOL above)
+            assert _cos(got, ref_s) >= 0.999 and err <= 6e-2, (n, err, _cos(got, ref_s))
+        else:
+            assert err <= 1e-4, (n, err)
