@@ -150,7 +150,13 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)
     dist = None
     force_dist = os.environ.get("QTCNN_FORCE_DIST") in ("1", "2")  # rehearse the RCCL path with a single rank
+    saved_stdout = None
     if world > 1 or force_dist:
+        # RCCL prints a version banner on the process's stdout when the first communicator comes up; the contract is ONE
+        # JSON line on stdout, so everything until that line goes to stderr (file-descriptor level: the banner is C code)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # nccl == RCCL over xGMI.  QTCNN_DIST_BACKEND=gloo only exists to rehearse the
@@ -339,8 +345,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         except Exception as e:  # the checker must never take the measurement down
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     print(json.dumps(out), flush=True)
     if dist is not None:
+        os.dup2(2, 1)  # (teardown chatter, if any, also stays off stdout)
         dist.destroy_process_group()
 
 
