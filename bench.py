@@ -296,6 +296,20 @@ def main():
                    "peak_tb_s": 8.0, "source": os.path.relpath(tf, ROOT) + " (5 profiled steps)"}
         except Exception:
             hbm = None
+    # the matrix pipes' busy cycles per step from the committed PMC pass (scripts/collect_mfma_busy.sh) against THIS run's
+    # step time: utilisation = busy SIMD-cycles / (1024 SIMDs x elapsed x 2.4 GHz)
+    mfma_pmc = None
+    if args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree" and not args.freeze_backbone:
+        try:
+            import glob
+            mf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_busy.json")))[-1]
+            rec = json.load(open(mf))["eval" if args.forward_only else "train"]
+            mfma_pmc = {"busy_simd_cycles_per_step": rec["mfma_busy_cycles_per_step"],
+                        "executed_over_algorithmic_flop": rec["executed_over_algorithmic"],
+                        "utilisation": round(rec["mfma_busy_cycles_per_step"] / (1024 * (elapsed / args.steps) * 2.4e9), 4),
+                        "source": os.path.relpath(mf, ROOT) + " (SQ_VALU_MFMA_BUSY_CYCLES)"}
+        except Exception:
+            mfma_pmc = None
     if dist is not None:
         dist.barrier()
     if rank != 0:
@@ -338,6 +352,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "model_mfma_util": round(gflop_img * value / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
         "roofline": roofline,
+        "mfma_pmc": mfma_pmc,
         "hbm": hbm,
     }
     if world == 1 and not args.no_cpu_baseline:
