@@ -390,6 +390,11 @@ constexpr int L1_PW = 58, L1_RING = 640, L1_WBYTES = 9 * 64 * kRowBytes, L1_RBYT
 constexpr int L1_RED = L1_WBYTES + L1_RBYTES;           // [8 waves][2 i][4 fk][4 r][3] floats
 constexpr int L1_LDS = L1_RED + 8 * 2 * 4 * 4 * 3 * 4;
 
+// Halo positions of a tile store their (meaningless) 16 bytes here instead of branching around the store: every wave then
+// issues exactly four stores per tile, and the next tile's barrier can wait with a COUNTED vmcnt for the window fetch alone
+// instead of for the acknowledgement of the tile's stores.
+__device__ uint4 l1_store_sink[NT];
+
 // OPS: the epilogue has memory operands (residual / ReLU mask / BatchNorm links), prefetched per tile.
 template <bool FLIP, bool OPS>
 __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
@@ -473,8 +478,14 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
 
   int base = 0;  // (256*k) mod 640
   for (int k = 0; k < nt; ++k) {
-    // this tile's window has landed; every wave is done reading the rows the next fetch replaces
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // this tile's window has landed; every wave is done reading the rows the next fetch replaces.  Vector-memory
+    // operations retire in issue order: the window fetch of this tile was issued before the previous tile's operand loads
+    // (all consumed by its epilogue) and its four stores, so "at most four outstanding" means the window is in LDS while
+    // the stores may still be on their way.
+    if (k == 0)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (k + 1 < nt) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma_ring(256 * k + 384 + i * 64);
@@ -551,8 +562,9 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (!OPS) prow[j] = out_row(j);
-      if (prow[j] < 0) continue;
-      const long long off = (long long)prow[j] * 64 + wn * 32 + fk * 8;
+      const bool live = prow[j] >= 0;
+      const float lm = live ? 1.f : 0.f;  // halo positions take no part in the statistics
+      const long long off = (long long)(live ? prow[j] : 0) * 64 + wn * 32 + fk * 8;
       bf16x8 o;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -560,8 +572,8 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
         if (!bwd_stats) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            s1[i][r] += v[r];
-            s2[i][r] += v[r] * v[r];
+            s1[i][r] += lm * v[r];
+            s2[i][r] += lm * v[r] * v[r];
           }
         }
 #pragma unroll
@@ -589,18 +601,19 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
           bf4(i ? pre_y0[j].z : pre_y0[j].x, i ? pre_y0[j].w : pre_y0[j].y, yv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            s1[i][r] += v[r];
-            s2[i][r] += v[r] * (yv[r] - mu0[i][r]) * is0[i][r];
+            s1[i][r] += lm * v[r];
+            s2[i][r] += lm * v[r] * (yv[r] - mu0[i][r]) * is0[i][r];
           }
           if (p.bn_y[1]) {
             float y2[4];
             bf4(i ? pre_y1[j].z : pre_y1[j].x, i ? pre_y1[j].w : pre_y1[j].y, y2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s3[i][r] += v[r] * (y2[r] - mu1[i][r]) * is1[i][r];
+            for (int r = 0; r < 4; ++r) s3[i][r] += lm * v[r] * (y2[r] - mu1[i][r]) * is1[i][r];
           }
         }
       }
-      *reinterpret_cast<bf16x8*>(dst + off) = o;
+      bf16x8* out = live ? reinterpret_cast<bf16x8*>(dst + off) : reinterpret_cast<bf16x8*>(&l1_store_sink[tid]);
+      *out = o;
     }
   }
 
