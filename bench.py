@@ -24,6 +24,8 @@ import os
 # queue with the main stream once RCCL is initialised (measured: 9.85 vs 8.32 ms/step).  Must be
 # set before the HIP runtime initialises, i.e. before torch touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# benchmarks run on the deterministic synthetic weights: no ImageNet checkpoint wanted, no warning about it
+os.environ.setdefault("QTCNN_RESNET18_WEIGHTS", "none")
 
 import argparse
 import ctypes
@@ -42,6 +44,39 @@ PKG = "multimodal-hierarchical-cnn-for-sun-salutation-pose-classification_amd"
 FWD_BWD_GFLOP_PER_IMAGE = 11.0792   # BASELINE.md section 3 (all parameters trainable)
 FWD_GFLOP_PER_IMAGE = 3.7718
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
+# kernel families (scripts/summarize_profiles.py) behind roofline.achieved: forward + data-gradient conv launches
+ROOFLINE_FAMILIES = ("conv_igemm_kernel", "conv_pp_kernel", "conv_l1_ring_kernel", "conv_stem_kernel")
+
+
+def kernel_sources_sha1():
+    """Identity of the kernel sources a PMC summary under profiles/ was collected on (scripts/summarize_*.py store it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, PKG, "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, PKG, "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "qtcnn.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_summary(pattern):
+    """Newest committed profiles/<pattern> collected on EXACTLY the kernel sources of this tree, else (None, reason).
+    PMC counters cannot be collected inside bench.py (rocprofv3 wraps the process), so the numbers are read from the
+    committed summary of the same command -- but never from one that predates a kernel change."""
+    import glob
+    cur = kernel_sources_sha1()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime, reverse=True)
+    for f in cands:
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("kernel_sources_sha1") == cur:
+            return rec, os.path.relpath(f, ROOT)
+    return None, ("no committed PMC summary matches the current kernel sources (sha1 %s): re-collect with "
+                  "scripts/collect_profiles.sh" % cur[:12])
 
 
 def parse():
@@ -63,6 +98,8 @@ def parse():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="Adam(lr 1e-4, wd 1e-4) by the package's FusedAdam kernel (default) or torch.optim.Adam(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forward-leg", action="store_true",
+                    help="skip the eval-forward timing after the train step (profiling runs: keeps kernel counts per step exact)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=2)
     return ap.parse_args()
@@ -74,10 +111,11 @@ def cpu_baseline(args, num_classes=12):
     P = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))   # the cores this process may really use (a 1-GPU box's share: 16)
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("QTCNN_CPU_THREADS", "16"))))  # a 1-GPU box's CPU share is 16
+    if os.environ.get("QTCNN_CPU_THREADS"):
+        cores = max(1, min(cores, int(os.environ["QTCNN_CPU_THREADS"])))
     torch.set_num_threads(cores)
     if args.model == "cnn_lstm":
         T = args.seq_len
@@ -131,21 +169,97 @@ def cpu_baseline(args, num_classes=12):
         step()
         iters += 1
     dt = time.perf_counter() - t0
-    return {"value": round(B * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} train steps (fwd+bwd+Adam) of batch {B}, torch {torch.__version__} CPU fp32, "
-                      f"oracle/quadtree_oracle.py"}
+    out = {"value": round(B * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{iters} train steps (fwd+bwd+Adam) of batch {B}, torch {torch.__version__} CPU fp32, "
+                     f"oracle/quadtree_oracle.py"}
+    if args.model != "quadtree":
+        return out
+    # BASELINE.md section 4 legs, each a bounded sample (whole baseline ~20-30 s): config 1 = StandardResNetCNN forward
+    # bs 1; QuadtreeCNN forward bs 1; QuadtreeCNN forward bs 256 (one pass).  fwd+bwd at bs 256 needs ~13 GB of f32
+    # activations and ~15 s per step on 16 cores: the train-step leg above runs at the stated smaller batch instead.
+    legs = []
+    del opt, params
+    for p in sd.values():
+        p.grad = None
+
+    def timed(fn, n_images, budget, max_iters):
+        fn()
+        k, t = 0, time.perf_counter()
+        while k < 1 or (time.perf_counter() - t < budget and k < max_iters):
+            fn()
+            k += 1
+        return round(n_images * k / (time.perf_counter() - t), 2), k
+
+    with torch.no_grad():
+        std = P.StandardResNetCNN(num_classes)
+        sd_std = synth.synth_state_dict(std)
+        v, k = timed(lambda: o.standard_resnet_forward(sd_std, x[:1]), 1, 2.0, 50)
+        legs.append({"what": "BASELINE config 1: StandardResNetCNN eval forward, bs 1", "value": v, "unit": "images/s",
+                     "iterations": k})
+        v, k = timed(lambda: forward(sd, x[:1], f[:1]), 1, 2.0, 50)
+        legs.append({"what": "QuadtreeCNN eval forward, bs 1", "value": v, "unit": "images/s", "iterations": k})
+        gb = torch.Generator().manual_seed(4321)
+        xb, fb = torch.randn(256, 3, 224, 224, generator=gb), torch.randn(256, 47, generator=gb)
+        forward(sd, xb[:16], fb[:16])
+        t = time.perf_counter()
+        forward(sd, xb, fb)
+        legs.append({"what": "QuadtreeCNN eval forward, bs 256 (one pass)", "unit": "images/s", "iterations": 1,
+                     "value": round(256 / (time.perf_counter() - t), 2)})
+    out["legs"] = legs
+    return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay rank 0's JSON line.  Runs BEFORE this process makes any HIP call (a process that has
+    initialised the GPU must not exec / fork GPU children on this pool); the children are ordinary subprocesses."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit code {proc.returncode}, "
+              f"{'no' if line is None else 'a'} JSON line from rank 0)", file=sys.stderr)
+        raise SystemExit(proc.returncode or 1)
+    rec = json.loads(line)
+    if rec.get("n_gpus") != args.gpus:
+        print(f"bench.py: asked for {args.gpus} GPUs, rank 0 reports {rec.get('n_gpus')}", file=sys.stderr)
+        raise SystemExit(1)
+    print(line, flush=True)
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)       # no launcher: become one (nothing has touched the GPU yet)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the product path has no CPU fallback)")
     ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("QTCNN_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible: RCCL needs one device per rank "
+                         "(QTCNN_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     dist = None
@@ -166,6 +280,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus and not force_dist:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     P = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
@@ -266,50 +382,82 @@ def main():
             ach = (fl[0] + fl[1]) / ((ms[0] + ms[1]) * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             traffic, traffic_src = None, None
-            try:  # HBM bytes per launch from the committed PMC summary (rocprofv3 cannot run inside bench.py)
-                import glob
-                tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
-                fam = json.load(open(tf))["families"]["conv_igemm_kernel"]
-                traffic, traffic_src = fam["hbm_bytes_per_launch"], os.path.relpath(tf, ROOT)
-            except Exception:
-                pass
+            rec, src = pmc_summary("*_traffic.json")
+            if rec is not None:  # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE passes of the same command)
+                fams = rec["families"]
+                n = sum(fams[k].get("launches_profiled", 0) for k in ROOFLINE_FAMILIES if k in fams)
+                if n:
+                    traffic = round(sum(fams[k]["hbm_bytes_per_launch"] * fams[k]["launches_profiled"]
+                                        for k in ROOFLINE_FAMILIES if k in fams) / n)
+                traffic_src = src + " (kernel sources sha1 " + rec["kernel_sources_sha1"][:12] + ")"
+            else:
+                traffic_src = src
             roofline = {"kernel": "forward + data-gradient conv launches (conv_igemm_kernel; conv_l1_ring_kernel for the "
                                   "56x56 64->64 layers; conv_stem_kernel for conv1)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(1e3 * (ms[0] + ms[1]) / nig, 2),
                         "gflop_per_launch": round((fl[0] + fl[1]) / nig / 1e9, 3),
-                        "mfma_ms_per_step": round(sum(ms) / args.profile_steps, 3),
+                        "sum_of_launch_ms_per_step": round(sum(ms) / args.profile_steps, 3),
+                        "sum_of_launch_ms_note": "sum of per-launch event times over TWO concurrent streams (weight "
+                                                 "gradients run beside the main chain): not a serial time, may exceed ms_per_step",
                         "steps_profiled": args.profile_steps, "by_kernel": per}
 
-    # whole-step HBM traffic from the committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of the same
-    # command, see scripts/collect_profiles.sh) against this run's step time
-    hbm = None
-    if not args.forward_only and args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree" and \
-            not args.freeze_backbone:
-        try:
-            import glob
-            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
-            fams = json.load(open(tf))["families"]
-            per_step = sum(v.get("hbm_bytes_per_launch", 0) * v.get("launches_profiled", 0) for v in fams.values()) / 5.0
+    # whole-step HBM traffic / matrix-pipe busy cycles from the committed PMC summaries of the same command
+    # (scripts/collect_profiles.sh, scripts/collect_mfma_busy.sh) against THIS run's step time -- only from summaries
+    # collected on exactly these kernel sources (otherwise null + the reason)
+    hbm = mfma_pmc = None
+    headline = args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree" and not args.freeze_backbone
+    if headline and not args.forward_only:
+        rec, src = pmc_summary("*_traffic.json")
+        if rec is not None:
+            fams = rec["families"]
+            steps_prof = float(rec.get("steps_profiled", 5))
+            per_step = sum(v.get("hbm_bytes_per_launch", 0) * v.get("launches_profiled", 0) for v in fams.values()) / steps_prof
             hbm = {"bytes_per_step": int(per_step), "achieved_tb_s": round(per_step / (elapsed / args.steps) / 1e12, 2),
-                   "peak_tb_s": 8.0, "source": os.path.relpath(tf, ROOT) + " (5 profiled steps)"}
-        except Exception:
-            hbm = None
-    # the matrix pipes' busy cycles per step from the committed PMC pass (scripts/collect_mfma_busy.sh) against THIS run's
-    # step time: utilisation = busy SIMD-cycles / (1024 SIMDs x elapsed x 2.4 GHz)
-    mfma_pmc = None
-    if args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree" and not args.freeze_backbone:
-        try:
-            import glob
-            mf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_busy.json")))[-1]
-            rec = json.load(open(mf))["eval" if args.forward_only else "train"]
-            mfma_pmc = {"busy_simd_cycles_per_step": rec["mfma_busy_cycles_per_step"],
-                        "executed_over_algorithmic_flop": rec["executed_over_algorithmic"],
-                        "utilisation": round(rec["mfma_busy_cycles_per_step"] / (1024 * (elapsed / args.steps) * 2.4e9), 4),
-                        "source": os.path.relpath(mf, ROOT) + " (SQ_VALU_MFMA_BUSY_CYCLES)"}
-        except Exception:
-            mfma_pmc = None
+                   "peak_tb_s": 8.0, "source": src, "kernel_sources_sha1": rec["kernel_sources_sha1"][:12]}
+        else:
+            hbm = {"bytes_per_step": None, "note": src}
+    if headline:
+        rec, src = pmc_summary("*_mfma_busy.json")
+        if rec is not None:
+            r = rec["eval" if args.forward_only else "train"]
+            mfma_pmc = {"busy_simd_cycles_per_step": r["mfma_busy_cycles_per_step"],
+                        "executed_over_algorithmic_flop": r["executed_over_algorithmic"],
+                        "utilisation": round(r["mfma_busy_cycles_per_step"] / (1024 * (elapsed / args.steps) * 2.4e9), 4),
+                        "source": src + " (SQ_VALU_MFMA_BUSY_CYCLES)", "kernel_sources_sha1": rec["kernel_sources_sha1"][:12]}
+        else:
+            mfma_pmc = {"utilisation": None, "note": src}
+
+    # ---- the north-star quantity on the same line: eval-mode forward of the same model, timed after the train step ----
+    forward = None
+    if not args.forward_only and not args.no_forward_leg:
+        model.eval()
+
+        def fwd():
+            with torch.no_grad():
+                return model(images, feats)
+        for _ in range(3):
+            fwd()
+        fence()
+        nf = max(10, args.steps)
+        t1 = time.perf_counter()
+        for _ in range(nf):
+            fwd()
+        fence()
+        ft = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([ft], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ft = float(t.item())
+        fwd_gflop = {"quadtree": FWD_GFLOP_PER_IMAGE, "attention": 3.9765, "cnn_lstm": 3.6311}[args.model]
+        fps = B * world * nf / ft
+        forward = {"metric": "images/sec eval forward (fused BN/ReLU/residual epilogues), same model and batch",
+                   "value": round(fps, 1), "unit": "images/s", "ms_per_batch": round(1e3 * ft / nf, 3), "passes": nf,
+                   "gflop_per_image": fwd_gflop,
+                   "model_mfma_util": round(fwd_gflop * fps / world / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
+                   "target": "north star: >= 0.60 at bs 256 (<= 0.643 ms)"}
+        model.train()
     if dist is not None:
         dist.barrier()
     if rank != 0:
@@ -350,7 +498,8 @@ def main():
                                      else "torch.optim.Adam(fused=True)")),
                    "global_batch": B * world, "per_gpu_batch": B, "image": "3x224x224", "num_classes": C,
                    "parallelism": f"dp{world}"},
-        "model_mfma_util": round(gflop_img * value / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
+        "model_mfma_util": round(gflop_img * value / world / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
+        "forward": forward,
         "roofline": roofline,
         "mfma_pmc": mfma_pmc,
         "hbm": hbm,

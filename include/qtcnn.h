@@ -8,9 +8,19 @@
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer unless it says "host";
  *   - the caller owns every buffer (including workspaces); the library allocates
- *     nothing persistent on the device and keeps no mutable global state;
- *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no
- *     internal synchronisation, re-entrant across streams / one process per GPU;
+ *     nothing persistent on the device.  Process-wide state is limited to (i) the
+ *     kernel-selection switches qt_set_patch_conv / qt_set_stem_conv /
+ *     qt_set_wgrad_patch_min_width and the QTCNN_* environment variables they mirror
+ *     (read once; DESIGN.md section 5 lists them) -- they pick between kernels that
+ *     compute the same result, set them before the first launch -- and (ii) the
+ *     per-device "LDS limit raised" bits of the large-LDS kernels;
+ *   - the per-op entry points enqueue all work on `stream` (a hipStream_t passed as
+ *     void*) with no internal synchronisation and are re-entrant across streams.  A
+ *     qt_plan additionally OWNS one side stream and a handful of events (created in
+ *     qt_plan_create, destroyed in qt_plan_destroy): qt_plan_backward forks the
+ *     weight-gradient launches onto it and joins them back into `stream` before it
+ *     returns (qt_plan_side_fence exposes the join to another stream).  One plan is
+ *     used by one host thread at a time; one process per GPU under data parallelism;
  *   - return value: QT_OK (0) or a negative qt_status; qt_last_error() returns a
  *     thread-local description of the last failure; nothing throws across the ABI;
  *   - activations are NHWC, element type qt_dtype (bf16 throughput build or the

@@ -582,16 +582,8 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int LDS = LDS0 > RED ? LDS0 : RED;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, DGRAD, EH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), LDS, lds_limit_set)) return rc;
   ConvArgs args = a;
   args.gridM = qt_cdiv(a.M, BM);
   args.gridN = qt_cdiv(a.N, BN);

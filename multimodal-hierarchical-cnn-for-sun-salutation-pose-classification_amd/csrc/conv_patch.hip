@@ -346,16 +346,8 @@ int launch_patch(PatchArgs a, hipStream_t stream) {
   constexpr int lds = lds_loop > lds_epi ? (lds_loop > red ? lds_loop : red) : (lds_epi > red ? lds_epi : red);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_patch_kernel<T, BN, WW, FLIP, NCHUNKS, PBUFS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
   a.PR = PR;
   a.pbufs = PBUFS;
   a.gridM = qt_cdiv(a.Q, BM);
@@ -671,16 +663,8 @@ inline int l1_ring_grid(long long Q) {
 template <bool FLIP, bool OPS>
 int launch_l1_ring(PatchArgs a, hipStream_t stream) {
   auto kern = conv_l1_ring_kernel<FLIP, OPS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), L1_LDS, lds_limit_set)) return rc;
   a.gridM = qt_cdiv(a.Q, BM);
   a.gridN = 1;
   hipLaunchKernelGGL(kern, dim3(l1_ring_grid(a.Q)), dim3(NT), L1_LDS, stream, a);

@@ -349,16 +349,9 @@ int qt_stem_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   const bool aff = a.scale != nullptr || a.relu, stats = a.stats != nullptr;
   void (*kern)(StemArgs) = aff ? (stats ? conv_stem_kernel<true, true> : conv_stem_kernel<true, false>)
                                : (stats ? conv_stem_kernel<false, true> : conv_stem_kernel<false, false>);
-  static bool attr_done[4] = {false, false, false, false};
+  static std::atomic<unsigned long long> lds_limit_set[4];  // per instantiation, per device
   const int ki = (aff ? 2 : 0) + (stats ? 1 : 0);
-  if (!attr_done[ki]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", ST_LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done[ki] = true;
-  }
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), ST_LDS, lds_limit_set[ki])) return rc;
   hipLaunchKernelGGL(kern, dim3(stem_grid(d->batch)), dim3(256), ST_LDS, static_cast<hipStream_t>(stream), a);
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -377,16 +370,8 @@ extern "C" int qt_stem_conv_pool(int dtype, const void* xpad, const void* weight
   StemPoolArgs a;
   a.x = static_cast<const bf16_t*>(xpad); a.w = static_cast<const bf16_t*>(weight);
   a.pooled = static_cast<bf16_t*>(pooled); a.scale = scale; a.shift = shift; a.taps = taps; a.ntiles = batch * 28;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", SP_LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(conv_stem_pool_kernel), SP_LDS, lds_limit_set)) return rc;
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
   hipLaunchKernelGGL(conv_stem_pool_kernel, dim3(grid), dim3(512), SP_LDS, static_cast<hipStream_t>(stream), a);
   QT_CHECK_LAUNCH();

@@ -326,16 +326,8 @@ int launch(WgradArgs a, hipStream_t stream) {
   constexpr int BNWP = STEM ? 256 : BNW;
   constexpr int LDS = 2 * KP * (BMW * ES + BNWP * ES);
   auto kern = conv_wgrad_kernel<T, BMW, BNW, STEM>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), LDS, lds_limit_set)) return rc;
   a.tilesN = qt_cdiv(a.N, BMW);
   a.tilesC = STEM ? 1 : qt_cdiv(a.KC, BNW);
   const int gtaps = STEM ? 1 : a.ntaps;

@@ -361,15 +361,8 @@ int launch_patch(WPArgs a, size_t part_bytes, int oihw, hipStream_t stream) {
     return QT_ERR_INVALID_ARG;
   }
   auto kern = conv_wgrad_patch_kernel<G, D, NX, ND>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), LDS, lds_limit_set)) return rc;
   hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(256 * G), LDS, stream, a);
   QT_CHECK_LAUNCH();
   if (a.part) {

@@ -197,16 +197,8 @@ extern "C" int qt_linear_bf16(const void* x, const void* w, const float* bias, i
   a.nsplit = pick_split(a.ntn, a.ksteps);
   a.steps_per = a.ksteps / a.nsplit;
   constexpr int LDS = LN_NST * LN_STAGE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_splitk_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      qt_set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-      return QT_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(linear_splitk_kernel), LDS, lds_limit_set)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(linear_splitk_kernel, dim3(a.ntn * a.nsplit), dim3(256), LDS, s, a);
   QT_CHECK_LAUNCH();

@@ -147,6 +147,24 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
 }
 
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember it per (kernel, device) --
+// one bit per device ordinal in an atomic owned by the call site -- so a process that runs plans on cuda:1
+// after cuda:0 raises the limit there too, and two host threads may race here harmlessly.
+#include <atomic>
+static inline int qt_raise_lds_limit(const void* kern, int lds_bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return QT_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    qt_set_error("hipFuncSetAttribute(%d B of LDS, device %d): %s", lds_bytes, dev, hipGetErrorString(e));
+    return QT_ERR_LAUNCH;
+  }
+  done.fetch_or(bit, std::memory_order_release);
+  return QT_OK;
+}
+
 static inline int qt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // qt_conv_desc::quad: 0 = whole images, 1 or 2 = 2 x 2 regions per image, 4 = 4 x 4 regions
 static inline int qt_quad_split(int quad) { return quad == 1 ? 2 : quad; }

@@ -4,12 +4,13 @@ gradient all-reduce (RCCL over xGMI; `nccl` backend of torch.distributed) per
 step.  The reference has no distributed code at all; message
 sizes and overlap plan are in SURVEY.md 8(e).
 
-The plan's backward hands over its flat f32 gradient buffer in three buckets, in
-the order they become final:
+The plan's backward runs in four phases and hands over its flat f32 gradient buffer
+in four buckets, in the order they become final (engine.py::PlanEngine.backward):
   head      classifier + numerical MLP + quadrant conv  (59 MB, 57 % of the bytes,
             ready before any backbone kernel has run)
   layer4    33.6 MB, ready after the first two residual blocks of backward
-  rest      layers 3..1 + stem, 11 MB: the only bucket whose reduction is not hidden
+  layer3+2  10.5 MB, on the wire while layer1 and the stem run
+  layer1+stem  0.6 MB: the only bucket whose reduction is exposed behind the last kernel
 Each bucket is averaged across ranks on a dedicated communication stream while
 the compute stream continues with the backbone backward; the compute stream
 waits for the communication stream once, at the end of backward.  BatchNorm

@@ -124,6 +124,15 @@ class PlanEngine:
         self._weights_stale = True
         self.fwd_counter = 0
         self.grad_sync = None  # optional callable(bucket: Tensor, phase: int) for data parallelism
+        self._flat_grad = None       # flat f32 gradient buffer of the last backward (re-used when nobody holds its views)
+
+    @staticmethod
+    def _storage_idle(t):
+        """True when no tensor but `t` itself shares t's storage (the caller dropped every gradient view)."""
+        try:
+            return torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2  # t + the temporary handle
+        except Exception:
+            return False
 
     def __del__(self):
         try:
@@ -238,7 +247,13 @@ class PlanEngine:
             ends[bucket_of(idx)] = total
         for b in range(1, 4):
             ends[b] = max(ends[b], ends[b - 1])
-        flat = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
+        # One flat buffer per (layout): re-used across steps unless a previous step's gradient views are still
+        # referenced by the caller (`.grad` kept with zero_grad(set_to_none=False), accumulation, retained graphs):
+        # then that step's buffer stays theirs and a fresh one is taken.
+        flat = self._flat_grad
+        if flat is None or flat.numel() != max(total, 1) or not self._storage_idle(flat):
+            flat = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
+            self._flat_grad = flat
         grad_ptrs = (ctypes.c_void_p * len(self.names))()
         views = {}
         for idx, shape in wanted:

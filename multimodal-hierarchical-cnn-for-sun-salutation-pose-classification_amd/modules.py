@@ -164,13 +164,31 @@ class ResNet18(nn.Module):
         return _Leaf.forward(self, x)
 
 
-def load_pretrained_resnet18(base_cnn):
-    """The reference downloads ImageNet weights (resnet18-f37072fd.pth) by URL.
-    Nothing is fetched here: if QTCNN_RESNET18_WEIGHTS names a local torchvision
-    ResNet-18 state_dict it is loaded, otherwise the random initialisation stays
-    (load a reference checkpoint with load_state_dict afterwards)."""
+_warned_no_weights = False
+
+
+def load_pretrained_resnet18(base_cnn, pretrained=True, frozen=False):
+    """The reference always starts from ImageNet weights: `resnet18(weights=ResNet18_Weights.IMAGENET1K_V1)` downloads
+    resnet18-f37072fd.pth by URL (Quadtree_from scratch/models.py:221, resnet/models.py:12,76, cnn+lstm/models.py:22).
+    Nothing is fetched here.  QTCNN_RESNET18_WEIGHTS = path of a local torchvision ResNet-18 state_dict: it is loaded.
+    Unset: the backbone keeps its random initialisation and a one-time UserWarning says so -- training heads on a
+    frozen random backbone (resnet/, cnn+lstm/ variants) silently diverges from the reference otherwise.  Opt out
+    with `pretrained=False` or QTCNN_RESNET18_WEIGHTS=none (tests, benchmarks, or when a full checkpoint is loaded
+    with load_state_dict right after construction).  Returns True when weights were loaded."""
+    global _warned_no_weights
     path = os.environ.get("QTCNN_RESNET18_WEIGHTS")
+    if not pretrained or (path is not None and path.strip().lower() in ("none", "random", "0", "")):
+        return False
     if path:
         base_cnn.load_state_dict(torch.load(path, map_location="cpu"))
         return True
+    if not _warned_no_weights:
+        _warned_no_weights = True
+        import warnings
+        warnings.warn(
+            "QuadtreeCNN build: the reference initialises its ResNet-18 from ImageNet weights (downloaded by URL), "
+            "which are not available offline; the backbone" + (" is FROZEN and" if frozen else "") + " keeps a RANDOM "
+            "initialisation. Set QTCNN_RESNET18_WEIGHTS=/path/to/resnet18-f37072fd.pth (torchvision state_dict), load a "
+            "checkpoint with load_state_dict(), or silence this with pretrained=False / QTCNN_RESNET18_WEIGHTS=none.",
+            UserWarning, stacklevel=3)
     return False

@@ -72,6 +72,20 @@ class _PlanModel(nn.Module):
     def _plan_extra(self):
         return {}
 
+    def _plan_writes_grad(self, plan_name):
+        """Does backward produce a gradient for this tensor?  The reference leaves `.grad` of a branch its `mode`
+        never runs at None (resnet/models.py:141-180: the branch is not in the autograd graph), and of the unused
+        `base_cnn.fc`; the plan skips the same branches, so their gradients must not be requested (they would be
+        views of uninitialised memory)."""
+        if plan_name.startswith("base_cnn.fc."):
+            return False
+        mode = self._plan_mode()
+        if mode == "image_only" and plan_name.startswith("numerical_mlp."):
+            return False
+        if mode == "numerical_only" and not plan_name.startswith(("numerical_mlp.", "classifier.")):
+            return False
+        return True
+
     def _eval_needs_backbone_backward(self):
         """eval() forward under autograd with a trainable ResNet parameter: the plan must keep what backward needs"""
         if not torch.is_grad_enabled() or self._param_list is None:
@@ -89,7 +103,8 @@ class _PlanModel(nn.Module):
             named = list(self.named_parameters())
             self._param_list = [p for _, p in named]
             self._param_plan_index = [
-                -1 if n.startswith("base_cnn.fc.") else eng.index.get(self._plan_name(n), -1) for n, _ in named]
+                eng.index.get(self._plan_name(n), -1) if self._plan_writes_grad(self._plan_name(n)) else -1
+                for n, _ in named]
         return sum(p._version for p in self._param_list)
 
     # ---- Grad-CAM compatibility (reference: resnet/grad_cam_analysis.py:251-259,286,306-316;
@@ -130,7 +145,21 @@ class _PlanModel(nn.Module):
         for hook in list(layer4._backward_hooks.values()):
             hook(layer4, (None,), (g,))
 
+    def _check_hooks(self):
+        """The plan never calls the leaf modules, so a hook registered on one of them would silently never fire.
+        Only `base_cnn.layer4` (the module the reference's Grad-CAM scripts hook, resnet/grad_cam_analysis.py:258-259)
+        is served from the plan's buffers; hooks on any other submodule raise here instead of staying dead."""
+        served = getattr(getattr(self, "base_cnn", None), "layer4", None)
+        for name, mod in self.named_modules():
+            if mod is self or mod is served:
+                continue
+            if mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks:
+                raise QtError(f"hook registered on submodule {name!r}: the fused HIP plan only serves hooks on "
+                              "`base_cnn.layer4` (forward hook + full backward hook, the Grad-CAM recipe) and on the "
+                              "model itself; hooks on other submodules would never fire")
+
     def _run(self, image_input, numerical_input):
+        self._check_hooks()
         ref = image_input if image_input is not None else numerical_input
         device = ref.device
         if device.type != "cuda":
@@ -158,7 +187,7 @@ class _PlanModel(nn.Module):
 
 class QuadtreeCNN(_PlanModel):
     def __init__(self, num_classes, cnn_feature_dim=512, numerical_feature_dim=47, dropout_rate=0.5,
-                 mode="fusion", freeze_backbone=False, compute_dtype=None, max_batch=None):
+                 mode="fusion", freeze_backbone=False, compute_dtype=None, max_batch=None, pretrained=True):
         super().__init__()
         if cnn_feature_dim != 512:
             raise ValueError("the gfx950 kernels are specialised for cnn_feature_dim=512 (the reference default)")
@@ -168,7 +197,7 @@ class QuadtreeCNN(_PlanModel):
         self.dropout_rate = dropout_rate
 
         self.base_cnn = M.ResNet18()
-        M.load_pretrained_resnet18(self.base_cnn)
+        M.load_pretrained_resnet18(self.base_cnn, pretrained, frozen=freeze_backbone)
         if freeze_backbone:
             for param in self.base_cnn.parameters():
                 param.requires_grad = False
@@ -221,13 +250,13 @@ class QuadtreeCNN(_PlanModel):
 class StandardResNetCNN(_PlanModel):
     _model_kind = _engine.QT_MODEL_STANDARD_RESNET
 
-    def __init__(self, num_classes, dropout_rate=0.5, compute_dtype=None, max_batch=None):
+    def __init__(self, num_classes, dropout_rate=0.5, compute_dtype=None, max_batch=None, pretrained=True):
         super().__init__()
         self.num_classes = num_classes
         self.numerical_feature_dim = 47
         self.dropout_rate = dropout_rate
         self.base_cnn = M.ResNet18()
-        M.load_pretrained_resnet18(self.base_cnn)
+        M.load_pretrained_resnet18(self.base_cnn, pretrained, frozen=True)
         for param in self.base_cnn.parameters():
             param.requires_grad = False
         b = self.base_cnn
@@ -263,13 +292,14 @@ class AttentionHierarchicalCNN(_PlanModel):
                     ("features_extractor.4.", "base_cnn.layer1."), ("features_extractor.5.", "base_cnn.layer2."),
                     ("global_processor.0.", "base_cnn.layer3."), ("global_processor.1.", "base_cnn.layer4."))
 
-    def __init__(self, num_classes, numerical_feature_dim=47, dropout_rate=0.5, compute_dtype=None, max_batch=None):
+    def __init__(self, num_classes, numerical_feature_dim=47, dropout_rate=0.5, compute_dtype=None, max_batch=None,
+                 pretrained=True):
         super().__init__()
         self.num_classes = num_classes
         self.numerical_feature_dim = numerical_feature_dim
         self.dropout_rate = dropout_rate
         base_cnn = M.ResNet18()
-        M.load_pretrained_resnet18(base_cnn)
+        M.load_pretrained_resnet18(base_cnn, pretrained)
         b = base_cnn
         self.features_extractor = nn.Sequential(b.conv1, b.bn1, b.relu, b.maxpool, b.layer1, b.layer2)
         base_feature_channels = 128
@@ -310,7 +340,7 @@ class CnnLstm(_PlanModel):
                     ("cnn_backbone.6.", "base_cnn.layer3."), ("cnn_backbone.7.", "base_cnn.layer4."))
 
     def __init__(self, num_classes, sequence_length=4, numerical_feature_dim=47, dropout_rate=0.5, lstm_hidden_size=256,
-                 compute_dtype=None, max_batch=None):
+                 compute_dtype=None, max_batch=None, pretrained=True):
         super().__init__()
         if lstm_hidden_size not in (256, 64):
             raise ValueError("the gfx950 LSTM kernel is instantiated for lstm_hidden_size 256 (reference default) and 64")
@@ -320,7 +350,7 @@ class CnnLstm(_PlanModel):
         self.dropout_rate = dropout_rate
         self.lstm_hidden_size = lstm_hidden_size
         resnet = M.ResNet18()
-        M.load_pretrained_resnet18(resnet)
+        M.load_pretrained_resnet18(resnet, pretrained, frozen=True)
         self.cnn_backbone = nn.Sequential(*list(resnet.children())[:-1])
         for param in self.cnn_backbone.parameters():
             param.requires_grad = False

@@ -19,7 +19,7 @@ src = os.path.join(root, "gpurun_out", name)
 
 
 def family(kernel):
-    for key in ("conv_igemm_kernel", "conv_wgrad_patch_kernel", "conv_wgrad_kernel", "conv_l1_ring_kernel",
+    for key in ("conv_igemm_kernel", "conv_pp_kernel", "conv_wgrad_patch_kernel", "conv_wgrad_kernel", "conv_l1_ring_kernel",
                 "conv_stem_kernel", "conv_patch_kernel", "wgrad_partial_sum", "bn_bwd_apply", "bn_bwd_reduce",
                 "bn_act", "stem_pool_bwd", "stem_bn_bwd_sums", "stem_pool", "pack_weights_batched",
                 "multi_tensor_apply"):
@@ -60,7 +60,10 @@ for r in rows:
 for fam, (ns, calls) in dur.items():
     summary.setdefault(fam, {})["avg_us"] = round(ns / calls / 1e3, 2)
     summary[fam]["calls"] = calls
-json.dump({"command": "bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 0 (B=256, bf16, 1 GPU)",
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_sources_sha1: ties the summary to the kernel sources it was collected on)
+json.dump({"command": "bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0 (B=256, bf16, 1 GPU)",
+           "kernel_sources_sha1": bench.kernel_sources_sha1(), "steps_profiled": 5,
            "corrections": "read = FETCH_SIZE*1024*2 (gfx950 half-count of wide coalesced reads), write = WRITE_SIZE*1024",
            "families": summary}, open(os.path.join(root, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the tests run on the deterministic synthetic weights (synth.py): opt out of the "no ImageNet checkpoint" warning
+# (tests/test_boundary_cpu.py::test_missing_pretrained_weights_are_loud checks the warning itself)
+os.environ.setdefault("QTCNN_RESNET18_WEIGHTS", "none")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -167,3 +167,73 @@ def test_plan_tensor_table_matches_module_tree():
     assert L.qt_plan_create(ctypes.byref(bad), ctypes.byref(h)) == -1
     L.qt_last_error.restype = ctypes.c_char_p
     assert b"dtype" in L.qt_last_error()
+
+
+def test_missing_pretrained_weights_are_loud(monkeypatch):
+    """The reference always starts from ImageNet weights (resnet18(weights=IMAGENET1K_V1), models.py:221); offline they
+    are absent, and a frozen random backbone must not go unnoticed: one UserWarning naming QTCNN_RESNET18_WEIGHTS,
+    silenced by pretrained=False or QTCNN_RESNET18_WEIGHTS=none."""
+    import warnings
+    P, M = pkg(), pkg("modules")
+    monkeypatch.delenv("QTCNN_RESNET18_WEIGHTS", raising=False)
+    monkeypatch.setattr(M, "_warned_no_weights", False)
+    with pytest.warns(UserWarning, match="QTCNN_RESNET18_WEIGHTS"):
+        P.StandardResNetCNN(12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        P.QuadtreeCNN(12)                      # one-time: already warned in this process
+        monkeypatch.setattr(M, "_warned_no_weights", False)
+        P.QuadtreeCNN(12, pretrained=False)    # explicit opt-out
+        monkeypatch.setenv("QTCNN_RESNET18_WEIGHTS", "none")
+        P.CnnLstm(12)
+    # a real file is loaded
+    ref = M.ResNet18()
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "qt_test_resnet18.pth")
+    torch.save(ref.state_dict(), path)
+    monkeypatch.setenv("QTCNN_RESNET18_WEIGHTS", path)
+    m = P.QuadtreeCNN(12)
+    assert torch.equal(m.base_cnn.layer3[1].conv2.weight, ref.layer3[1].conv2.weight)
+    os.remove(path)
+
+
+def test_gradients_are_only_requested_where_the_mode_produces_them():
+    """resnet/models.py:141-180: the branch a `mode` never runs is not in the autograd graph, its parameters keep
+    grad None (Adam skips them, the checkpoint keeps their values).  The plan skips the same branches, so the module
+    must not hand it gradient buffers for them."""
+    P = pkg()
+    cases = {"fusion": lambda n: True,
+             "image_only": lambda n: not n.startswith("numerical_mlp."),
+             "numerical_only": lambda n: n.startswith(("numerical_mlp.", "classifier."))}
+    for mode, produced in cases.items():
+        m = P.QuadtreeCNN(12, mode=mode)
+        for n, _ in m.named_parameters():
+            want = produced(n) and not n.startswith("base_cnn.fc.")
+            assert m._plan_writes_grad(m._plan_name(n)) == want, (mode, n)
+
+
+def test_hooks_on_unserved_submodules_raise_instead_of_staying_dead():
+    P = pkg()
+    QtError = pkg("_lib").QtError
+    m = P.QuadtreeCNN(12)
+    h = m.base_cnn.layer4.register_forward_hook(lambda *a: None)     # the Grad-CAM hook point: served
+    m.register_forward_hook(lambda *a: None)                          # on the model itself: torch fires it
+    m._check_hooks()
+    h2 = m.base_cnn.layer3.register_forward_hook(lambda *a: None)
+    with pytest.raises(QtError, match="layer3"):
+        m._check_hooks()
+    h2.remove()
+    h3 = m.classifier[0].register_full_backward_hook(lambda *a: None)
+    with pytest.raises(QtError, match="classifier.0"):
+        m._check_hooks()
+    h3.remove(); h.remove()
+    m._check_hooks()
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """`--gpus N` under a launcher with another WORLD_SIZE must fail loudly (round-1 bug: it silently benched 1 GPU)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    assert r.stdout.strip() == ""

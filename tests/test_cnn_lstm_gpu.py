@@ -156,3 +156,65 @@ def test_cnn_lstm_matches_oracle_other_shape_and_trains():
     out = d(x.to(dev), f.to(dev))
     F.cross_entropy(out, y.to(dev)).backward()
     assert torch.isfinite(out).all() and torch.isfinite(d.lstm.weight_ih_l0.grad).all()
+
+
+def test_cnn_lstm_config5_size_t16_x6_matches_oracle():
+    """BASELINE config 5 at its own size: 6 viewpoint sequences x T = 16 frames (cnn+lstm/models.py:58-89 on
+    [6,16,3,224,224] + [6,16,47]).  f32 build: eval logits and a dropout-free train step (loss + all 16 trainable
+    gradients) against the CPU oracle; the 16-step recurrence is 4x longer than the fixtures' T=3/4."""
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    B, T = 6, 16
+    x = synth.synth_images(B * T, salt=160).view(B, T, 3, 224, 224)
+    f = synth.synth_pose_features(B * T, salt=160).view(B, T, 47)
+    y = synth.synth_labels(B, 12, salt=160)
+    m = _build(torch.float32, T).to(dev).eval()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    base = o.cnn_lstm_sd_to_base(sd0)
+    with torch.no_grad():
+        got = m(x.to(dev), f.to(dev)).cpu()
+        ref = o.cnn_lstm_forward(base, x, f)
+    assert got.shape == (B, 12)
+    assert rel_err(got, ref) <= 1e-3
+    # train step (train-mode BatchNorm over the 96 frames, dropout 0)
+    m.train()
+    loss = F.cross_entropy(m(x.to(dev), f.to(dev)), y.to(dev))
+    loss.backward()
+    keys = [k for k in base if k.split(".")[0] in ("numerical_mlp", "lstm", "classifier")]
+    sd = o.unique_params(base, keys)
+    ref_loss = F.cross_entropy(o.cnn_lstm_forward(sd, x, f, train=True, dropout_p=0.0), y)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-3 * max(1.0, abs(ref_loss.item()))
+    params = dict(m.named_parameters())
+    checked = 0
+    for k in keys:
+        g = params[k].grad
+        assert g is not None, k
+        assert rel_err(g.cpu(), sd[k].grad) <= 2e-3, (k, rel_err(g.cpu(), sd[k].grad))
+        checked += 1
+    assert checked == 16
+    assert all(p.grad is None for p in m.cnn_backbone.parameters())
+
+
+def test_cnn_lstm_config5_size_bf16_properties():
+    """bf16 throughput build at 6 x 16: eval logits within the stated bf16 bound of the oracle, sequences are
+    independent in eval mode (running them 6 at a time equals 2 + 4), gradients finite."""
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    B, T = 6, 16
+    x = synth.synth_images(B * T, salt=161).view(B, T, 3, 224, 224).to(dev)
+    f = synth.synth_pose_features(B * T, salt=161).view(B, T, 47).to(dev)
+    y = synth.synth_labels(B, 12, salt=161).to(dev)
+    m = _build(torch.bfloat16, T).to(dev).eval()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        all6 = m(x, f).clone()
+        parts = torch.cat([m(x[:2], f[:2]).clone(), m(x[2:], f[2:]).clone()])
+        ref = o.cnn_lstm_forward(o.cnn_lstm_sd_to_base(sd0), x.cpu(), f.cpu())
+    assert torch.equal(all6, parts)
+    assert rel_err(all6.cpu(), ref) <= LOGIT_TOL[torch.bfloat16]
+    m.train()
+    F.cross_entropy(m(x, f), y).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
