@@ -105,17 +105,43 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may really use: min(CPU affinity, cgroup CPU quota).  On the GPU boxes the affinity mask shows
+    every core of the host (256) while the container's share is 16: 256 torch threads on a 16-core quota run ~100x
+    slower than 16 (measured: 0.17 vs ~70 images/s), so the quota decides.  No quota visible: the documented share of a
+    1-GPU box (16), or the affinity count if smaller.  QTCNN_CPU_THREADS overrides."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    if os.environ.get("QTCNN_CPU_THREADS"):
+        return max(1, min(aff, int(os.environ["QTCNN_CPU_THREADS"]))), "QTCNN_CPU_THREADS"
+    quota = None
+    try:   # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(per)))
+    except Exception:
+        pass
+    if quota is None:
+        try:   # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, -(-q // per))
+        except Exception:
+            pass
+    if quota is not None:
+        return max(1, min(aff, quota)), f"min(affinity {aff}, cgroup quota {quota})"
+    return max(1, min(aff, 16)), f"min(affinity {aff}, 16 = CPU share of a 1-GPU box; no cgroup quota visible)"
+
+
 def cpu_baseline(args, num_classes=12):
     """The oracle (kind "port") on the host cores: fwd+bwd+Adam on a bounded sample."""
     import oracle.quadtree_oracle as o  # checker only, never the product path
     P = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
-    try:
-        cores = len(os.sched_getaffinity(0))   # the cores this process may really use (a 1-GPU box's share: 16)
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    if os.environ.get("QTCNN_CPU_THREADS"):
-        cores = max(1, min(cores, int(os.environ["QTCNN_CPU_THREADS"])))
+    cores, cores_source = host_cores()
     torch.set_num_threads(cores)
     if args.model == "cnn_lstm":
         T = args.seq_len
@@ -135,7 +161,8 @@ def cpu_baseline(args, num_classes=12):
             opt.step()
             iters += 1
         dt = time.perf_counter() - t0
-        return {"value": round(S * T * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+        return {"value": round(S * T * iters / dt, 2), "unit": "images/s", "cores": cores, "cores_source": cores_source,
+                "kind": "port",
                 "sample": f"{iters} train steps of {S} sequences x {T} frames, torch {torch.__version__} CPU fp32, "
                           f"oracle/quadtree_oracle.py::cnn_lstm_forward"}
     if args.model == "attention":
@@ -169,7 +196,7 @@ def cpu_baseline(args, num_classes=12):
         step()
         iters += 1
     dt = time.perf_counter() - t0
-    out = {"value": round(B * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+    out = {"value": round(B * iters / dt, 2), "unit": "images/s", "cores": cores, "cores_source": cores_source, "kind": "port",
            "sample": f"{iters} train steps (fwd+bwd+Adam) of batch {B}, torch {torch.__version__} CPU fp32, "
                      f"oracle/quadtree_oracle.py"}
     if args.model != "quadtree":

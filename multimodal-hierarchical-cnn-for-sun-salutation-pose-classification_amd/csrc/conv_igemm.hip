@@ -18,40 +18,11 @@
 // fusing scale/shift (+residual) (+ReLU) (+ReLU-mask) and BatchNorm partial sums.
 #include <stdlib.h>
 
-#include "qt_common.h"
+#include "conv_args.h"
 
 namespace {
 
-struct ConvArgs {
-  const void* src;
-  const void* wgt;
-  void* dst;
-  const float* scale;      // per destination channel, nullable
-  const float* shift;      // per destination channel, nullable
-  const void* residual;    // [M][N] same dtype, nullable
-  const void* relu_mask;   // [M][N] same dtype: result *= (mask > 0), nullable
-  float* stats_partial;    // [gridM][2][N] per-tile sum / sum of squares, nullable
-  // BatchNorm-backward partial sums of the value written to dst (g): sum g and sum g*xhat with
-  // xhat = (bn_y - mean) * invstd, for up to two BatchNorms that consume g
-  const void* bn_y[2];
-  const float* bn_mean[2];
-  const float* bn_invstd[2];
-  float* bn_partial[2];     // [gridM][2][N] each
-  long long src_img_stride;
-  int src_row_stride, src_pix_stride;
-  int M, N;
-  int OH, OW, IH, IW;
-  int KC;                  // K elements per tap
-  int ntaps, KW;
-  int stride, pad;
-  int quad;
-  int relu;
-  int gridM, gridN;
-  // destination row mapping (0 = dense): row m = (img, oh, ow) of the OHxOW grid is written to
-  // pixel (oh*dst_sub + dst_oh, ow*dst_sub + dst_ow) of a dst_h x dst_w image
-  int dst_sub, dst_h, dst_w, dst_oh, dst_ow;
-  FastDiv div_ohw, div_ow;
-};
+using qtc::ConvArgs;
 
 constexpr int kRowBytes = 128;  // bytes of K per row per K-step
 // s_setprio 1 around a K-step's MFMA block: with two workgroups per CU the wave that has its fragments goes
@@ -658,6 +629,11 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   if (qt_stem_eligible(d, nullptr)) return qt_stem_stats_rows(d);
   const long long M = (long long)d->batch * (d->mode == QT_CONV_FWD ? qt_quad_regions(d->quad) : 1) * d->out_h * d->out_w;
   const int esz = d->dtype == QT_F32 ? 4 : 2;
+  {
+    ConvArgs a = {};
+    a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride;
+    if (qt_pp_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_cdiv(M, qt_pp_tile_m(a, d->dtype));
+  }
   return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
 }
 
@@ -728,5 +704,6 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
                                    (d->out_w - 1) * d->dst_sub + d->dst_off_w < d->dst_w),
                "qt_conv2d_igemm: bad destination mapping");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (qt_pp_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pp_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
   return d->dtype == QT_F32 ? dispatch<float>(d, a, s) : dispatch<bf16_t>(d, a, s);
 }
