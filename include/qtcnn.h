@@ -9,7 +9,7 @@
  *   - plain C types only; every pointer is a DEVICE pointer unless it says "host";
  *   - the caller owns every buffer (including workspaces); the library allocates
  *     nothing persistent on the device.  Process-wide state is limited to (i) the
- *     kernel-selection switches qt_set_patch_conv / qt_set_pp_conv / qt_set_stem_conv /
+ *     kernel-selection switches qt_set_patch_conv / qt_set_pt_conv / qt_set_stem_conv /
  *     qt_set_wgrad_patch_min_width and the QTCNN_* environment variables they mirror
  *     (read once; DESIGN.md section 5 lists them) -- they pick between kernels that
  *     compute the same result, set them before the first launch -- and (ii) the
@@ -113,12 +113,13 @@ typedef struct qt_conv_io {
  * one-tile-per-workgroup kernel is experimental), 2 (default) only the persistent sliding-ring
  * kernel for the 56x56 64->64 bf16 layers. */
 void qt_set_patch_conv(int mode);
-/* Long stride-1 convolutions (>= 128 output channels, >= 8192 pixels, >= 8 K-tiles: the 3x3 convs of layer2..4, forward
- * and data gradient, the quadrant conv, the per-class gathers of the stride-2 data gradients) take the 8-wave ping-pong
- * kernel (csrc/conv_pp.hip: 256-pixel tiles, LDS-DMA ring with 2-3 K-tiles in flight, the two wave groups of a
- * workgroup half a period apart).  1 (default) on, 0 generic implicit GEMM.  Same results either way (same MFMA, same
- * K order); qt_conv2d_stats_rows follows the choice. */
-void qt_set_pp_conv(int mode);
+/* 3x3 / stride 1 / pad 1 convolutions on dense 28x28, 14x14 and 7x7 maps with >= 16 images and a multiple of 128 output
+ * channels (the twelve such convs of layer2..4, forward and data gradient) take the patch-resident ping-pong kernel
+ * (csrc/conv_pt.hip: 196-pixel tiles of whole image rows, input patch + halo of a 128-byte channel chunk in LDS for all
+ * nine taps, weight tiles streamed through an LDS-DMA ring, two wave groups half a period apart).  1 (default) on,
+ * 0 generic implicit GEMM.  Same arithmetic (f32 accumulation on MFMA) in a different K order: chunk-major, tap-minor;
+ * qt_conv2d_stats_rows follows the choice (one row per 196-pixel tile). */
+void qt_set_pt_conv(int mode);
 /* The packed bf16 stem convolution (desc of qt_pack_stem_input: kh 7|8, kw 1, stride 2, k_per_tap 32,
  * 64 outputs, no residual / mask / bwd_bn) takes a dedicated kernel (csrc/conv_stem.hip: input
  * rows of a 4 x 112 pixel tile in LDS, filter in registers, one partial-statistics row per

@@ -1,5 +1,5 @@
 // Arguments shared by the implicit-GEMM convolution kernels (conv_igemm.hip: generic tiles;
-// conv_pp.hip: the 8-wave ping-pong kernel for the long 3x3 layers).
+// conv_pt.hip: the patch-resident ping-pong kernel for the 3x3 layers of layer2..4).
 #pragma once
 #include "qt_common.h"
 
@@ -38,7 +38,8 @@ struct ConvArgs {
 
 }  // namespace qtc
 
-// conv_pp.hip: does the ping-pong kernel take this problem, with which pixel-tile height, and its launch
-bool qt_pp_eligible(const qtc::ConvArgs& a, int dtype, bool dgrad);
-int qt_pp_tile_m(const qtc::ConvArgs& a, int dtype);
-int qt_pp_launch(const qtc::ConvArgs& a, int dtype, bool dgrad, hipStream_t stream);
+// conv_pt.hip (3x3 stride-1 convolutions of the 28x28 / 14x14 / 7x7 stages: input patch resident in LDS, ping-pong MFMA
+// schedule): does it take this problem, how many statistics rows (= pixel tiles) it writes, and its launch
+bool qt_pt_eligible(const qtc::ConvArgs& a, int dtype);
+int qt_pt_stats_rows(const qtc::ConvArgs& a);
+int qt_pt_launch(const qtc::ConvArgs& a, int dtype, bool dgrad, hipStream_t stream);

@@ -632,7 +632,9 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   {
     ConvArgs a = {};
     a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride;
-    if (qt_pp_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_cdiv(M, qt_pp_tile_m(a, d->dtype));
+    a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.dst_sub = d->dst_sub;
+    a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
+    if (qt_pt_eligible(a, d->dtype)) return qt_pt_stats_rows(a);
   }
   return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
 }
@@ -704,6 +706,6 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
                                    (d->out_w - 1) * d->dst_sub + d->dst_off_w < d->dst_w),
                "qt_conv2d_igemm: bad destination mapping");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (qt_pp_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pp_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
+  if (qt_pt_eligible(a, d->dtype)) return qt_pt_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
   return d->dtype == QT_F32 ? dispatch<float>(d, a, s) : dispatch<bf16_t>(d, a, s);
 }

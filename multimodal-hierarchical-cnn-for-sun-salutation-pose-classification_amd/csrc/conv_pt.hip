@@ -1,0 +1,523 @@
+// 3x3 / stride-1 convolution of the 28x28, 14x14 and 7x7 stages (layer2..4 of the ResNet-18 stack, forward and
+// data gradient) with the INPUT PATCH RESIDENT IN LDS and a ping-pong MFMA schedule.
+//
+// Replaces the same ATen calls as conv_igemm.hip (conv2d forward / backward-input reached from
+// /root/reference/Quadtree_from scratch/models.py:222-243,289 and Quadtree_train.py:65).
+//
+// What bounds the implicit GEMM (conv_igemm.hip, and the ping-pong variant of it measured in round 2):
+// a CU moves ~65-70 GB/s from L2 into LDS, and an implicit GEMM stages every input pixel once PER TAP:
+// 128x128 tiles 64 FLOP per staged byte, 256x128 tiles 85 -> 4.5-6 TFLOP/s per CU however the MFMAs are scheduled.
+// Here a workgroup owns 196 output pixels that form whole image rows --
+//     28x28 maps: a quarter image (7 rows),   14x14: one image,   7x7: four images
+// (256 images -> exactly 1024 / 256 / 64 pixel tiles: every CU busy, no ragged last round) -- and keeps their input
+// patch (rows + halo, zero rows for the padding) for one 128-byte channel chunk in LDS: all nine taps read it at a
+// constant row shift.  Per K-tile (one tap of one chunk) only the weight tile is staged (+ 1/9 of the next patch):
+// 196x256 outputs: 176 FLOP/B, 196x128: 160 FLOP/B.  The MFMA pipe becomes the bound.
+//
+// Schedule (as the ring kernels of MI355X_MICROARCH.md, two wave groups instead of loader / consumer waves):
+// 8 waves = 2 pixel halves x 4 channel quarters; waves 0-3 (group 0) and 4-7 (group 1) share the SIMDs pairwise and run
+// the same program one barrier apart: while one group issues the MFMAs of K-tile t the other issues LDS-DMA (weight
+// tile t+D, one 64-row pass of the next chunk's patch) and reads its fragments of K-tile t.  Counted vmcnt waits keep
+// D = 2..3 weight tiles and the patch passes in flight across the raw s_barriers.
+//   group 0:  b0 | L0 | b1 | C0 | b2 | L1 | b3 | C1 | ...
+//   group 1:  b0 |    | b1 | L0 | b2 | C0 | b3 | L1 | ...
+//   RAW  a wave waits for ITS DMA of weight tile t+1 (and of everything older: vmcnt is in issue order, the patch passes
+//        of the next chunk are older than its first weight tile) at the end of L_t, before a barrier; group 0 reads
+//        K-tile t after b_2t, by which both groups have passed such a wait;
+//   WAR  weight tile t+D lands in the slot of tile t-1, patch chunk c+1 in the buffer of chunk c-1; both are issued
+//        after b_2t / b_18c, and the last reads of the old contents (group 1's L_{t-1}) were retired by lgkmcnt(0)
+//        before that barrier.
+// The epilogue runs straight from the accumulators (the weight rows are staged permuted so that a lane owns eight
+// consecutive channels of a pixel): no LDS round trip.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_args.h"
+
+namespace {
+
+using qtc::ConvArgs;
+
+constexpr int kNT = 512;        // 8 waves: two per SIMD, one of each group
+constexpr int kKB = 128;        // bytes of K per row and K-tile (one channel chunk)
+constexpr int kTM = 7;          // 16-pixel tiles per wave: 2 wave rows x 7 x 16 = 224 rows, 196 valid
+constexpr int kPix = 196;       // output pixels per workgroup
+constexpr int kMaxPass = 6;     // 64-row DMA passes of a patch (<= 384 positions)
+
+struct PtArgs {
+  ConvArgs c;
+  int G, R, W, H;               // sub-images per tile, rows per sub-image part, image width / height
+  int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
+  int tpi, tiles_m, batch;      // pixel tiles per image (G == 1), pixel tiles in all, images
+  int nchunks;                  // 128-byte channel chunks of the source
+  FastDiv div_rw, div_w, div_pp, div_pw;
+};
+
+// eight consecutive elements as loaded (decoded to f32 only where they are consumed)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 u;
+  __device__ __forceinline__ void load(const bf16_t* p) { u = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&f)[8]) const {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const float4*>(p);
+    b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ __forceinline__ void get(float (&f)[8]) const {
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+};
+
+// DMA instructions a wave issues in the L segment of tap `tp` (-1: tap 8 of the previous chunk, or the prologue's last
+// weight tile): one patch pass of the next chunk on the first NPASS taps (never in the last chunk) + RW for weight tile
+// t+D (not on the last D taps of the last chunk)
+template <int NPASS, int RW, int D>
+constexpr int issued_in(int tp, bool last) {
+  if (tp < 0) return RW;
+  return ((!last && tp < NPASS) ? 1 : 0) + ((!last || tp + D < 9) ? RW : 0);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose counter is a constant expression
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+template <typename T, int BN, int NBW, int NPASS, bool DGRAD>
+__global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
+  static_assert(NPASS >= 1 && NPASS <= kMaxPass && NPASS - 1 <= 9 - (NBW - 1),
+                "the last patch pass is issued no later than (and, in its L segment, before) weight tile 0 of the next chunk");
+  static_assert(BN == 128 || BN == 256, "channel tile");
+  static_assert(NBW == 3 || NBW == 4, "weight ring slots");
+  constexpr int TM = kTM;
+  constexpr int TN = BN / 4 / 16;           // 16-channel tiles per wave (4 channel quarters)
+  constexpr int NP = TN / 2;                // pairs of them = 32-channel groups
+  constexpr int RW = BN / 64;               // LDS-DMA instructions per wave and weight tile (64 rows per pass)
+  constexpr int D = NBW - 1;                // weight tiles in flight
+  constexpr int BK = kKB / (int)sizeof(T);  // K elements per chunk
+  constexpr int WSLOT = BN * kKB;           // bytes of a weight ring slot
+  static_assert(TN % 2 == 0 && TN >= 2, "a wave owns whole 32-channel groups");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvArgs& p = q.c;
+
+  const T* __restrict__ src = static_cast<const T*>(p.src);
+  const T* __restrict__ wgt = static_cast<const T*>(p.wgt);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;               // waves w and w+4 share a SIMD: one of each group per SIMD
+  const int wm = grp, wn = wave & 3;       // pixel half, channel quarter
+  const int frow = lane & 15, fk = lane >> 4;
+
+  // consecutive logical ids share an XCD (its L2): 32 pixel tiles of ONE channel tile -> one weight slice per XCD
+  const int nblk = q.tiles_m * p.gridN;
+  const int bid = qt_xcd_remap(blockIdx.x, nblk);
+  const int nt = bid / q.tiles_m, mt = bid - nt * q.tiles_m;
+  const int n0 = nt * BN;
+  // the tile's images: G == 1: part (mt % tpi) of image mt / tpi;  G > 1: images mt*G .. mt*G + G-1, whole
+  const int img0 = q.G == 1 ? mt / q.tpi : mt * q.G;
+  const int row0 = q.G == 1 ? (mt - img0 * q.tpi) * q.R : 0;
+
+  constexpr int patch_bytes = NPASS * 64 * kKB;
+  const unsigned smem_base = lds_addr_of(smem);
+  const unsigned wring = smem_base + 2 * patch_bytes;
+  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
+
+  // ---- per-thread staging rows -------------------------------------------------
+  // a DMA wave instruction fills 8 rows x 128 B, lane-linear; LDS slot (lane & 7) of row r receives source chunk
+  // (lane & 7) ^ (r & 7), the fragment reads apply the same XOR (conflict-free ds_read_b128)
+  const int rbase = tid >> 3;                         // row inside a 64-row pass
+  const int chunk = (tid & 7) ^ (rbase & 7);          // source 16-byte chunk of this lane (64 | pass stride)
+  const int ce = chunk * (16 / (int)sizeof(T));       // ... in elements
+  // patch position i*64 + rbase of pass i: sub-image, patch row / column -> source pixel or the zero page
+  // (32-bit element offsets from `src`, -1 = zero page: the tensor has < 2^31 elements, checked by the launcher)
+  int pp_off[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    pp_off[i] = -1;
+    const int pos = i * 64 + rbase;
+    if (pos < q.npos) {
+      const unsigned s = fdiv((unsigned)pos, q.div_pp);
+      const unsigned rem = (unsigned)pos - s * (unsigned)q.PP;
+      const unsigned pr = fdiv(rem, q.div_pw);
+      const unsigned pc = rem - pr * (unsigned)q.PW;
+      const int ir = row0 + (int)pr - 1, ic = (int)pc - 1, img = img0 + (int)s;
+      if ((unsigned)ir < (unsigned)q.H && (unsigned)ic < (unsigned)q.W && img < q.batch)
+        pp_off[i] = (int)((long long)img * p.src_img_stride + (long long)ir * p.src_row_stride +
+                          (long long)ic * p.src_pix_stride) + ce;
+    }
+  }
+  // LDS weight row rho = 32*g + 16*i + x holds output channel 32*g + 8*(x>>2) + 4*i + (x&3): a lane's two 16x16
+  // tiles (i = 0, 1) of a 32-channel group then own eight consecutive channels 8*fk .. 8*fk+7 of a pixel
+  int w_off[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int rho = rbase + 64 * i;
+    const int x = rho & 15, ii = (rho >> 4) & 1;
+    const int n = n0 + (rho & ~31) + 8 * (x >> 2) + 4 * ii + (x & 3);
+    w_off[i] = n * (9 * p.KC) + ce;    // N % BN == 0 (checked by the launcher)
+  }
+
+  // rows [pass*64, pass*64+64) of chunk cidx into patch buffer cidx & 1 (`off` = this thread's pp_off[pass])
+  auto dma_patch_pass = [&](int pass, int off, int cidx) {
+    const T* g = off >= 0 ? src + (off + cidx * BK) : zero_src;
+    glds16(g, smem_base + (cidx & 1) * patch_bytes + pass * (64 * kKB) + wave * 1024);
+  };
+  auto dma_weights = [&](int tap, int cidx, int slot) {
+    const unsigned sw = wring + slot * WSLOT + wave * 1024;
+    const int off = tap * p.KC + cidx * BK;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) glds16(wgt + (w_off[i] + off), sw + i * (64 * kKB));
+  };
+
+  // ---- per-lane fragment addressing ------------------------------------------------
+  // pixel rows of this lane: m = wm*112 + j*16 + frow; its patch row for tap (0,0) is p0 = s*PP + r*PW + c
+  int a_base[TM];     // p0 * 128 (bytes)
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = wm * (TM * 16) + j * 16 + frow;
+    a_base[j] = 0;
+    if (m < kPix) {
+      const unsigned s = fdiv((unsigned)m, q.div_rw);
+      const unsigned rem = (unsigned)m - s * (unsigned)(q.R * q.W);
+      const unsigned r = fdiv(rem, q.div_w);
+      const unsigned c = rem - r * (unsigned)q.W;
+      a_base[j] = (int)(s * (unsigned)q.PP + r * (unsigned)q.PW + c) * kKB;
+    }
+  }
+  int b_off[2];       // lane part of a weight-fragment address: row frow, chunk (kk*4 + fk) ^ (frow & 7)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) b_off[kk] = (wn * (BN / 4) + frow) * kKB + (((kk * 4 + fk) ^ (frow & 7)) << 4);
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: patch of chunk 0, D weight tiles; everything older than weight tile 1 landed ----
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) dma_patch_pass(i, pp_off[i], 0);
+#pragma unroll
+  for (int s = 0; s < D; ++s) dma_weights(s, 0, s);   // (D < 9: all in chunk 0)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RW * (D - 1)) : "memory");
+  if (grp == 1) asm volatile("s_barrier" ::: "memory");
+
+  int rd = 0, wr = D;                       // weight ring slots
+  // One channel chunk = nine K-tiles (taps), unrolled: the tap's row shift, the patch pass that rides on it and the
+  // counted wait are compile-time.  DMA instructions a wave issues in L_t: one patch pass of the NEXT chunk on taps
+  // 0 .. NPASS-1 (not in the last chunk) + RW for weight tile t+D (not on the last D K-tiles of the last chunk).
+  auto chunk_body = [&](int cidx, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const unsigned char* patch = smem + (cidx & 1) * patch_bytes;
+    static_for<9>([&](auto tap_tag) {
+      constexpr int tap = decltype(tap_tag)::value;
+      // ---- L_t ----
+      if (!LAST && tap < NPASS) dma_patch_pass(tap, pp_off[tap < NPASS ? tap : 0], cidx + 1);
+      if (!LAST || tap + D < 9) dma_weights((tap + D) % 9, cidx + (tap + D) / 9, wr);
+      wr = wr + 1 == NBW ? 0 : wr + 1;
+      // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
+      const int kh = tap / 3, kw = tap % 3;
+      int sh = (DGRAD ? ((2 - kh) * q.PW + (2 - kw)) : (kh * q.PW + kw)) * kKB;   // bytes
+      // (opaque to the optimiser: otherwise the 7 x 9 fragment addresses, invariant across chunks, are hoisted out
+      // of the chunk loop and 63 live registers spill the accumulators)
+      asm volatile("" : "+s"(sh));
+      const unsigned char* pa = patch + sh;
+      const unsigned char* pw = smem + 2 * patch_bytes + rd * WSLOT;
+      rd = rd + 1 == NBW ? 0 : rd + 1;
+      uint4 fw[2][TN], fa[2][TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
+        fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int rowb = a_base[j] + sh;
+        const int a0 = a_base[j] + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
+        fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0);
+        fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64));
+      }
+      // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
+      // L_{t+2-D} .. L_t (vmcnt retires in issue order; at a chunk boundary this also covers the next patch, whose
+      // last pass was issued on tap NPASS-1 < 9-D, i.e. before weight tile t+1 of tap 8).
+      constexpr int allowed = issued_in<NPASS, RW, D>(tap, LAST) + (D == 3 ? issued_in<NPASS, RW, D>(tap - 1, LAST) : 0);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(allowed) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C_t ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[kk][i], fa[kk][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+    });
+  };
+  for (int cidx = 0; cidx + 1 < q.nchunks; ++cidx) chunk_body(cidx, std::false_type{});
+  chunk_body(q.nchunks - 1, std::true_type{});
+  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (group 1's last MFMA segment)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all reads done before the epilogue reuses LDS
+
+  // ---- epilogue: straight from the accumulators ------------------------------------------------
+  // a lane's two 16x16 tiles (i = 2*pi, 2*pi+1) hold EIGHT consecutive channels c0 .. c0+7 of one pixel,
+  // c0 = wave's first channel + pi*32 + fk*8: one 16-byte (bf16) access per lane and operand.
+  T* __restrict__ dst = static_cast<T*>(p.dst);
+  const T* __restrict__ res = static_cast<const T*>(p.residual);
+  const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  const bool bwd_stats = p.bn_y[0] != nullptr;
+  const bool want_stats = p.stats_partial != nullptr || bwd_stats;
+  float* red = reinterpret_cast<float*>(smem);   // [2][BN][3] per-wave-row sums (the ring is dead: barrier above)
+  int drow[TM];       // destination row (dense pixel index) of this lane's pixels, -1: none
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = wm * (TM * 16) + j * 16 + frow;
+    drow[j] = -1;
+    if (m < kPix) {
+      const unsigned s = fdiv((unsigned)m, q.div_rw);
+      const unsigned rem = (unsigned)m - s * (unsigned)(q.R * q.W);
+      const unsigned r = fdiv(rem, q.div_w);
+      const unsigned c = rem - r * (unsigned)q.W;
+      const int img = img0 + (int)s;
+      if (img < q.batch) drow[j] = (img * q.H + row0 + (int)r) * q.W + (int)c;
+    }
+  }
+#pragma unroll
+  for (int pi = 0; pi < NP; ++pi) {
+    const int cl = wn * (BN / 4) + pi * 32 + fk * 8;   // channel inside the tile
+    const int c0 = n0 + cl;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = p.scale ? p.scale[c0 + e] : 1.f;
+      sh[e] = p.shift ? p.shift[c0 + e] : 0.f;
+    }
+    float mu0[8], is0[8], mu1[8], is1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu0[e] = bwd_stats ? p.bn_mean[0][c0 + e] : 0.f;
+      is0[e] = bwd_stats ? p.bn_invstd[0][c0 + e] : 0.f;
+      mu1[e] = p.bn_y[1] ? p.bn_mean[1][c0 + e] : 0.f;
+      is1[e] = p.bn_y[1] ? p.bn_invstd[1][c0 + e] : 0.f;
+    }
+    float s1[8], s2[8], s3[8];  // forward: sum v, sum v^2;  backward: sum g, sum g*xhat0, sum g*xhat1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
+    // pixel tiles in batches: the batch's memory operands are requested before its first row is finished
+    constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? 2 : 4) : 1;   // (BN == 256: 112 accumulator registers are live)
+#pragma unroll
+    for (int jb = 0; jb < TM; jb += JB) {
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of later batches from being hoisted over this one)
+      Raw8<T> rres[JB], rmsk[JB], ry0[JB], ry1[JB];
+      bool ok[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        ok[u] = jb + u < TM && drow[jb + u < TM ? jb + u : 0] >= 0;
+        if (ok[u]) {
+          const long long off = (long long)drow[jb + u] * p.N + c0;
+          if (res) rres[u].load(res + off);
+          if (msk) rmsk[u].load(msk + off);
+          if (bwd_stats) ry0[u].load(static_cast<const T*>(p.bn_y[0]) + off);
+          if (p.bn_y[1]) ry1[u].load(static_cast<const T*>(p.bn_y[1]) + off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        if (jb + u >= TM) continue;
+        const int j = jb + u;
+        float v[8] = {acc[2 * pi][j][0],     acc[2 * pi][j][1],     acc[2 * pi][j][2],     acc[2 * pi][j][3],
+                      acc[2 * pi + 1][j][0], acc[2 * pi + 1][j][1], acc[2 * pi + 1][j][2], acc[2 * pi + 1][j][3]};
+        if (!ok[u]) continue;
+        const long long off = (long long)drow[j] * p.N + c0;
+        if (!bwd_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += v[e];
+            s2[e] += v[e] * v[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res) {
+          float rv[8];
+          rres[u].get(rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (msk) {
+          float mv[8];
+          rmsk[u].get(mv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+        }
+        QtVec8<T>::store(dst + off, v);
+        if (bwd_stats) {
+          float yv[8];
+          ry0[u].get(yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += v[e];
+            s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
+          }
+          if (p.bn_y[1]) {
+            ry1[u].get(yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
+          }
+        }
+      }
+    }
+    if (want_stats) {
+      // sum over the 16 pixels (lanes with equal fk) of the wave, fixed butterfly order -> deterministic
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) {
+          s1[e] += __shfl_xor(s1[e], sft);
+          s2[e] += __shfl_xor(s2[e], sft);
+          s3[e] += __shfl_xor(s3[e], sft);
+        }
+      }
+      if (frow == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[(wm * BN + cl + e) * 3 + 0] = s1[e];
+          red[(wm * BN + cl + e) * 3 + 1] = s2[e];
+          red[(wm * BN + cl + e) * 3 + 2] = s3[e];
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BN) {
+      const float a = red[tid * 3 + 0] + red[(BN + tid) * 3 + 0];   // fixed order over the two wave rows
+      const float b = red[tid * 3 + 1] + red[(BN + tid) * 3 + 1];
+      const float c = red[tid * 3 + 2] + red[(BN + tid) * 3 + 2];
+      float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
+      o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
+      o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
+      if (bwd_stats && p.bn_y[1]) {
+        p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
+        p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
+      }
+    }
+  }
+}
+
+// geometry of the 196-pixel tiles for an H x W image; false: shape not covered
+bool pt_geometry(int H, int W, PtArgs& q) {
+  if (H == 28 && W == 28) { q.G = 1; q.R = 7; }
+  else if (H == 14 && W == 14) { q.G = 1; q.R = 14; }
+  else if (H == 7 && W == 7) { q.G = 4; q.R = 7; }
+  else return false;
+  q.H = H; q.W = W;
+  q.PW = W + 2;
+  q.PP = (q.R + 2) * q.PW;
+  q.npos = q.G * q.PP;
+  q.npass = (q.npos + 63) / 64;
+  q.tpi = q.G == 1 ? H / q.R : 0;
+  q.div_rw = make_fastdiv((unsigned)(q.R * W));
+  q.div_w = make_fastdiv((unsigned)W);
+  q.div_pp = make_fastdiv((unsigned)q.PP);
+  q.div_pw = make_fastdiv((unsigned)q.PW);
+  return q.npass >= 4 && q.npass <= kMaxPass;
+}
+inline int pt_tiles_m(const PtArgs& q, int batch) { return q.G == 1 ? batch * q.tpi : (batch + q.G - 1) / q.G; }
+// (a 256-channel tile -- 7 x 4 accumulator tiles per wave -- was built: 245 registers, and the compiler spills inside the
+// unrolled tap loop; 128 channels everywhere: 2 x 256 tiles on the 14x14 stage, still whole rounds)
+inline int pt_bn(const ConvArgs&) { return 128; }
+
+template <typename T, int BN, int NBW, int NPASS, bool DGRAD>
+int launch(PtArgs q, hipStream_t stream) {
+  constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, DGRAD>;
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
+  q.c.gridN = q.c.N / BN;
+  q.c.gridM = q.tiles_m;
+  hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.c.gridN), dim3(kNT), lds, stream, q);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+template <typename T, bool DGRAD>
+int dispatch(const PtArgs& q, hipStream_t stream) {
+  switch (q.npass) {   // 14x14: 256 patch positions, 28x28 quarter: 270, 4 x 7x7: 324
+    case 4: return launch<T, 128, 4, 4, DGRAD>(q, stream);
+    case 5: return launch<T, 128, 4, 5, DGRAD>(q, stream);
+    case 6: return launch<T, 128, 4, 6, DGRAD>(q, stream);
+  }
+  qt_set_error("conv_pt: %d patch passes not instantiated", q.npass);
+  return QT_ERR_UNSUPPORTED;
+}
+
+// 0: off, 1: on (default).  QTCNN_PT_CONV / qt_set_pt_conv: same-box A/B against the generic kernel.
+int g_pt_enabled = -1;
+inline int pt_enabled() {
+  if (g_pt_enabled < 0) {
+    const char* e = getenv("QTCNN_PT_CONV");
+    g_pt_enabled = e ? atoi(e) : 1;
+  }
+  return g_pt_enabled;
+}
+
+}  // namespace
+
+extern "C" void qt_set_pt_conv(int mode) { g_pt_enabled = mode < 0 ? 1 : mode; }
+
+// `batch` = images (a.M / (OH*OW)); the descriptor must be a dense 3x3 / stride 1 / pad 1 convolution
+bool qt_pt_eligible(const ConvArgs& a, int dtype) {
+  if (!pt_enabled()) return false;
+  const int esz = dtype == QT_F32 ? 4 : 2;
+  if (a.ntaps != 9 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.quad || a.dst_sub) return false;
+  if (a.OH != a.IH || a.OW != a.IW) return false;
+  PtArgs q;
+  if (!pt_geometry(a.OH, a.OW, q)) return false;
+  if ((a.KC * esz) % kKB != 0 || a.N % 128 != 0) return false;
+  if (a.M % (a.OH * a.OW) != 0) return false;
+  if ((long long)a.M * a.KC >= (1ll << 31) || (long long)a.N * 9 * a.KC >= (1ll << 31)) return false;  // 32-bit offsets
+  const int batch = a.M / (a.OH * a.OW);
+  // dense NHWC source (the patch walks it with its own strides, but the launcher only has these three)
+  if (batch < 16) return false;   // a handful of tiles: the generic kernel's small tiles cover the chip better
+  return true;
+}
+
+int qt_pt_stats_rows(const ConvArgs& a) {
+  PtArgs q;
+  pt_geometry(a.OH, a.OW, q);
+  return pt_tiles_m(q, a.M / (a.OH * a.OW));
+}
+
+int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
+  PtArgs q;
+  q.c = a;
+  pt_geometry(a.OH, a.OW, q);
+  q.batch = a.M / (a.OH * a.OW);
+  q.tiles_m = pt_tiles_m(q, q.batch);
+  const int esz = dtype == QT_F32 ? 4 : 2;
+  q.nchunks = a.KC * esz / kKB;
+  if (dtype == QT_F32) return dgrad ? dispatch<float, true>(q, stream) : dispatch<float, false>(q, stream);
+  return dgrad ? dispatch<bf16_t, true>(q, stream) : dispatch<bf16_t, false>(q, stream);
+}

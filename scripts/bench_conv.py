@@ -149,19 +149,19 @@ if __name__ == "__main__" and which == "epi":   # generic implicit GEMM, layer2 
         bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True, H=H, C=C)
         bench_ring("dgrad + residual + mask + bn link", L.QT_CONV_DGRAD, residual=True, mask=True, link=True, H=H, C=C)
 
-if __name__ == "__main__" and which == "pp":   # ping-pong kernel against the generic one, same process, interleaved rounds
+if __name__ == "__main__" and which == "pt":   # patch-resident ping-pong kernel (conv_pt.hip) against the generic one, same process, interleaved rounds
     shapes = [("fwd", 28, 128, 128), ("fwd", 14, 256, 256), ("fwd", 7, 512, 512),
               ("dgrad", 28, 128, 128), ("dgrad", 14, 256, 256), ("dgrad", 7, 512, 512)]
     import io as _io, contextlib
     for rnd in range(2):
         for on in (1, 0):
-            L.lib().qt_set_pp_conv(on)
-            print(f"-- round {rnd} qt_set_pp_conv({on})", flush=True)
+            L.lib().qt_set_pt_conv(on)
+            print(f"-- round {rnd} qt_set_pt_conv({on})", flush=True)
             for kind, H, ci, co in shapes:
                 bench(kind, B, H, ci, co, 3, 1, 1)
-    L.lib().qt_set_pp_conv(1)
+    L.lib().qt_set_pt_conv(1)
     for (H, C) in ((28, 128), (14, 256), (7, 512)):
-        print("epilogues, pp kernel, H", H, "C", C)
+        print("epilogues, pt kernel, H", H, "C", C)
         bench_ring("fwd plain", L.QT_CONV_FWD, H=H, C=C)
         bench_ring("fwd + scale/shift + residual + relu", L.QT_CONV_FWD, residual=True, H=H, C=C)
         bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True, H=H, C=C)
