@@ -95,7 +95,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int BN, int NBW, int NPASS, bool DGRAD>
+template <typename T, int BN, int NBW, int NPASS, bool POS, bool DGRAD>
 __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   static_assert(NPASS >= 1 && NPASS <= kMaxPass && NPASS - 1 <= 9 - (NBW - 1),
                 "the last patch pass is issued no later than (and, in its L segment, before) weight tile 0 of the next chunk");
@@ -173,21 +173,30 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
 
   // rows [pass*64, pass*64+64) of chunk cidx into patch buffer cidx & 1 (`off` = this thread's pp_off[pass])
   auto dma_patch_pass = [&](int pass, int off, int cidx) {
-    const T* g = off >= 0 ? src + (off + cidx * BK) : zero_src;
+    int coff = cidx * BK;
+    asm volatile("" : "+s"(coff));
+    const T* g = off >= 0 ? src + (off + coff) : zero_src;
     glds16(g, smem_base + (cidx & 1) * patch_bytes + pass * (64 * kKB) + wave * 1024);
   };
   auto dma_weights = [&](int tap, int cidx, int slot) {
     const unsigned sw = wring + slot * WSLOT + wave * 1024;
-    const int off = tap * p.KC + cidx * BK;
+    int off = tap * p.KC + cidx * BK;
+    asm volatile("" : "+s"(off));   // (opaque: keeps 9 x RW per-tap pointers from being hoisted out of the chunk loop and spilled)
 #pragma unroll
     for (int i = 0; i < RW; ++i) glds16(wgt + (w_off[i] + off), sw + i * (64 * kKB));
   };
 
   // ---- per-lane fragment addressing ------------------------------------------------
   // pixel rows of this lane: m = wm*112 + j*16 + frow; its patch row for tap (0,0) is p0 = s*PP + r*PW + c
-  int a_base[TM];     // p0 * 128 (bytes)
+  // POS: the 224 tile rows are 224 consecutive PATCH POSITIONS of the output rows (row pitch PW = W + 2: positions with
+  // column >= W are pad columns, computed and discarded): row m reads patch row m + shift, 16-row tiles are 2 KB apart
+  // -> one address register per K sub-step, immediate offsets per tile.  Used where R * PW <= 224 (28x28: 7 x 30 = 210,
+  // 14x14: 14 x 16 = 224): no extra MFMA work, a fifth of the address arithmetic.
+  // !POS (7x7, four images): rows are the 196 pixels; per-tile base addresses.
+  const int a_lane = (wm * (TM * 16) + frow) * kKB;
+  int a_base[POS ? 1 : TM];     // p0 * 128 (bytes)
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
+  for (int j = 0; j < (POS ? 0 : TM); ++j) {
     const int m = wm * (TM * 16) + j * 16 + frow;
     a_base[j] = 0;
     if (m < kPix) {
@@ -244,12 +253,22 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
         fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
       }
+      if constexpr (POS) {
+        const int rowb = a_lane + sh;
+        const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // (adding 16 rows does not change row & 7)
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int rowb = a_base[j] + sh;
-        const int a0 = a_base[j] + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
-        fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0);
-        fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64));
+        for (int j = 0; j < TM; ++j) {
+          fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0 + j * (16 * kKB));
+          fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64) + j * (16 * kKB));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int rowb = a_base[j] + sh;
+          const int a0 = a_base[j] + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
+          fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0);
+          fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64));
+        }
       }
       // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
       // L_{t+2-D} .. L_t (vmcnt retires in issue order; at a chunk boundary this also covers the next patch, whose
@@ -289,7 +308,11 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   for (int j = 0; j < TM; ++j) {
     const int m = wm * (TM * 16) + j * 16 + frow;
     drow[j] = -1;
-    if (m < kPix) {
+    if constexpr (POS) {
+      const unsigned r = fdiv((unsigned)m, q.div_pw);
+      const unsigned c = (unsigned)m - r * (unsigned)q.PW;
+      if ((int)r < q.R && (int)c < q.W && img0 < q.batch) drow[j] = (img0 * q.H + row0 + (int)r) * q.W + (int)c;
+    } else if (m < kPix) {
       const unsigned s = fdiv((unsigned)m, q.div_rw);
       const unsigned rem = (unsigned)m - s * (unsigned)(q.R * q.W);
       const unsigned r = fdiv(rem, q.div_w);
@@ -446,13 +469,13 @@ bool pt_geometry(int H, int W, PtArgs& q) {
 inline int pt_tiles_m(const PtArgs& q, int batch) { return q.G == 1 ? batch * q.tpi : (batch + q.G - 1) / q.G; }
 // (a 256-channel tile -- 7 x 4 accumulator tiles per wave -- was built: 245 registers, and the compiler spills inside the
 // unrolled tap loop; 128 channels everywhere: 2 x 256 tiles on the 14x14 stage, still whole rounds)
-inline int pt_bn(const ConvArgs&) { return 128; }
+inline int pt_bn(const ConvArgs& a) { return (a.N % 256 == 0 && a.OH == 14) ? 256 : 128; }
 
-template <typename T, int BN, int NBW, int NPASS, bool DGRAD>
+template <typename T, int BN, int NBW, int NPASS, bool POS, bool DGRAD>
 int launch(PtArgs q, hipStream_t stream) {
   constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, DGRAD>;
+  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, POS, DGRAD>;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
   if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
   q.c.gridN = q.c.N / BN;
@@ -465,9 +488,11 @@ int launch(PtArgs q, hipStream_t stream) {
 template <typename T, bool DGRAD>
 int dispatch(const PtArgs& q, hipStream_t stream) {
   switch (q.npass) {   // 14x14: 256 patch positions, 28x28 quarter: 270, 4 x 7x7: 324
-    case 4: return launch<T, 128, 4, 4, DGRAD>(q, stream);
-    case 5: return launch<T, 128, 4, 5, DGRAD>(q, stream);
-    case 6: return launch<T, 128, 4, 6, DGRAD>(q, stream);
+    case 4:
+      if (pt_bn(q.c) == 256) return launch<T, 256, 3, 4, true, DGRAD>(q, stream);
+      return launch<T, 128, 4, 4, true, DGRAD>(q, stream);
+    case 5: return launch<T, 128, 4, 5, true, DGRAD>(q, stream);
+    case 6: return launch<T, 128, 4, 6, false, DGRAD>(q, stream);
   }
   qt_set_error("conv_pt: %d patch passes not instantiated", q.npass);
   return QT_ERR_UNSUPPORTED;
