@@ -51,6 +51,7 @@ struct PtArgs {
   int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
   int tpi, tiles_m, batch;      // pixel tiles per image (G == 1), pixel tiles in all, images
   int nchunks;                  // 128-byte channel chunks of the source
+  unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
   FastDiv div_rw, div_w, div_pp, div_pw;
 };
 
@@ -76,6 +77,53 @@ template <> struct Raw8<float> {
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
   }
 };
+
+// LDS-DMA through a buffer resource: 64 lanes x 16 B from  base + voff (per lane, bytes) + soff (wave-uniform)  to the
+// 1 KiB at LDS byte address `lds_addr`.  Lanes whose voff is outside [0, num_records) write ZEROS (hardware range check
+// of raw buffers; soff does not take part in it): halo rows and rows past the tensor need no second pointer, and a
+// transfer costs no vector instruction -- the per-lane offsets are loop invariants, tap / chunk offsets are scalar.
+// (Issued from inline asm, like glds16: the compiler neither counts it in vmcnt nor fences LDS reads with vmcnt(0).)
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+constexpr unsigned kOob = 0x80000000u;   // a per-lane offset no tensor here reaches (< 2 GiB, checked by the launcher)
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));   // stride 0: raw buffer
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;                                                  // 32-bit data format, no swizzle (gfx94x / gfx950)
+  return r;
+}
+__device__ __forceinline__ void blds16(const i32x4& rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+// two / four transfers 8 KiB apart in LDS (consecutive 64-row passes of a tile), M0 saved once
+__device__ __forceinline__ void blds16x2(const i32x4& rsrc, unsigned v0, unsigned v1, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory", "scc");
+}
+__device__ __forceinline__ void blds16x4(const i32x4& rsrc, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff,
+                                         unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory", "scc");
+}
 
 // DMA instructions a wave issues in the L segment of tap `tp` (-1: tap 8 of the previous chunk, or the prologue's last
 // weight tile): one patch pass of the next chunk on the first NPASS taps (never in the last chunk) + RW for weight tile
@@ -112,8 +160,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvArgs& p = q.c;
 
-  const T* __restrict__ src = static_cast<const T*>(p.src);
-  const T* __restrict__ wgt = static_cast<const T*>(p.wgt);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -134,7 +180,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   constexpr int patch_bytes = NPASS * 64 * kKB;
   const unsigned smem_base = lds_addr_of(smem);
   const unsigned wring = smem_base + 2 * patch_bytes;
-  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
 
   // ---- per-thread staging rows -------------------------------------------------
   // a DMA wave instruction fills 8 rows x 128 B, lane-linear; LDS slot (lane & 7) of row r receives source chunk
@@ -143,11 +188,11 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int chunk = (tid & 7) ^ (rbase & 7);          // source 16-byte chunk of this lane (64 | pass stride)
   const int ce = chunk * (16 / (int)sizeof(T));       // ... in elements
   // patch position i*64 + rbase of pass i: sub-image, patch row / column -> source pixel or the zero page
-  // (32-bit element offsets from `src`, -1 = zero page: the tensor has < 2^31 elements, checked by the launcher)
-  int pp_off[NPASS];
+  // (32-bit BYTE offsets from `src`; kOob = out of the buffer's range: the DMA writes zeros there)
+  unsigned pp_off[NPASS];
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
-    pp_off[i] = -1;
+    pp_off[i] = kOob;
     const int pos = i * 64 + rbase;
     if (pos < q.npos) {
       const unsigned s = fdiv((unsigned)pos, q.div_pp);
@@ -156,34 +201,34 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
       const unsigned pc = rem - pr * (unsigned)q.PW;
       const int ir = row0 + (int)pr - 1, ic = (int)pc - 1, img = img0 + (int)s;
       if ((unsigned)ir < (unsigned)q.H && (unsigned)ic < (unsigned)q.W && img < q.batch)
-        pp_off[i] = (int)((long long)img * p.src_img_stride + (long long)ir * p.src_row_stride +
-                          (long long)ic * p.src_pix_stride) + ce;
+        pp_off[i] = (unsigned)(((long long)img * p.src_img_stride + (long long)ir * p.src_row_stride +
+                                (long long)ic * p.src_pix_stride) + ce) * (unsigned)sizeof(T);
     }
   }
   // LDS weight row rho = 32*g + 16*i + x holds output channel 32*g + 8*(x>>2) + 4*i + (x&3): a lane's two 16x16
   // tiles (i = 0, 1) of a 32-channel group then own eight consecutive channels 8*fk .. 8*fk+7 of a pixel
-  int w_off[RW];
+  unsigned w_off[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
     const int rho = rbase + 64 * i;
     const int x = rho & 15, ii = (rho >> 4) & 1;
     const int n = n0 + (rho & ~31) + 8 * (x >> 2) + 4 * ii + (x & 3);
-    w_off[i] = n * (9 * p.KC) + ce;    // N % BN == 0 (checked by the launcher)
+    w_off[i] = (unsigned)(n * (9 * p.KC) + ce) * (unsigned)sizeof(T);    // N % BN == 0 (checked by the launcher)
   }
+  const i32x4 rs_src = make_rsrc(p.src, q.src_bytes), rs_wgt = make_rsrc(p.wgt, q.wgt_bytes);
 
   // rows [pass*64, pass*64+64) of chunk cidx into patch buffer cidx & 1 (`off` = this thread's pp_off[pass])
-  auto dma_patch_pass = [&](int pass, int off, int cidx) {
-    int coff = cidx * BK;
-    asm volatile("" : "+s"(coff));
-    const T* g = off >= 0 ? src + (off + coff) : zero_src;
-    glds16(g, smem_base + (cidx & 1) * patch_bytes + pass * (64 * kKB) + wave * 1024);
+  auto dma_patch_pass = [&](int pass, unsigned off, int cidx) {
+    int coff = cidx * (int)kKB;       // chunk offset in bytes
+    asm volatile("" : "+s"(coff));    // (opaque: keeps per-chunk address arithmetic out of the loop invariants)
+    blds16(rs_src, off, (unsigned)coff, smem_base + (cidx & 1) * patch_bytes + pass * (64 * kKB) + wave * 1024);
   };
   auto dma_weights = [&](int tap, int cidx, int slot) {
     const unsigned sw = wring + slot * WSLOT + wave * 1024;
-    int off = tap * p.KC + cidx * BK;
-    asm volatile("" : "+s"(off));   // (opaque: keeps 9 x RW per-tap pointers from being hoisted out of the chunk loop and spilled)
-#pragma unroll
-    for (int i = 0; i < RW; ++i) glds16(wgt + (w_off[i] + off), sw + i * (64 * kKB));
+    int off = (tap * p.KC) * (int)sizeof(T) + cidx * (int)kKB;
+    asm volatile("" : "+s"(off));
+    if constexpr (RW == 2) blds16x2(rs_wgt, w_off[0], w_off[1], (unsigned)off, sw);
+    else blds16x4(rs_wgt, w_off[0], w_off[1], w_off[2], w_off[3], (unsigned)off, sw);
   };
 
   // ---- per-lane fragment addressing ------------------------------------------------
@@ -522,7 +567,9 @@ bool qt_pt_eligible(const ConvArgs& a, int dtype) {
   if (!pt_geometry(a.OH, a.OW, q)) return false;
   if ((a.KC * esz) % kKB != 0 || a.N % 128 != 0) return false;
   if (a.M % (a.OH * a.OW) != 0) return false;
-  if ((long long)a.M * a.KC >= (1ll << 31) || (long long)a.N * 9 * a.KC >= (1ll << 31)) return false;  // 32-bit offsets
+  // 32-bit byte offsets below kOob
+  const long long img_elems = a.src_img_stride > 0 ? a.src_img_stride : (long long)a.IH * a.IW * a.KC;
+  if ((a.M / (a.OH * a.OW)) * img_elems * esz >= (1ll << 31) || (long long)a.N * 9 * a.KC * esz >= (1ll << 31)) return false;
   const int batch = a.M / (a.OH * a.OW);
   // dense NHWC source (the patch walks it with its own strides, but the launcher only has these three)
   if (batch < 16) return false;   // a handful of tiles: the generic kernel's small tiles cover the chip better
@@ -543,6 +590,9 @@ int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
   q.tiles_m = pt_tiles_m(q, q.batch);
   const int esz = dtype == QT_F32 ? 4 : 2;
   q.nchunks = a.KC * esz / kKB;
+  q.src_bytes = (unsigned)((((long long)q.batch - 1) * a.src_img_stride + ((long long)a.IH - 1) * a.src_row_stride +
+                            ((long long)a.IW - 1) * a.src_pix_stride + a.KC) * esz);
+  q.wgt_bytes = (unsigned)((long long)a.N * 9 * a.KC * esz);
   if (dtype == QT_F32) return dgrad ? dispatch<float, true>(q, stream) : dispatch<float, false>(q, stream);
   return dgrad ? dispatch<bf16_t, true>(q, stream) : dispatch<bf16_t, false>(q, stream);
 }

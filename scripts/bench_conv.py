@@ -166,3 +166,15 @@ if __name__ == "__main__" and which == "pt":   # patch-resident ping-pong kernel
         bench_ring("fwd + scale/shift + residual + relu", L.QT_CONV_FWD, residual=True, H=H, C=C)
         bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True, H=H, C=C)
         bench_ring("dgrad + residual + mask + bn link", L.QT_CONV_DGRAD, residual=True, mask=True, link=True, H=H, C=C)
+
+if __name__ == "__main__" and which == "pt1":   # few launches of the three stage shapes, patch-resident kernel on (PMC runs)
+    L.lib().qt_set_pt_conv(1)
+    for H, C in ((28, 128), (14, 256), (7, 512)):
+        dt = torch.bfloat16
+        d, Ho = desc(dt, L.QT_CONV_FWD, B, H, C, C, 3, 1, 1)
+        x = torch.randn(B, H, H, C, device=dev).to(dt); w = torch.randn(C, 9, C, device=dev).to(dt)
+        y = torch.empty(B * H * H, C, device=dev, dtype=dt)
+        io = L.ConvIO(L.ptr(x), L.ptr(w), L.ptr(y), None, None, None, None, None)
+        for _ in range(5):
+            L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()))
+        torch.cuda.synchronize()
