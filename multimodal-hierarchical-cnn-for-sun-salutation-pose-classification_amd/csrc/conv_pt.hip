@@ -41,18 +41,23 @@ using qtc::ConvArgs;
 
 constexpr int kNT = 512;        // 8 waves: two per SIMD, one of each group
 constexpr int kKB = 128;        // bytes of K per row and K-tile (one channel chunk)
-constexpr int kTM = 7;          // 16-pixel tiles per wave: 2 wave rows x 7 x 16 = 224 rows, 196 valid
-constexpr int kPix = 196;       // output pixels per workgroup
-constexpr int kMaxPass = 6;     // 64-row DMA passes of a patch (<= 384 positions)
+// Tile rows are PATCH POSITIONS (pad positions are computed and discarded), so a tap is one row shift for all rows and
+// 16-row tiles are a constant 2 KB apart: one fragment address per K sub-step.  196 output pixels per workgroup:
+//   GEO_ROWS   R rows of one W-wide image, row pitch PW = W + 2 (28x28: R = 7 -> 210 positions, 14x14: R = 14 -> 224):
+//              224 rows = 2 wave rows x 7 tiles;
+//   GEO_STACK  four 7x7 images, row pitch 8 (the right pad of a row is the left pad of the next), image pitch 64 (the
+//              bottom pad row of an image is the top pad row of the next): 256 rows = 2 x 8 tiles.
+enum { GEO_ROWS = 0, GEO_STACK = 1 };
+constexpr int kMaxPass = 5;     // 64-row DMA passes of a patch (<= 320 positions)
 
 struct PtArgs {
   ConvArgs c;
   int G, R, W, H;               // sub-images per tile, rows per sub-image part, image width / height
   int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
-  int tpi, tiles_m, batch;      // pixel tiles per image (G == 1), pixel tiles in all, images
+  int tpi, tiles_m, batch;      // pixel tiles per image (GEO_ROWS), pixel tiles in all, images
   int nchunks;                  // 128-byte channel chunks of the source
   unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
-  FastDiv div_rw, div_w, div_pp, div_pw;
+  FastDiv div_pw;
 };
 
 // eight consecutive elements as loaded (decoded to f32 only where they are consumed)
@@ -143,18 +148,17 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int BN, int NBW, int NPASS, bool POS, bool DGRAD>
+template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD>
 __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   static_assert(NPASS >= 1 && NPASS <= kMaxPass && NPASS - 1 <= 9 - (NBW - 1),
                 "the last patch pass is issued no later than (and, in its L segment, before) weight tile 0 of the next chunk");
   static_assert(BN == 128 || BN == 256, "channel tile");
   static_assert(NBW == 3 || NBW == 4, "weight ring slots");
-  constexpr int TM = kTM;
+  constexpr int TM = GEO == GEO_STACK ? 8 : 7;   // 16-row tiles per wave (two wave rows)
   constexpr int TN = BN / 4 / 16;           // 16-channel tiles per wave (4 channel quarters)
   constexpr int NP = TN / 2;                // pairs of them = 32-channel groups
   constexpr int RW = BN / 64;               // LDS-DMA instructions per wave and weight tile (64 rows per pass)
   constexpr int D = NBW - 1;                // weight tiles in flight
-  constexpr int BK = kKB / (int)sizeof(T);  // K elements per chunk
   constexpr int WSLOT = BN * kKB;           // bytes of a weight ring slot
   static_assert(TN % 2 == 0 && TN >= 2, "a wave owns whole 32-channel groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -173,9 +177,9 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int bid = qt_xcd_remap(blockIdx.x, nblk);
   const int nt = bid / q.tiles_m, mt = bid - nt * q.tiles_m;
   const int n0 = nt * BN;
-  // the tile's images: G == 1: part (mt % tpi) of image mt / tpi;  G > 1: images mt*G .. mt*G + G-1, whole
-  const int img0 = q.G == 1 ? mt / q.tpi : mt * q.G;
-  const int row0 = q.G == 1 ? (mt - img0 * q.tpi) * q.R : 0;
+  // the tile's images: GEO_ROWS: part (mt % tpi) of image mt / tpi;  GEO_STACK: images 4*mt .. 4*mt + 3, whole
+  const int img0 = GEO == GEO_ROWS ? mt / q.tpi : mt * 4;
+  const int row0 = GEO == GEO_ROWS ? (mt - img0 * q.tpi) * q.R : 0;
 
   constexpr int patch_bytes = NPASS * 64 * kKB;
   const unsigned smem_base = lds_addr_of(smem);
@@ -194,16 +198,21 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   for (int i = 0; i < NPASS; ++i) {
     pp_off[i] = kOob;
     const int pos = i * 64 + rbase;
-    if (pos < q.npos) {
-      const unsigned s = fdiv((unsigned)pos, q.div_pp);
-      const unsigned rem = (unsigned)pos - s * (unsigned)q.PP;
-      const unsigned pr = fdiv(rem, q.div_pw);
-      const unsigned pc = rem - pr * (unsigned)q.PW;
-      const int ir = row0 + (int)pr - 1, ic = (int)pc - 1, img = img0 + (int)s;
-      if ((unsigned)ir < (unsigned)q.H && (unsigned)ic < (unsigned)q.W && img < q.batch)
-        pp_off[i] = (unsigned)(((long long)img * p.src_img_stride + (long long)ir * p.src_row_stride +
-                                (long long)ic * p.src_pix_stride) + ce) * (unsigned)sizeof(T);
+    int ir, ic, img;
+    bool ok;
+    if constexpr (GEO == GEO_ROWS) {
+      const unsigned pr = fdiv((unsigned)pos, q.div_pw);
+      const unsigned pc = (unsigned)pos - pr * (unsigned)q.PW;
+      ir = row0 + (int)pr - 1; ic = (int)pc - 1; img = img0;
+      ok = pos < q.npos && (unsigned)ir < (unsigned)q.H && (unsigned)ic < (unsigned)q.W;
+    } else {
+      const int pr = (pos >> 3) & 7, pc = pos & 7;          // pr = 0 / pc = 0: shared pad row / column
+      ir = pr - 1; ic = pc - 1; img = img0 + (pos >> 6);
+      ok = pos < 256 && pr >= 1 && pc >= 1;                  // (positions 256..: the last image's bottom pad row)
     }
+    if (ok && img < q.batch)
+      pp_off[i] = (unsigned)(((long long)img * p.src_img_stride + (long long)ir * p.src_row_stride +
+                              (long long)ic * p.src_pix_stride) + ce) * (unsigned)sizeof(T);
   }
   // LDS weight row rho = 32*g + 16*i + x holds output channel 32*g + 8*(x>>2) + 4*i + (x&3): a lane's two 16x16
   // tiles (i = 0, 1) of a 32-channel group then own eight consecutive channels 8*fk .. 8*fk+7 of a pixel
@@ -233,25 +242,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
 
   // ---- per-lane fragment addressing ------------------------------------------------
   // pixel rows of this lane: m = wm*112 + j*16 + frow; its patch row for tap (0,0) is p0 = s*PP + r*PW + c
-  // POS: the 224 tile rows are 224 consecutive PATCH POSITIONS of the output rows (row pitch PW = W + 2: positions with
-  // column >= W are pad columns, computed and discarded): row m reads patch row m + shift, 16-row tiles are 2 KB apart
-  // -> one address register per K sub-step, immediate offsets per tile.  Used where R * PW <= 224 (28x28: 7 x 30 = 210,
-  // 14x14: 14 x 16 = 224): no extra MFMA work, a fifth of the address arithmetic.
-  // !POS (7x7, four images): rows are the 196 pixels; per-tile base addresses.
+  // row m of the tile reads patch row m + shift(tap); tiles of 16 rows are 2 KB apart (row & 7 unchanged)
   const int a_lane = (wm * (TM * 16) + frow) * kKB;
-  int a_base[POS ? 1 : TM];     // p0 * 128 (bytes)
-#pragma unroll
-  for (int j = 0; j < (POS ? 0 : TM); ++j) {
-    const int m = wm * (TM * 16) + j * 16 + frow;
-    a_base[j] = 0;
-    if (m < kPix) {
-      const unsigned s = fdiv((unsigned)m, q.div_rw);
-      const unsigned rem = (unsigned)m - s * (unsigned)(q.R * q.W);
-      const unsigned r = fdiv(rem, q.div_w);
-      const unsigned c = rem - r * (unsigned)q.W;
-      a_base[j] = (int)(s * (unsigned)q.PP + r * (unsigned)q.PW + c) * kKB;
-    }
-  }
   int b_off[2];       // lane part of a weight-fragment address: row frow, chunk (kk*4 + fk) ^ (frow & 7)
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) b_off[kk] = (wn * (BN / 4) + frow) * kKB + (((kk * 4 + fk) ^ (frow & 7)) << 4);
@@ -285,7 +277,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
       wr = wr + 1 == NBW ? 0 : wr + 1;
       // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
       const int kh = tap / 3, kw = tap % 3;
-      int sh = (DGRAD ? ((2 - kh) * q.PW + (2 - kw)) : (kh * q.PW + kw)) * kKB;   // bytes
+      const int pitch = GEO == GEO_STACK ? 8 : q.PW;
+      int sh = (DGRAD ? ((2 - kh) * pitch + (2 - kw)) : (kh * pitch + kw)) * kKB;   // bytes
       // (opaque to the optimiser: otherwise the 7 x 9 fragment addresses, invariant across chunks, are hoisted out
       // of the chunk loop and 63 live registers spill the accumulators)
       asm volatile("" : "+s"(sh));
@@ -298,21 +291,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
         fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
       }
-      if constexpr (POS) {
+      {
         const int rowb = a_lane + sh;
-        const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // (adding 16 rows does not change row & 7)
+        const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0 + j * (16 * kKB));
           fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64) + j * (16 * kKB));
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const int rowb = a_base[j] + sh;
-          const int a0 = a_base[j] + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
-          fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0);
-          fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64));
         }
       }
       // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
@@ -353,17 +338,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   for (int j = 0; j < TM; ++j) {
     const int m = wm * (TM * 16) + j * 16 + frow;
     drow[j] = -1;
-    if constexpr (POS) {
+    if constexpr (GEO == GEO_ROWS) {
       const unsigned r = fdiv((unsigned)m, q.div_pw);
       const unsigned c = (unsigned)m - r * (unsigned)q.PW;
       if ((int)r < q.R && (int)c < q.W && img0 < q.batch) drow[j] = (img0 * q.H + row0 + (int)r) * q.W + (int)c;
-    } else if (m < kPix) {
-      const unsigned s = fdiv((unsigned)m, q.div_rw);
-      const unsigned rem = (unsigned)m - s * (unsigned)(q.R * q.W);
-      const unsigned r = fdiv(rem, q.div_w);
-      const unsigned c = rem - r * (unsigned)q.W;
-      const int img = img0 + (int)s;
-      if (img < q.batch) drow[j] = (img * q.H + row0 + (int)r) * q.W + (int)c;
+    } else {
+      const int r = (m >> 3) & 7, c = m & 7, img = img0 + (m >> 6);
+      if (r < 7 && c < 7 && img < q.batch) drow[j] = (img * 7 + r) * 7 + c;
     }
   }
 #pragma unroll
@@ -500,27 +481,30 @@ bool pt_geometry(int H, int W, PtArgs& q) {
   else if (H == 7 && W == 7) { q.G = 4; q.R = 7; }
   else return false;
   q.H = H; q.W = W;
-  q.PW = W + 2;
-  q.PP = (q.R + 2) * q.PW;
-  q.npos = q.G * q.PP;
+  if (q.G == 1) {
+    q.PW = W + 2;
+    q.PP = (q.R + 2) * q.PW;
+    q.npos = q.PP;
+    q.tpi = H / q.R;
+  } else {                       // stacked 7x7 images: pitch 8 / 64, one more pad row and the wrap-around pad at the end
+    q.PW = 8;
+    q.PP = 64;
+    q.npos = 4 * 64 + 9;
+    q.tpi = 0;
+  }
   q.npass = (q.npos + 63) / 64;
-  q.tpi = q.G == 1 ? H / q.R : 0;
-  q.div_rw = make_fastdiv((unsigned)(q.R * W));
-  q.div_w = make_fastdiv((unsigned)W);
-  q.div_pp = make_fastdiv((unsigned)q.PP);
   q.div_pw = make_fastdiv((unsigned)q.PW);
-  return q.npass >= 4 && q.npass <= kMaxPass;
+  return q.npass == 4 || q.npass == 5;
 }
 inline int pt_tiles_m(const PtArgs& q, int batch) { return q.G == 1 ? batch * q.tpi : (batch + q.G - 1) / q.G; }
-// (a 256-channel tile -- 7 x 4 accumulator tiles per wave -- was built: 245 registers, and the compiler spills inside the
-// unrolled tap loop; 128 channels everywhere: 2 x 256 tiles on the 14x14 stage, still whole rounds)
+// 256-channel tiles where the channel count allows it and 256 pixel tiles still cover the chip (14x14: one per image)
 inline int pt_bn(const ConvArgs& a) { return (a.N % 256 == 0 && a.OH == 14) ? 256 : 128; }
 
-template <typename T, int BN, int NBW, int NPASS, bool POS, bool DGRAD>
+template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD>
 int launch(PtArgs q, hipStream_t stream) {
   constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, POS, DGRAD>;
+  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, GEO, DGRAD>;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
   if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
   q.c.gridN = q.c.N / BN;
@@ -532,12 +516,13 @@ int launch(PtArgs q, hipStream_t stream) {
 
 template <typename T, bool DGRAD>
 int dispatch(const PtArgs& q, hipStream_t stream) {
-  switch (q.npass) {   // 14x14: 256 patch positions, 28x28 quarter: 270, 4 x 7x7: 324
-    case 4:
-      if (pt_bn(q.c) == 256) return launch<T, 256, 3, 4, true, DGRAD>(q, stream);
-      return launch<T, 128, 4, 4, true, DGRAD>(q, stream);
-    case 5: return launch<T, 128, 4, 5, true, DGRAD>(q, stream);
-    case 6: return launch<T, 128, 4, 6, false, DGRAD>(q, stream);
+  if (q.G == 4) return launch<T, 128, 4, 5, GEO_STACK, DGRAD>(q, stream);            // 7x7: 265 patch positions
+  if (q.npass == 5) return launch<T, 128, 4, 5, GEO_ROWS, DGRAD>(q, stream);        // 28x28 quarter: 270
+  if (q.npass == 4) {                                                                // 14x14: 256
+    if constexpr (sizeof(T) == 2) {   // (the f32 instantiation of the 256-channel tile spills 8 registers: 128 there)
+      if (pt_bn(q.c) == 256) return launch<T, 256, 3, 4, GEO_ROWS, DGRAD>(q, stream);
+    }
+    return launch<T, 128, 4, 4, GEO_ROWS, DGRAD>(q, stream);
   }
   qt_set_error("conv_pt: %d patch passes not instantiated", q.npass);
   return QT_ERR_UNSUPPORTED;
