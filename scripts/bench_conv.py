@@ -178,3 +178,10 @@ if __name__ == "__main__" and which == "pt1":   # few launches of the three stag
         for _ in range(5):
             L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()))
         torch.cuda.synchronize()
+
+if __name__ == "__main__" and which == "pt3":   # forward of the three stage shapes with the patch-resident kernel (QTCNN_PT_DBG experiments)
+    L.lib().qt_set_pt_conv(1)
+    for _ in range(2):
+        bench("fwd", B, 28, 128, 128, 3, 1, 1)
+        bench("fwd", B, 14, 256, 256, 3, 1, 1)
+        bench("fwd", B, 7, 512, 512, 3, 1, 1)
