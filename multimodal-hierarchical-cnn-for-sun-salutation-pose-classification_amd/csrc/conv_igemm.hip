@@ -634,7 +634,8 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
     a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride;
     a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.dst_sub = d->dst_sub;
     a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
-    if (qt_pt_eligible(a, d->dtype)) return qt_pt_stats_rows(a);
+    a.src_img_stride = d->src_img_stride; a.src_row_stride = d->src_row_stride; a.src_pix_stride = d->src_pix_stride;
+    if (qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
   }
   return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
 }
@@ -706,6 +707,6 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
                                    (d->out_w - 1) * d->dst_sub + d->dst_off_w < d->dst_w),
                "qt_conv2d_igemm: bad destination mapping");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (qt_pt_eligible(a, d->dtype)) return qt_pt_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
+  if (qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
   return d->dtype == QT_F32 ? dispatch<float>(d, a, s) : dispatch<bf16_t>(d, a, s);
 }

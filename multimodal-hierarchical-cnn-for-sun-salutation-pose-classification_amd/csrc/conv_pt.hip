@@ -57,6 +57,10 @@ struct PtArgs {
   int tpi, tiles_m, batch;      // pixel tiles per image (GEO_ROWS), pixel tiles in all, images
   int nchunks;                  // 128-byte channel chunks of the source
   unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
+  // GEO_STACK on the 2x2 quadrants of 14x14 maps (the quadrant conv, Quadtree_from scratch/models.py:277-287): "image"
+  // n*4 + q is quadrant q of map n.  1: forward, the SOURCE is the un-split map (zero halo at the seam comes for free:
+  // the patch's pad positions); 2: data gradient, the DESTINATION is the un-split map.
+  int quad;
   FastDiv div_pw;
 };
 
@@ -210,9 +214,16 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
       ir = pr - 1; ic = pc - 1; img = img0 + (pos >> 6);
       ok = pos < 256 && pr >= 1 && pc >= 1;                  // (positions 256..: the last image's bottom pad row)
     }
-    if (ok && img < q.batch)
-      pp_off[i] = (unsigned)(((long long)img * p.src_img_stride + (long long)ir * p.src_row_stride +
+    if (ok && img < q.batch) {
+      long long simg = img;
+      if (GEO == GEO_STACK && q.quad == 1) {   // quadrant (img & 3) of map img >> 2
+        simg = img >> 2;
+        ir += ((img >> 1) & 1) * 7;
+        ic += (img & 1) * 7;
+      }
+      pp_off[i] = (unsigned)((simg * p.src_img_stride + (long long)ir * p.src_row_stride +
                               (long long)ic * p.src_pix_stride) + ce) * (unsigned)sizeof(T);
+    }
   }
   // LDS weight row rho = 32*g + 16*i + x holds output channel 32*g + 8*(x>>2) + 4*i + (x&3): a lane's two 16x16
   // tiles (i = 0, 1) of a 32-channel group then own eight consecutive channels 8*fk .. 8*fk+7 of a pixel
@@ -344,7 +355,10 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
       if ((int)r < q.R && (int)c < q.W && img0 < q.batch) drow[j] = (img0 * q.H + row0 + (int)r) * q.W + (int)c;
     } else {
       const int r = (m >> 3) & 7, c = m & 7, img = img0 + (m >> 6);
-      if (r < 7 && c < 7 && img < q.batch) drow[j] = (img * 7 + r) * 7 + c;
+      if (r < 7 && c < 7 && img < q.batch) {
+        if (q.quad == 2) drow[j] = ((img >> 2) * 14 + ((img >> 1) & 1) * 7 + r) * 14 + (img & 1) * 7 + c;
+        else drow[j] = (img * 7 + r) * 7 + c;
+      }
     }
   }
 #pragma unroll
@@ -542,41 +556,56 @@ inline int pt_enabled() {
 
 extern "C" void qt_set_pt_conv(int mode) { g_pt_enabled = mode < 0 ? 1 : mode; }
 
-// `batch` = images (a.M / (OH*OW)); the descriptor must be a dense 3x3 / stride 1 / pad 1 convolution
-bool qt_pt_eligible(const ConvArgs& a, int dtype) {
+// images the kernel walks (quadrant modes: four 7x7 region images per map) and the quadrant mode, -1: not covered
+static int pt_images(const ConvArgs& a, bool dgrad, int* quad) {
+  *quad = 0;
+  if (a.quad) {
+    if (a.quad != 2 || a.IH != 7 || a.IW != 7) return -1;
+    if (!dgrad && a.OH == 7 && a.OW == 7) { *quad = 1; return a.M / 49; }            // M = maps * 4 * 49
+    if (dgrad && a.OH == 14 && a.OW == 14) { *quad = 2; return a.M / 196 * 4; }     // M = maps * 196
+    return -1;
+  }
+  if (a.OH != a.IH || a.OW != a.IW || a.M % (a.OH * a.OW) != 0) return -1;
+  return a.M / (a.OH * a.OW);
+}
+
+// the descriptor must be a 3x3 / stride 1 / pad 1 convolution on 28x28, 14x14 or 7x7 images (or 7x7 quadrants of 14x14 maps)
+bool qt_pt_eligible(const ConvArgs& a, int dtype, bool dgrad) {
   if (!pt_enabled()) return false;
   const int esz = dtype == QT_F32 ? 4 : 2;
-  if (a.ntaps != 9 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.quad || a.dst_sub) return false;
-  if (a.OH != a.IH || a.OW != a.IW) return false;
+  if (a.ntaps != 9 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.dst_sub) return false;
+  int quad;
+  const int batch = pt_images(a, dgrad, &quad);
+  if (batch < 0) return false;
   PtArgs q;
-  if (!pt_geometry(a.OH, a.OW, q)) return false;
+  if (!pt_geometry(a.IH, a.IW, q)) return false;
   if ((a.KC * esz) % kKB != 0 || a.N % 128 != 0) return false;
-  if (a.M % (a.OH * a.OW) != 0) return false;
   // 32-bit byte offsets below kOob
-  const long long img_elems = a.src_img_stride > 0 ? a.src_img_stride : (long long)a.IH * a.IW * a.KC;
-  if ((a.M / (a.OH * a.OW)) * img_elems * esz >= (1ll << 31) || (long long)a.N * 9 * a.KC * esz >= (1ll << 31)) return false;
-  const int batch = a.M / (a.OH * a.OW);
-  // dense NHWC source (the patch walks it with its own strides, but the launcher only has these three)
+  const long long simgs = quad == 1 ? batch / 4 : batch;
+  if (simgs * a.src_img_stride * esz >= (1ll << 31) || (long long)a.N * 9 * a.KC * esz >= (1ll << 31)) return false;
   if (batch < 16) return false;   // a handful of tiles: the generic kernel's small tiles cover the chip better
   return true;
 }
 
-int qt_pt_stats_rows(const ConvArgs& a) {
+int qt_pt_stats_rows(const ConvArgs& a, bool dgrad) {
   PtArgs q;
-  pt_geometry(a.OH, a.OW, q);
-  return pt_tiles_m(q, a.M / (a.OH * a.OW));
+  int quad;
+  pt_geometry(a.IH, a.IW, q);
+  return pt_tiles_m(q, pt_images(a, dgrad, &quad));
 }
 
 int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
   PtArgs q;
   q.c = a;
-  pt_geometry(a.OH, a.OW, q);
-  q.batch = a.M / (a.OH * a.OW);
+  pt_geometry(a.IH, a.IW, q);
+  q.batch = pt_images(a, dgrad, &q.quad);
   q.tiles_m = pt_tiles_m(q, q.batch);
   const int esz = dtype == QT_F32 ? 4 : 2;
   q.nchunks = a.KC * esz / kKB;
-  q.src_bytes = (unsigned)((((long long)q.batch - 1) * a.src_img_stride + ((long long)a.IH - 1) * a.src_row_stride +
-                            ((long long)a.IW - 1) * a.src_pix_stride + a.KC) * esz);
+  const long long simgs = q.quad == 1 ? q.batch / 4 : q.batch;
+  const int sh = q.quad == 1 ? 14 : a.IH, sw = q.quad == 1 ? 14 : a.IW;
+  q.src_bytes = (unsigned)(((simgs - 1) * a.src_img_stride + ((long long)sh - 1) * a.src_row_stride +
+                            ((long long)sw - 1) * a.src_pix_stride + a.KC) * esz);
   q.wgt_bytes = (unsigned)((long long)a.N * 9 * a.KC * esz);
   if (dtype == QT_F32) return dgrad ? dispatch<float, true>(q, stream) : dispatch<float, false>(q, stream);
   return dgrad ? dispatch<bf16_t, true>(q, stream) : dispatch<bf16_t, false>(q, stream);
