@@ -153,6 +153,47 @@ def test_pt_dgrad_with_mask_residual_and_bn_links(dt, cfg):
             assert rel_err(s_pt[k], s_gen[k]) <= (1e-4 if dt == torch.float32 else 5e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pt_quadrant_conv_forward_and_data_gradient(dt):
+    """The quadrant head (Quadtree_from scratch/models.py:277-287: conv 256 -> 128 on the four 7x7 quadrants of the
+    14x14 map, zero padding AT the seam) through the stacked-7x7 geometry: forward reads the un-split map, the data
+    gradient scatters the four per-quadrant images back onto it."""
+    dev = _dev()
+    L = pkg("_lib")
+    B, C, N = 19, 256, 128
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(B, C, 14, 14, generator=g).to(dt).float()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5).to(dt).float()
+    bias = torch.randn(N, generator=g) * 0.1
+    quads = [base[:, :, :7, :7], base[:, :, :7, 7:], base[:, :, 7:, :7], base[:, :, 7:, 7:]]
+    ref = torch.stack([F.relu(F.conv2d(qd, w, bias, 1, 1)) for qd in quads], 1)  # [B,4,N,7,7]
+    xd = nhwc(base).to(dev, dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev, dt)
+    ys = {}
+    for on in (True, False):
+        with _pt(L, on):
+            ys[on], _ = run_conv(L, dt, xd, wd, B, (7, 7), (7, 7), C, N, 3, 3, 1, 1, L.QT_CONV_FWD, quad=1, relu=1,
+                                 shift=bias.to(dev), strides=(14 * 14 * C, 14 * C, C))
+    got = ys[True].float().cpu().view(B, 4, 7, 7, N).permute(0, 1, 4, 2, 3)
+    assert rel_err(got, ref) <= TOL[dt]
+    assert rel_err(ys[True].float().cpu(), ys[False].float().cpu()) <= TOL[dt]
+    dyq = torch.randn(B, 4, N, 7, 7, generator=g).to(dt).float()
+    dbase = torch.zeros(B, C, 14, 14)
+    sl = [(slice(0, 7), slice(0, 7)), (slice(0, 7), slice(7, 14)), (slice(7, 14), slice(0, 7)), (slice(7, 14), slice(7, 14))]
+    for k in range(4):
+        dbase[:, :, sl[k][0], sl[k][1]] = torch.nn.grad.conv2d_input((B, C, 7, 7), w, dyq[:, k], 1, 1)
+    dyd = dyq.permute(0, 1, 3, 4, 2).contiguous().to(dev, dt)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dev, dt)
+    res = torch.randn(B, C, 14, 14, generator=g).to(dt).float()
+    for on in (True, False):
+        with _pt(L, on):
+            ys[on], _ = run_conv(L, dt, dyd, wt, B, (7, 7), (14, 14), N, C, 3, 3, 1, 1, L.QT_CONV_DGRAD, quad=1,
+                                 strides=(49 * N, 7 * N, N), residual=nhwc(res).to(dev, dt).view(-1, C))
+    got = ys[True].float().cpu().view(B, 14, 14, C).permute(0, 3, 1, 2)
+    assert rel_err(got, dbase + res) <= TOL[dt]
+    assert rel_err(ys[True].float().cpu(), ys[False].float().cpu()) <= TOL[dt]
+
+
 def test_pt_full_benchmark_batch_matches_generic_kernel():
     """B = 256, bf16, the three stage shapes of the benchmark: every CU holds a tile (1024 / 512 / 256 workgroups);
     forward with statistics and the data gradient with mask + residual against the generic kernel."""
@@ -200,7 +241,8 @@ def test_pt_is_chosen_exactly_where_it_is_eligible():
     assert rows(4, 28, 128, 128) == (4 * 784 + 127) // 128           # few images: generic 128-pixel tiles
     assert rows(256, 28, 64, 128, k=1, stride=2) == (256 * 196 + 127) // 128   # 1x1 stride 2: generic
     assert rows(256, 28, 128, 64) == (256 * 784 + 127) // 128        # 64 output channels: generic
-    assert rows(64, 7, 256, 128, quad=1) == (64 * 4 * 49 + 127) // 128   # quadrant mode: generic
+    assert rows(64, 7, 256, 128, quad=1) == 64                       # quadrant mode: the four quadrants of a map per tile
+    assert rows(3, 7, 256, 128, quad=1) == (3 * 4 * 49 + 127) // 128 # 12 region images: generic
     L.lib().qt_set_pt_conv(0)
     assert rows(256, 14, 256, 256) == 392
     L.lib().qt_set_pt_conv(-1)
