@@ -581,20 +581,15 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 // Workgroups per CU on the 128x64 kernel (LDS padded): 1 / 2 / 3 -> 242 / 149 / 121 us.  A second wave per SIMD is worth
 // 1.6x, a third 1.2x; neither deeper DMA prefetch nor fewer LDS reads per MFMA pays while a wave's own LDS-read -> MFMA ->
 // barrier chain is exposed, and halving the K-step costs more in barriers than the third workgroup returns.
+// (Round 1 shipped a single-buffered instantiation -- NSTAGE == 1, half-tile epilogue, three workgroups per CU -- for
+// layer2's 3x3 convs; it needed 168 VGPRs and spilled 20.  Those convs now take conv_pt.hip; the one launch that still
+// reached it (layer2.0.conv1, stride 2) measures the same on the two-stage tile, so the dispatch no longer uses it.)
 // Single-buffered tiles + half-tile epilogue (32 KB of LDS, three workgroups per CU): every fragment of
 // a K-step is read into registers, a second barrier frees the tiles, and the next K-step's DMA runs
 // under the MFMAs.  Measured alone (B=256, bf16): layer2's 3x3 convs 93 -> 81 us forward, 93 -> 82 us data
 // gradient; layer3 / layer4 (784 / 392 workgroups: no better fit on 768 slots than on 512) unchanged; short
 // K loops (1x1 downsamples, classifier) slower.  Used only where it wins: 9 taps, N == 128, >= 100 k pixels
 // (train step -0.5 %, eval forward -1.0 %).  QTCNN_IGEMM_SINGLE_BUFFER=0 turns it off.
-inline bool igemm_single_buffer() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("QTCNN_IGEMM_SINGLE_BUFFER");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
 inline int tile_m(long long M, int N, int ksteps) { return (M >= 256 * 256 && ksteps >= 36 && N > 64) ? 256 : 128; }
 
 template <typename T, bool DGRAD>
@@ -602,8 +597,6 @@ int dispatch2(const ConvArgs& a, hipStream_t stream) {
   const int bm = tile_m(a.M, a.N, a.ntaps * a.KC * (int)sizeof(T) / kRowBytes);
   if (a.N <= 64) return launch<T, 128, 64, 2, 2, 2, DGRAD>(a, stream);
   if (bm == 256) return launch<T, 256, 128, 4, 2, 3, DGRAD>(a, stream);
-  if (sizeof(T) == 2 && igemm_single_buffer() && !(DGRAD && a.stride == 2) && a.ntaps == 9 && a.N == 128 && a.M >= 100000)
-    return launch<T, 128, 128, 2, 2, 1, DGRAD, 2>(a, stream);
   return launch<T, 128, 128, 2, 2, 2, DGRAD>(a, stream);
 }
 
