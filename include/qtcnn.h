@@ -362,6 +362,32 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
                   void* stream);
 
 /* ------------------------------------------------------------------------
+ * 3-D clip models (Quadtree3DCNN 3dcnn/models.py:96-214, Ji3DCNN cnn+lstm/models.py:93-142).  Clip activations are
+ * time-major NHWC [T][B][H][W][C]: a Conv3d(3x3x3, padding 1) is three qt_conv2d_igemm launches over contiguous frame
+ * ranges (out[t] += conv2d(in[t+kt-1], W[:,:,kt]), accumulated through `residual` = dst), its gradients three
+ * QT_CONV_DGRAD / qt_conv2d_wgrad launches (host side: <pkg>/video3d.py).  The HBM-bound pieces:
+ * ------------------------------------------------------------------------ */
+/* clips [B][T][3][H][W] f32 (the reference's image_sequence_input) -> [T][B][H][W][128] of `dtype`: the 27 taps x 3
+ * channels of pixel (t,b,h,w), element ((kt*3+kh)*3+kw)*3+c, zeros outside the clip and in 81..127: the first Conv3d
+ * (3 input channels) becomes a 1x1 convolution with k_per_tap = 128 */
+int qt_pack_clip27(int dtype, const float* clips, void* dst, int batch, int frames, int h, int w, void* stream);
+/* BatchNorm3d batch statistics of a finished map y [M][C]: partial[qt_bn_stats_rows(M,C)][2][C] sums / sums of squares
+ * (fixed summation order), input of qt_bn_finalize (buffer capacity qt_stats_capacity_rows(rows)) */
+int qt_bn_stats_rows(long long M, int C);
+int qt_bn_stats(int dtype, const void* y, long long M, int C, float* partial, void* stream);
+/* nn.MaxPool3d(kernel = stride = (pool_t, 2, 2)), pool_t 1 or 2, floor mode: x [T][B][H][W][C] ->
+ * out [T/pool_t][B][H/2][W/2][C]; argmax (u8 per output element, optional) = index of the first maximum in (t,h,w)
+ * scan order, which is where torch's backward sends the gradient.  _bwd writes every element of dx. */
+int qt_pool3d_max(int dtype, const void* x, void* out, unsigned char* argmax, int frames, int batch, int h, int w, int C,
+                  int pool_t, void* stream);
+int qt_pool3d_max_bwd(int dtype, const void* dout, const unsigned char* argmax, void* dx, int frames, int batch, int h,
+                      int w, int C, int pool_t, void* stream);
+/* nn.AdaptiveAvgPool3d((1,1,1)) + flatten(1) into columns [col0, col0+C) of an f32 [B][ld] matrix, and its backward */
+int qt_avgpool_tb(int dtype, const void* x, float* dst, int frames, int batch, int hw, int C, int ld, int col0, void* stream);
+int qt_avgpool_tb_bwd(int dtype, const float* d, void* g, int frames, int batch, int hw, int C, int ld, int col0,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
  * Whole-network executor.  One plan = one model variant at a maximum batch:
  *   QT_MODEL_QUADTREE         QuadtreeCNN  (Quadtree_from scratch/models.py:214-305;
  *                             resnet/models.py:70-180 with `mode`)

@@ -9,5 +9,7 @@ reference's `from models import get_model`.
 from ._lib import LIB_PATH, QtError  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .quadtree import AttentionHierarchicalCNN, CnnLstm, QuadtreeCNN, StandardResNetCNN  # noqa: F401
+from .video3d import Ji3DCNN, Quadtree3DCNN  # noqa: F401
 
-__all__ = ["QuadtreeCNN", "StandardResNetCNN", "AttentionHierarchicalCNN", "CnnLstm", "FusedAdam", "QtError", "LIB_PATH"]
+__all__ = ["QuadtreeCNN", "StandardResNetCNN", "AttentionHierarchicalCNN", "CnnLstm", "Quadtree3DCNN", "Ji3DCNN", "FusedAdam",
+           "QtError", "LIB_PATH"]

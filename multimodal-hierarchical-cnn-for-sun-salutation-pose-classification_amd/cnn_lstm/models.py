@@ -2,7 +2,7 @@
 
 CnnLstm (:14-89) and get_model (:145-153) with the reference's signatures; the per-frame ResNet-18 runs on the
 MFMA conv kernels, the LSTM recurrence in csrc/lstm.hip.  Ji3DCNN (:93-142, the '3d_cnn' option: Conv3d stream +
-LSTM on the pose vectors) needs a conv3d kernel family that is not built yet.
+LSTM on the pose vectors) runs its 3x3x3 convolutions as three 2-D MFMA launches each (<pkg>/video3d.py).
 """
 import importlib
 import os
@@ -23,10 +23,11 @@ class CnnLstm(_impl.CnnLstm):
         super().__init__(num_classes, sequence_length, numerical_feature_dim, dropout_rate, lstm_hidden_size, **kw)
 
 
-class Ji3DCNN:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("Ji3DCNN (reference cnn+lstm/models.py:93-142) needs the conv3d kernels of "
-                                  "SURVEY.md 8f rank 4; not built in this round")
+class Ji3DCNN(importlib.import_module(_PKG + ".video3d").Ji3DCNN):
+    """reference cnn+lstm/models.py:93-142: three Conv3d blocks + LSTM(47 -> 64) + classifier (<pkg>/video3d.py)"""
+
+    def __init__(self, num_classes, sequence_length=4, numerical_feature_dim=47, dropout_rate=0.5, **kw):
+        super().__init__(num_classes, sequence_length, numerical_feature_dim, dropout_rate, **kw)
 
 
 def get_model(model_name, num_classes, device, seq_len=4, num_features=47):

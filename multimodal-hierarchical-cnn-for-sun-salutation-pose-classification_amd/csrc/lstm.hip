@@ -147,8 +147,10 @@ extern "C" int qt_lstm_forward(const float* xproj, const float* whh_t, const flo
     hipLaunchKernelGGL(lstm_fwd_kernel<256>, dim3(batch), dim3(1024), 0, s, xproj, whh_t, bhh, gates, cell, hprev, hout, T);
   else if (H == 64)
     hipLaunchKernelGGL(lstm_fwd_kernel<64>, dim3(batch), dim3(256), 0, s, xproj, whh_t, bhh, gates, cell, hprev, hout, T);
+  else if (H == 188)   // Quadtree3DCNN: nn.LSTM(47, 47 * 4) (3dcnn/models.py:146-152)
+    hipLaunchKernelGGL(lstm_fwd_kernel<188>, dim3(batch), dim3(752), 0, s, xproj, whh_t, bhh, gates, cell, hprev, hout, T);
   else {
-    qt_set_error("qt_lstm_forward: hidden size %d is not instantiated (256, 64)", H);
+    qt_set_error("qt_lstm_forward: hidden size %d is not instantiated (256, 188, 64)", H);
     return QT_ERR_UNSUPPORTED;
   }
   QT_CHECK_LAUNCH();
@@ -163,8 +165,10 @@ extern "C" int qt_lstm_backward(const float* dhout, const float* dlast, const fl
     hipLaunchKernelGGL(lstm_bwd_kernel<256>, dim3(batch), dim3(1024), 0, s, dhout, dlast, gates, cell, whh, dgates, T);
   else if (H == 64)
     hipLaunchKernelGGL(lstm_bwd_kernel<64>, dim3(batch), dim3(256), 0, s, dhout, dlast, gates, cell, whh, dgates, T);
+  else if (H == 188)
+    hipLaunchKernelGGL(lstm_bwd_kernel<188>, dim3(batch), dim3(752), 0, s, dhout, dlast, gates, cell, whh, dgates, T);
   else {
-    qt_set_error("qt_lstm_backward: hidden size %d is not instantiated (256, 64)", H);
+    qt_set_error("qt_lstm_backward: hidden size %d is not instantiated (256, 188, 64)", H);
     return QT_ERR_UNSUPPORTED;
   }
   QT_CHECK_LAUNCH();

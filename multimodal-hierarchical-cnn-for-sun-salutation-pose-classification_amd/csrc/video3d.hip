@@ -1,0 +1,295 @@
+// Memory-bound pieces of the 3-D clip models (BASELINE config 4):
+//   Quadtree3DCNN  /root/reference/3dcnn/models.py:96-214   (5 x Conv3d 3x3x3 + BatchNorm3d + ReLU + MaxPool3d, T = 8 clips)
+//   Ji3DCNN        /root/reference/cnn+lstm/models.py:93-142 (3 x Conv3d block)
+//
+// Layout.  Clip activations are TIME-MAJOR NHWC: [T][B][H][W][C].  A 3x3x3 convolution with padding 1 is then the sum
+// over the frame tap kt of three 3x3 2-D convolutions whose operands are CONTIGUOUS sub-batches of frames --
+//     out[t] += conv2d(in[t + kt - 1], W[:, :, kt])   for the t with 0 <= t + kt - 1 < T   (images t*B .. t*B+B-1)
+// -- so the MFMA work runs on the implicit-GEMM kernels of conv_igemm.hip / conv_pt.hip / conv_wgrad.hip unchanged (frames
+// past the clip's ends are simply not part of the launch: no padding frames, no wasted MFMAs); the first layer (3 input
+// channels) is packed to one 128-wide K row per pixel (27 taps x 3 channels) and runs as a 1x1 convolution.
+// What lives here is HBM-bound: the clip packing, BatchNorm3d batch statistics of a finished map (the conv epilogue's
+// statistics cannot be used: a map is finished by the last of three launches), MaxPool3d (1,2,2) / (2,2,2) with its
+// backward, AdaptiveAvgPool3d(1,1,1) with its backward.  8 channels (16 B of bf16) per thread, f32 arithmetic.
+#include "qt_common.h"
+
+namespace {
+
+// ---- clip packing: [B][T][3][H][W] f32 (image_sequence_input, 3dcnn/models.py:189 permutes it to B,C,T,H,W) ->
+// [T][B][H][W][128]: element ((kt*3 + kh)*3 + kw)*3 + c = x[b][t+kt-1][c][h+kh-1][w+kw-1] (0 outside), 81..127 = 0
+template <typename T>
+__global__ void pack_clip27_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, int Tn, int H, int W) {
+  const long long rows = (long long)Tn * B * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < rows * 16; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i >> 4;
+    const int chunk = (int)(i & 15);
+    const int w = (int)(row % W);
+    const int h = (int)((row / W) % H);
+    const int b = (int)((row / ((long long)W * H)) % B);
+    const int t = (int)(row / ((long long)W * H * B));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = chunk * 8 + e;
+      v[e] = 0.f;
+      if (k < 81) {
+        const int c = k % 3, tap = k / 3;
+        const int kw = tap % 3, kh = (tap / 3) % 3, kt = tap / 9;
+        const int tt = t + kt - 1, hh = h + kh - 1, ww = w + kw - 1;
+        if ((unsigned)tt < (unsigned)Tn && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+          v[e] = x[((((long long)b * Tn + tt) * 3 + c) * H + hh) * W + ww];
+      }
+    }
+    QtVec8<T>::store(dst + row * 128 + chunk * 8, v);
+  }
+}
+
+// ---- per-channel sum / sum of squares of y [M][C] over row slabs -> partial [rows][2][C] (for qt_bn_finalize) ----
+template <typename T>
+__global__ void bn_stats_kernel(const T* __restrict__ y, long long M, int C, float* __restrict__ partial, int slab) {
+  // block = 256 threads = (C/8 channel groups) x (256 / (C/8) row lanes); one partial row per block
+  const int groups = C / 8;
+  const int lanes = 256 / groups;
+  const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
+  const long long r0 = (long long)blockIdx.x * slab, r1 = min(M, r0 + slab);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  if (rl < lanes) {
+    for (long long r = r0 + rl; r < r1; r += lanes) {
+      float v[8];
+      QtVec8<T>::load(y + r * C + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += v[e];
+        q[e] += v[e] * v[e];
+      }
+    }
+  }
+  __shared__ float red[256 * 16];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x * 16 + e] = s[e];
+    red[threadIdx.x * 16 + 8 + e] = q[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {   // fixed order over the row lanes: deterministic
+    const int which = c / C, ch = c % C;
+    const int gg = ch / 8, e = ch % 8;
+    float a = 0.f;
+    for (int l = 0; l < lanes; ++l) a += red[(l * groups + gg) * 16 + which * 8 + e];
+    partial[((long long)blockIdx.x * 2 + which) * C + ch] = a;
+  }
+}
+
+// ---- MaxPool3d, kernel = stride = (PT, 2, 2), floor mode: x [T][B][H][W][C] -> out [T/PT][B][H/2][W/2][C];
+// arg (u8) = index of the FIRST maximum in (t, h, w) scan order, as torch's kernel keeps it ----
+template <typename T, int PT>
+__global__ void pool3d_max_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* __restrict__ arg, int Tn,
+                                  int B, int H, int W, int C) {
+  const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = C / 8;
+  const long long n = (long long)To * B * Ho * Wo * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int b = (int)(r % B);
+    const int to = (int)(r / B);
+    float best[8];
+    unsigned char idx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; idx[e] = 0; }
+#pragma unroll
+    for (int dt = 0; dt < PT; ++dt)
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          const long long src = ((((long long)(to * PT + dt) * B + b) * H + ho * 2 + dh) * W + wo * 2 + dw) * C + g * 8;
+          float v[8];
+          QtVec8<T>::load(x + src, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (v[e] > best[e]) { best[e] = v[e]; idx[e] = (unsigned char)((dt * 2 + dh) * 2 + dw); }
+        }
+    const long long o = ((((long long)to * B + b) * Ho + ho) * Wo + wo) * C + g * 8;
+    QtVec8<T>::store(out + o, best);
+    if (arg) {
+      uint2 pk;
+      pk.x = idx[0] | (idx[1] << 8) | (idx[2] << 16) | ((unsigned)idx[3] << 24);
+      pk.y = idx[4] | (idx[5] << 8) | (idx[6] << 16) | ((unsigned)idx[7] << 24);
+      *reinterpret_cast<uint2*>(arg + o) = pk;
+    }
+  }
+}
+// dx [T][B][H][W][C] (every element written: windows tile the pooled part; the floor-mode remainder gets zeros)
+template <typename T, int PT>
+__global__ void pool3d_max_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg, T* __restrict__ dx,
+                                      int Tn, int B, int H, int W, int C) {
+  const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = C / 8;
+  const long long n = (long long)Tn * B * H * W * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); r /= H;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    const int to = t / PT, ho = h / 2, wo = w / 2;
+    if (to < To && ho < Ho && wo < Wo) {
+      const long long o = ((((long long)to * B + b) * Ho + ho) * Wo + wo) * C + g * 8;
+      const uint2 pk = *reinterpret_cast<const uint2*>(arg + o);
+      const unsigned me = (unsigned)(((t - to * PT) * 2 + (h & 1)) * 2 + (w & 1));
+      float d[8];
+      QtVec8<T>::load(dout + o, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+        v[e] = a == me ? d[e] : 0.f;
+      }
+    }
+    QtVec8<T>::store(dx + i * 8, v);
+  }
+}
+
+// ---- AdaptiveAvgPool3d((1,1,1)) + flatten: x [T][B][HW][C] -> dst[b*ld + col0 + c] (f32) = mean over t, hw ----
+template <typename T>
+__global__ void avgpool_tb_kernel(const T* __restrict__ x, float* __restrict__ dst, int Tn, int B, int HW, int C, int ld, int col0) {
+  const int b = blockIdx.x, G = C / 8;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (int t = 0; t < Tn; ++t)
+      for (int p = 0; p < HW; ++p) {   // fixed order: deterministic
+        float v[8];
+        QtVec8<T>::load(x + (((long long)t * B + b) * HW + p) * C + g * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[e];
+      }
+    const float inv = 1.f / (float)(Tn * HW);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(long long)b * ld + col0 + g * 8 + e] = s[e] * inv;
+  }
+}
+// g [T][B][HW][C] = d[b*ld + col0 + c] / (T*HW)
+template <typename T>
+__global__ void avgpool_tb_bwd_kernel(const float* __restrict__ d, T* __restrict__ g, int Tn, int B, int HW, int C, int ld, int col0) {
+  const int G = C / 8;
+  const long long n = (long long)Tn * B * HW * G;
+  const float inv = 1.f / (float)(Tn * HW);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int gg = (int)(i % G);
+    const int b = (int)((i / ((long long)G * HW)) % B);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = d[(long long)b * ld + col0 + gg * 8 + e] * inv;
+    QtVec8<T>::store(g + i * 8, v);
+  }
+}
+
+inline unsigned grid_for(long long n) {
+  const long long b = (n + 255) / 256;
+  return (unsigned)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int qt_pack_clip27(int dtype, const float* clips, void* dst, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(clips && dst && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_pack_clip27: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pack_clip27: bad dtype %d", dtype);
+  const long long n = (long long)frames * batch * h * w * 16;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(pack_clip27_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, clips, (float*)dst, batch, frames, h, w);
+  else
+    hipLaunchKernelGGL(pack_clip27_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, clips, (bf16_t*)dst, batch, frames, h, w);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+// rows of partial sums qt_bn_stats writes for an [M][C] map (at most 1024 slabs of at least 256 rows)
+extern "C" int qt_bn_stats_rows(long long M, int C) {
+  (void)C;
+  const long long slabs = (M + 255) / 256;
+  return (int)(slabs > 1024 ? 1024 : (slabs < 1 ? 1 : slabs));
+}
+
+extern "C" int qt_bn_stats(int dtype, const void* y, long long M, int C, float* partial, void* stream) {
+  QT_CHECK_ARG(y && partial && M > 0, "qt_bn_stats: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_bn_stats: bad dtype %d", dtype);
+  QT_CHECK_ARG(C >= 8 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0,
+               "qt_bn_stats: C=%d: C / 8 must divide 256", C);
+  const int rows = qt_bn_stats_rows(M, C);
+  const int slab = (int)((M + rows - 1) / rows);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)y, M, C, partial, slab);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)y, M, C, partial, slab);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pool3d_max(int dtype, const void* x, void* out, unsigned char* argmax, int frames, int batch, int h, int w,
+                             int C, int pool_t, void* stream) {
+  QT_CHECK_ARG(x && out && frames > 0 && batch > 0 && h >= 2 && w >= 2 && C % 8 == 0, "qt_pool3d_max: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pool3d_max: bad dtype %d", dtype);
+  QT_CHECK_ARG((pool_t == 1 || pool_t == 2) && frames >= pool_t, "qt_pool3d_max: pool_t=%d (1 or 2, <= frames)", pool_t);
+  const long long n = (long long)(frames / pool_t) * batch * (h / 2) * (w / 2) * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(n)), blk(256);
+#define QT_POOL(TT, PT) hipLaunchKernelGGL((pool3d_max_kernel<TT, PT>), grid, blk, 0, s, (const TT*)x, (TT*)out, argmax, frames, batch, h, w, C)
+  if (dtype == QT_F32) { if (pool_t == 1) QT_POOL(float, 1); else QT_POOL(float, 2); }
+  else { if (pool_t == 1) QT_POOL(bf16_t, 1); else QT_POOL(bf16_t, 2); }
+#undef QT_POOL
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pool3d_max_bwd(int dtype, const void* dout, const unsigned char* argmax, void* dx, int frames, int batch,
+                                 int h, int w, int C, int pool_t, void* stream) {
+  QT_CHECK_ARG(dout && argmax && dx && frames > 0 && batch > 0 && h >= 2 && w >= 2 && C % 8 == 0, "qt_pool3d_max_bwd: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pool3d_max_bwd: bad dtype %d", dtype);
+  QT_CHECK_ARG((pool_t == 1 || pool_t == 2) && frames >= pool_t, "qt_pool3d_max_bwd: pool_t=%d", pool_t);
+  const long long n = (long long)frames * batch * h * w * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(n)), blk(256);
+#define QT_POOLB(TT, PT) hipLaunchKernelGGL((pool3d_max_bwd_kernel<TT, PT>), grid, blk, 0, s, (const TT*)dout, argmax, (TT*)dx, frames, batch, h, w, C)
+  if (dtype == QT_F32) { if (pool_t == 1) QT_POOLB(float, 1); else QT_POOLB(float, 2); }
+  else { if (pool_t == 1) QT_POOLB(bf16_t, 1); else QT_POOLB(bf16_t, 2); }
+#undef QT_POOLB
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_avgpool_tb(int dtype, const void* x, float* dst, int frames, int batch, int hw, int C, int ld, int col0,
+                             void* stream) {
+  QT_CHECK_ARG(x && dst && frames > 0 && batch > 0 && hw > 0 && C % 8 == 0 && ld >= col0 + C, "qt_avgpool_tb: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_avgpool_tb: bad dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(avgpool_tb_kernel<float>, dim3(batch), dim3(128), 0, s, (const float*)x, dst, frames, batch, hw, C, ld, col0);
+  else
+    hipLaunchKernelGGL(avgpool_tb_kernel<bf16_t>, dim3(batch), dim3(128), 0, s, (const bf16_t*)x, dst, frames, batch, hw, C, ld, col0);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_avgpool_tb_bwd(int dtype, const float* d, void* g, int frames, int batch, int hw, int C, int ld, int col0,
+                                 void* stream) {
+  QT_CHECK_ARG(d && g && frames > 0 && batch > 0 && hw > 0 && C % 8 == 0 && ld >= col0 + C, "qt_avgpool_tb_bwd: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_avgpool_tb_bwd: bad dtype %d", dtype);
+  const long long n = (long long)frames * batch * hw * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(avgpool_tb_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, d, (float*)g, frames, batch, hw, C, ld, col0);
+  else
+    hipLaunchKernelGGL(avgpool_tb_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, d, (bf16_t*)g, frames, batch, hw, C, ld, col0);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

@@ -60,6 +60,43 @@ class BatchNorm2d(_Leaf):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
 
 
+class Conv3d(_Leaf):
+    """nn.Conv3d holder: weight [O][I][kT][kH][kW], bias [O]; torch's default initialisation"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        k = (kernel_size,) * 3 if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = k, (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        self.padding = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *k))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(in_channels * k[0] * k[1] * k[2])
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}")
+
+
+class BatchNorm3d(BatchNorm2d):
+    pass
+
+
+class MaxPool3d(_Leaf):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride or kernel_size, padding
+
+
+class AdaptiveAvgPool3d(_Leaf):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+
 class Linear(_Leaf):
     def __init__(self, in_features, out_features):
         super().__init__()

@@ -64,6 +64,9 @@ def synth_tensor(key, ref, salt=0):
     if leaf == "weight" and len(shape) == 4:  # conv, Kaiming-uniform (ReLU gain)
         a = float(np.sqrt(6.0 / (shape[1] * shape[2] * shape[3])))
         return _fill(key, shape, -a, a, salt)
+    if leaf == "weight" and len(shape) == 5:  # conv3d, Kaiming-uniform (ReLU gain)
+        a = float(np.sqrt(6.0 / (shape[1] * shape[2] * shape[3] * shape[4])))
+        return _fill(key, shape, -a, a, salt)
     if leaf.startswith("bias_") and len(shape) == 1:  # nn.LSTM bias_ih_l{k} / bias_hh_l{k}
         return _fill(key, shape, -0.2, 0.2, salt)
     if leaf.startswith("weight_") and len(shape) == 2:  # nn.LSTM weight_ih_l{k} / weight_hh_l{k}

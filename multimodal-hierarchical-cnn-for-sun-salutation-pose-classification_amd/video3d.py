@@ -1,0 +1,683 @@
+"""3-D clip models on the HIP kernels (BASELINE config 4).
+
+Drop-in counterparts of
+  Quadtree3DCNN  /root/reference/3dcnn/models.py:96-214   (mode quadtree_3d_fusion / quadtree_3d_image_only)
+  Ji3DCNN        /root/reference/cnn+lstm/models.py:93-142
+with the reference's constructor arguments, attribute tree, state_dict keys and forward signature
+(image_sequence [B,T,3,H,W], numerical_sequence [B,T,47]) -> logits [B,C].
+
+How a Conv3d runs here.  Clip activations are TIME-MAJOR NHWC, [T][B][H][W][C], in the compute dtype (bf16, or f32
+with QTCNN_DTYPE=f32).  A 3x3x3 convolution with padding 1 is the sum over the frame tap kt of three 3x3 2-D
+convolutions over CONTIGUOUS ranges of frames (out[t] += conv2d(in[t+kt-1], W[:,:,kt]) for the t whose source frame
+exists), so forward, data gradient and weight gradient are three launches each of the implicit-GEMM MFMA kernels
+behind qt_conv2d_igemm / qt_conv2d_wgrad (csrc/conv_igemm.hip, conv_pt.hip, conv_wgrad*.hip), accumulated through the
+kernels' `residual` input.  The first layer (3 input channels) is packed to one 128-wide K row per pixel (27 taps x 3
+channels, qt_pack_clip27) and runs as a 1x1 convolution; its 32 output channels are padded to 64 with zero filters so
+that the next layer's K rows are whole 128-byte chunks.  BatchNorm3d statistics come from qt_bn_stats over the
+finished map, MaxPool3d / AdaptiveAvgPool3d from csrc/video3d.hip, the LSTM recurrences from csrc/lstm.hip, the thin
+dense products from csrc/gemm_small.hip.  The whole forward / backward is ONE autograd node; PyTorch only owns the
+buffers.  There is no torch / CPU fallback.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import modules as M
+from ._lib import QtError
+from .engine import default_compute_dtype
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+_c = ctypes
+
+
+class _GemmDesc(ctypes.Structure):   # qt_gemm_small_desc
+    _fields_ = [("M", _c.c_int), ("N", _c.c_int), ("K", _c.c_int),
+                ("a_dtype", _c.c_int), ("b_dtype", _c.c_int), ("c_dtype", _c.c_int),
+                ("a_row_stride", _c.c_longlong), ("a_k_stride", _c.c_longlong),
+                ("b_row_stride", _c.c_longlong), ("b_k_stride", _c.c_longlong),
+                ("c_row_stride", _c.c_longlong), ("relu", _c.c_int), ("accumulate", _c.c_int)]
+
+
+class _BnEvalItem(ctypes.Structure):   # qt_bn_eval_item
+    _fields_ = [("gamma", _c.c_void_p), ("beta", _c.c_void_p), ("running_mean", _c.c_void_p), ("running_var", _c.c_void_p),
+                ("scale", _c.c_void_p), ("shift", _c.c_void_p), ("C", _c.c_int), ("mean", _c.c_void_p),
+                ("invstd", _c.c_void_p)]
+
+
+def _ptr(t, byte_offset=0):
+    return None if t is None else _c.c_void_p(t.data_ptr() + byte_offset)
+
+
+class _Ops:
+    """ctypes view of the C ABI used by the clip models; every call checks its status."""
+
+    def __init__(self):
+        self.L = _lib.lib()
+        L = self.L
+        L.qt_stats_capacity_rows.restype = _c.c_int
+        L.qt_bn_stats_rows.argtypes = [_c.c_longlong, _c.c_int]
+        L.qt_bn_bwd_partial_rows.argtypes = [_c.c_longlong, _c.c_int]
+
+    def check(self, rc, what):
+        _lib.check(rc, what)
+
+    # ---- convolutions -------------------------------------------------------------------------------------
+    @staticmethod
+    def conv_desc(dt, mode, images, h, w, k_per_tap, n_out, k, pad):
+        d = _lib.ConvDesc()
+        d.dtype = _lib.qt_dtype(dt)
+        d.mode = mode
+        d.batch = images
+        d.in_h, d.in_w, d.out_h, d.out_w = h, w, h, w
+        d.k_per_tap, d.n_out = k_per_tap, n_out
+        d.kh = d.kw = k
+        d.stride, d.pad = 1, pad
+        d.src_img_stride, d.src_row_stride, d.src_pix_stride = h * w * k_per_tap, w * k_per_tap, k_per_tap
+        return d
+
+    def igemm(self, d, src, w, dst, shift=None, residual=None):
+        io = _lib.ConvIO(src, w, dst, None, _ptr(shift), residual, None, None)
+        self.check(self.L.qt_conv2d_igemm(_c.byref(d), _c.byref(io), _lib.stream_ptr()), "qt_conv2d_igemm")
+
+    def wgrad(self, d, dy, x, dw):
+        self.check(self.L.qt_conv2d_wgrad(_c.byref(d), dy, x, _ptr(dw), _lib.stream_ptr()), "qt_conv2d_wgrad")
+
+    def pack_weight(self, dt, w_oihw, w_fwd, w_dgrad, O, I, k):
+        self.check(self.L.qt_pack_conv_weight(_lib.qt_dtype(dt), _ptr(w_oihw), _ptr(w_fwd), _ptr(w_dgrad), O, I, k, k,
+                                              _lib.stream_ptr()), "qt_pack_conv_weight")
+
+    def unpack_wgrad(self, dw, grad_oihw, O, I, k):
+        self.check(self.L.qt_unpack_conv_wgrad(_ptr(dw), _ptr(grad_oihw), O, I, k, k, 0, _lib.stream_ptr()),
+                   "qt_unpack_conv_wgrad")
+
+    # ---- BatchNorm / activation / pooling -------------------------------------------------------------------
+    def bn_train(self, dt, y, Mrows, C, gamma, beta, rmean, rvar, nbt, dev):
+        rows = self.L.qt_bn_stats_rows(_c.c_longlong(Mrows), C)
+        part = torch.empty(self.L.qt_stats_capacity_rows(rows), 2, C, dtype=torch.float32, device=dev)
+        self.check(self.L.qt_bn_stats(_lib.qt_dtype(dt), _ptr(y), _c.c_longlong(Mrows), C, _ptr(part), _lib.stream_ptr()),
+                   "qt_bn_stats")
+        out = torch.empty(4, C, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+        self.check(self.L.qt_bn_finalize(_ptr(part), rows, C, _c.c_longlong(Mrows), _ptr(gamma), _ptr(beta), _ptr(rmean),
+                                         _ptr(rvar), _ptr(nbt), _c.c_float(BN_MOMENTUM), _c.c_float(BN_EPS),
+                                         _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _lib.stream_ptr()),
+                   "qt_bn_finalize")
+        return out
+
+    def bn_eval(self, gamma, beta, rmean, rvar, C, dev):
+        out = torch.empty(4, C, dtype=torch.float32, device=dev)   # running mean, 1/sqrt(running var + eps), scale, shift
+        item = _BnEvalItem(_ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(out[2]), _ptr(out[3]), C, _ptr(out[0]),
+                           _ptr(out[1]))
+        self.check(self.L.qt_bn_eval_affine_batched(_c.byref(item), 1, _c.c_float(BN_EPS), _lib.stream_ptr()),
+                   "qt_bn_eval_affine_batched")
+        return out
+
+    def bn_act(self, dt, y, stats, out, Mrows, C):
+        self.check(self.L.qt_bn_act(_lib.qt_dtype(dt), _ptr(y), _ptr(stats[2]), _ptr(stats[3]), None, None, None, 1, _ptr(out),
+                                    _c.c_longlong(Mrows), C, _lib.stream_ptr()), "qt_bn_act")
+
+    def bn_backward(self, dt, g, act, y, stats, gamma, Mrows, C, dev, batch_stats):
+        """g = d/d(relu(bn(y))) -> (dy, dgamma, dbeta); `act` is the ReLU output (its mask)."""
+        rows = self.L.qt_bn_bwd_partial_rows(_c.c_longlong(Mrows), C)
+        part = torch.empty(self.L.qt_stats_capacity_rows(rows), 2, C, dtype=torch.float32, device=dev)
+        q = _lib.qt_dtype(dt)
+        self.check(self.L.qt_bn_bwd_reduce(q, _ptr(g), _ptr(act), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(part),
+                                           _c.c_longlong(Mrows), C, _lib.stream_ptr()), "qt_bn_bwd_reduce")
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        self.check(self.L.qt_bn_bwd_finalize(_ptr(part), rows, C, _c.c_longlong(Mrows if batch_stats else 0), _ptr(gamma),
+                                             _ptr(stats[1]), _ptr(dgb[0]), _ptr(dgb[1]), 0, _ptr(coef), _lib.stream_ptr()),
+                   "qt_bn_bwd_finalize")
+        dy = torch.empty_like(y)
+        self.check(self.L.qt_bn_bwd_apply(q, _ptr(g), _ptr(act), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(coef), _ptr(dy),
+                                          None, _c.c_longlong(Mrows), C, _lib.stream_ptr()), "qt_bn_bwd_apply")
+        return dy, dgb[0], dgb[1]
+
+    def pool(self, dt, x, out, arg, T, B, H, W, C, pt):
+        self.check(self.L.qt_pool3d_max(_lib.qt_dtype(dt), _ptr(x), _ptr(out), _ptr(arg), T, B, H, W, C, pt,
+                                        _lib.stream_ptr()), "qt_pool3d_max")
+
+    def pool_bwd(self, dt, dout, arg, dx, T, B, H, W, C, pt):
+        self.check(self.L.qt_pool3d_max_bwd(_lib.qt_dtype(dt), _ptr(dout), _ptr(arg), _ptr(dx), T, B, H, W, C, pt,
+                                            _lib.stream_ptr()), "qt_pool3d_max_bwd")
+
+    def col_sum(self, dt, x, rows, cols, ld, out):
+        self.check(self.L.qt_col_sum(_lib.qt_dtype(dt), _ptr(x), _c.c_longlong(rows), cols, ld, _ptr(out), 0, _lib.stream_ptr()),
+                   "qt_col_sum")
+
+    # ---- thin dense products (f32) --------------------------------------------------------------------------
+    def gemm(self, Mr, N, K, A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, c_rs, bias=None, relu=0, a_off=0, c_off=0):
+        d = _GemmDesc(Mr, N, K, _lib.QT_F32, _lib.QT_F32, _lib.QT_F32, a_rs, a_ks, b_rs, b_ks, c_rs, relu, 0)
+        self.check(self.L.qt_gemm_small(_c.byref(d), _ptr(A, a_off * 4), _ptr(Bm), _ptr(bias), _ptr(Cm, c_off * 4),
+                                        _lib.stream_ptr()), "qt_gemm_small")
+
+    def linear(self, x, x_ld, x_off, W, b, rows, out, out_ld, out_off, relu):
+        """out[r, out_off:out_off+N] = relu?(x[r, x_off:x_off+K] W^T + b)  (nn.Linear; W [N,K])"""
+        N, K = W.shape
+        self.gemm(rows, N, K, x, x_ld, 1, W, K, 1, out, out_ld, b, relu, x_off, out_off)
+
+    def dropout(self, x, rows, cols, ld, off, seed, p):
+        self.check(self.L.qt_dropout(_lib.QT_F32, _ptr(x, off * 4), _c.c_longlong(rows), cols, ld, _c.c_ulonglong(seed),
+                                     _c.c_float(p), _lib.stream_ptr()), "qt_dropout")
+
+
+_ops = None
+
+
+def ops():
+    global _ops
+    if _ops is None:
+        _ops = _Ops()
+    return _ops
+
+
+def _cpad(c):
+    """channel count the conv kernels see: K rows are whole 128-byte chunks (64 bf16 / 32 f32 -> 64 covers both)"""
+    return max(64, (c + 63) // 64 * 64)
+
+
+class _ConvBlock:
+    """Conv3d(3x3x3, pad 1, bias) + BatchNorm3d + ReLU (+ MaxPool3d (pt,2,2)) on [T][B][H][W][C]."""
+
+    def __init__(self, conv, bn, pool_t, first):
+        self.conv, self.bn, self.pool_t, self.first = conv, bn, pool_t, first
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.cin_p = 128 if first else _cpad(self.cin)
+        self.cout_p = _cpad(self.cout)
+
+    # -- operand packing (per forward: parameters may have changed) --
+    def pack(self, dt, need_dgrad):
+        o, dev = ops(), self.conv.weight.device
+        W = self.conv.weight.detach()
+        self.wf, self.wd = [], []
+        if self.first:   # [O][3][kt][kh][kw] -> [O][(kt,kh,kw,c)] padded to [cout_p][128], a 1x1 filter
+            w1 = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
+            w1[:self.cout, :81] = W.permute(0, 2, 3, 4, 1).reshape(self.cout, 81)
+            wf = torch.empty(self.cout_p, 1, 1, 128, dtype=dt, device=dev)
+            o.pack_weight(dt, w1, wf, None, self.cout_p, 128, 1)
+            self.wf.append(wf)
+        else:
+            for kt in range(3):
+                wk = torch.zeros(self.cout_p, self.cin_p, 3, 3, dtype=torch.float32, device=dev)
+                wk[:self.cout, :self.cin] = W[:, :, kt]
+                wf = torch.empty(self.cout_p, 3, 3, self.cin_p, dtype=dt, device=dev)
+                wd = torch.empty(self.cin_p, 3, 3, self.cout_p, dtype=dt, device=dev) if need_dgrad else None
+                o.pack_weight(dt, wk, wf, wd, self.cout_p, self.cin_p, 3)
+                self.wf.append(wf)
+                self.wd.append(wd)
+        pad = self.cout_p - self.cout
+        z, one = torch.zeros(pad, device=dev), torch.ones(pad, device=dev)
+        self.bias_p = torch.cat([self.conv.bias.detach(), z])
+        self.gamma_p = torch.cat([self.bn.weight.detach(), one])
+        self.beta_p = torch.cat([self.bn.bias.detach(), z])
+        self.rmean_p = torch.cat([self.bn.running_mean, z])
+        self.rvar_p = torch.cat([self.bn.running_var, one])
+
+    @staticmethod
+    def _ranges(T, kt):
+        """(dst frame begin, src frame begin, frames) of out[t] += conv(in[t + kt - 1])"""
+        lo = max(0, 1 - kt)
+        hi = min(T, T + 1 - kt)
+        return lo, lo + kt - 1, max(0, hi - lo)
+
+    def forward(self, dt, x, T, B, H, W, training, keep):
+        o, dev = ops(), x.device
+        esz = 2 if dt == torch.bfloat16 else 4
+        rows = T * B * H * W
+        y = torch.empty(rows, self.cout_p, dtype=dt, device=dev)
+        if self.first:
+            d = o.conv_desc(dt, _lib.QT_CONV_FWD, T * B, H, W, 128, self.cout_p, 1, 0)
+            o.igemm(d, _ptr(x), _ptr(self.wf[0]), _ptr(y), shift=self.bias_p)
+        else:
+            frame_in, frame_out = B * H * W * self.cin_p * esz, B * H * W * self.cout_p * esz
+            for n, kt in enumerate((1, 0, 2)):     # the centre tap covers every frame: it goes first and carries the bias
+                dlo, slo, cnt = self._ranges(T, kt)
+                if cnt == 0:
+                    continue
+                d = o.conv_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
+                dst = _ptr(y, dlo * frame_out)
+                o.igemm(d, _ptr(x, slo * frame_in), _ptr(self.wf[kt]), dst, shift=self.bias_p if n == 0 else None,
+                        residual=None if n == 0 else dst)
+        if training:
+            nbt = self.bn.num_batches_tracked
+            stats = o.bn_train(dt, y, rows, self.cout_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, nbt, dev)
+            self.bn.running_mean.copy_(self.rmean_p[:self.cout])
+            self.bn.running_var.copy_(self.rvar_p[:self.cout])
+        else:
+            stats = o.bn_eval(self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, self.cout_p, dev)
+        a = torch.empty_like(y)
+        o.bn_act(dt, y, stats, a, rows, self.cout_p)
+        arg, out, To, Ho, Wo = None, a, T, H, W
+        if self.pool_t:
+            To, Ho, Wo = T // self.pool_t, H // 2, W // 2
+            out = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=dt, device=dev)
+            arg = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=torch.uint8, device=dev) if keep else None
+            o.pool(dt, a, out, arg, T, B, H, W, self.cout_p, self.pool_t)
+        saved = (x, y, a, arg, stats, (T, B, H, W), training) if keep else None
+        return out, (To, Ho, Wo), saved
+
+    def backward(self, dt, dout, saved):
+        """dout: d/d(block output) -> (dx or None, dW, db, dgamma, dbeta)"""
+        o = ops()
+        x, y, a, arg, stats, (T, B, H, W), training = saved
+        dev = x.device
+        esz = 2 if dt == torch.bfloat16 else 4
+        rows = T * B * H * W
+        if self.pool_t:
+            da = torch.empty_like(a)
+            o.pool_bwd(dt, dout, arg, da, T, B, H, W, self.cout_p, self.pool_t)
+        else:
+            da = dout
+        dy, dgamma, dbeta = o.bn_backward(dt, da, a, y, stats, self.gamma_p, rows, self.cout_p, dev, training)
+        db = torch.empty(self.cout_p, dtype=torch.float32, device=dev)
+        o.col_sum(dt, dy, rows, self.cout_p, self.cout_p, db)
+        dW = torch.empty_like(self.conv.weight)
+        dx = None
+        if self.first:
+            d = o.conv_desc(dt, _lib.QT_CONV_FWD, T * B, H, W, 128, self.cout_p, 1, 0)
+            dw = torch.zeros(self.cout_p, 1, 128, dtype=torch.float32, device=dev)
+            o.wgrad(d, _ptr(dy), _ptr(x), dw)
+            dW.copy_(dw[:self.cout, 0, :81].view(self.cout, 3, 3, 3, 3).permute(0, 4, 1, 2, 3))
+        else:
+            frame_in, frame_out = B * H * W * self.cin_p * esz, B * H * W * self.cout_p * esz
+            dx = torch.empty(T * B * H * W, self.cin_p, dtype=dt, device=dev)
+            g4 = torch.empty(self.cout_p, self.cin_p, 3, 3, dtype=torch.float32, device=dev)
+            for n, kt in enumerate((1, 0, 2)):
+                dlo, slo, cnt = self._ranges(T, kt)   # forward: out[dlo + i] read in[slo + i]
+                if cnt == 0:
+                    dW[:, :, kt].zero_()
+                    continue
+                d = o.conv_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
+                dw = torch.zeros(self.cout_p, 9, self.cin_p, dtype=torch.float32, device=dev)
+                o.wgrad(d, _ptr(dy, dlo * frame_out), _ptr(x, slo * frame_in), dw)
+                o.unpack_wgrad(dw, g4, self.cout_p, self.cin_p, 3)
+                dW[:, :, kt].copy_(g4[:self.cout, :self.cin])
+                # data gradient: dx[slo + i] += conv_transpose(dy[dlo + i]); the centre tap writes every frame first
+                dd = o.conv_desc(dt, _lib.QT_CONV_DGRAD, cnt * B, H, W, self.cout_p, self.cin_p, 3, 1)
+                dst = _ptr(dx, slo * frame_in)
+                o.igemm(dd, _ptr(dy, dlo * frame_out), _ptr(self.wd[kt]), dst, residual=None if n == 0 else dst)
+        return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
+
+
+class _Lstm:
+    """nn.LSTM(batch_first) layers on f32 [B][T][I]: input products by qt_gemm_small, recurrences by qt_lstm_*."""
+
+    def __init__(self, lstm):
+        self.m = lstm
+        self.H, self.layers = lstm.hidden_size, lstm.num_layers
+
+    def params(self, k):
+        return (getattr(self.m, f"weight_ih_l{k}"), getattr(self.m, f"weight_hh_l{k}"),
+                getattr(self.m, f"bias_ih_l{k}"), getattr(self.m, f"bias_hh_l{k}"))
+
+    def forward(self, x, B, T, training, seed):
+        o, dev, H = ops(), x.device, self.H
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.saved = []
+        inp = x
+        for k in range(self.layers):
+            w_ih, w_hh, b_ih, b_hh = (p.detach() for p in self.params(k))
+            I = w_ih.shape[1]
+            xproj = torch.empty(B * T, 4 * H, **f32)
+            o.gemm(B * T, 4 * H, I, inp, I, 1, w_ih, I, 1, xproj, 4 * H, b_ih)
+            whh_t = torch.empty(H, 4 * H, **f32)
+            o.check(o.L.qt_transpose_f32(_ptr(w_hh), _ptr(whh_t), 4 * H, H, _lib.stream_ptr()), "qt_transpose_f32")
+            gates, cell = torch.empty(B * T, 4 * H, **f32), torch.empty(B * T, H, **f32)
+            hprev, hout = torch.empty(B * T, H, **f32), torch.empty(B * T, H, **f32)
+            o.check(o.L.qt_lstm_forward(_ptr(xproj), _ptr(whh_t), _ptr(b_hh), _ptr(gates), _ptr(cell), _ptr(hprev), _ptr(hout),
+                                        B, T, H, _lib.stream_ptr()), "qt_lstm_forward")
+            nxt = hout
+            p = self.m.dropout if (training and k + 1 < self.layers) else 0.0
+            if p > 0:   # nn.LSTM drops the outputs of every layer but the last; the recurrent path keeps the undropped h
+                nxt = hout.clone()
+                o.dropout(nxt, B * T, H, H, 0, seed + 17 * (k + 1), p)
+            self.saved.append((inp, gates, cell, hprev, nxt if p > 0 else None, p))
+            inp = nxt
+        return hout   # [B*T][H] of the last layer
+
+    def backward(self, dlast, B, T):
+        """dlast [B][H]: gradient of the last layer's final step -> parameter gradients in nn.LSTM order"""
+        o, dev, H = ops(), dlast.device, self.H
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = [None] * (4 * self.layers)
+        dh_all = None
+        for k in reversed(range(self.layers)):
+            w_ih, w_hh, _, _ = (p.detach() for p in self.params(k))
+            inp, gates, cell, hprev, dropped, p = self.saved[k]
+            I = w_ih.shape[1]
+            dgates = torch.empty(B * T, 4 * H, **f32)
+            o.check(o.L.qt_lstm_backward(_ptr(dh_all), _ptr(dlast) if k == self.layers - 1 else None, _ptr(gates), _ptr(cell),
+                                         _ptr(w_hh), _ptr(dgates), B, T, H, _lib.stream_ptr()), "qt_lstm_backward")
+            dW_ih, dW_hh = torch.empty(4 * H, I, **f32), torch.empty(4 * H, H, **f32)
+            o.gemm(4 * H, I, B * T, dgates, 1, 4 * H, inp, 1, I, dW_ih, I)       # dgates^T x
+            o.gemm(4 * H, H, B * T, dgates, 1, 4 * H, hprev, 1, H, dW_hh, H)     # dgates^T h_{t-1}
+            db = torch.empty(4 * H, **f32)
+            o.col_sum(torch.float32, dgates, B * T, 4 * H, 4 * H, db)
+            grads[4 * k:4 * k + 4] = [dW_ih, dW_hh, db, db.clone()]
+            if k > 0:
+                dx = torch.empty(B * T, I, **f32)
+                o.gemm(B * T, I, 4 * H, dgates, 4 * H, 1, w_ih, 1, I, dx, I)      # dgates W_ih
+                pk = self.saved[k - 1][5]
+                if pk > 0:   # through the inter-layer dropout: from the dropped activations themselves
+                    o.check(o.L.qt_scale_by_nonzero(_ptr(dx), _ptr(self.saved[k - 1][4]), _c.c_longlong(B * T * I),
+                                                    _c.c_float(1.0 / (1.0 - pk)), _lib.stream_ptr()), "qt_scale_by_nonzero")
+                dh_all = dx
+        return grads
+
+
+class _ClipModel(nn.Module):
+    """Shared driver: builds the block list / head description and runs them inside one autograd node."""
+
+    def _init_clip_state(self, compute_dtype):
+        self.compute_dtype = compute_dtype or default_compute_dtype()
+        self._blocks = None
+
+    def _check_inputs(self, image_sequence, numerical_sequence, need_numerical):
+        if image_sequence.dim() != 5 or image_sequence.shape[2] != 3:
+            raise ValueError(f"image_sequence must be [B,T,3,H,W], got {tuple(image_sequence.shape)}")
+        if image_sequence.device.type != "cuda":
+            raise QtError("this build of the model runs on an AMD GPU only: move the model and its inputs to cuda:N "
+                          "(there is no CPU fallback for the product path)")
+        B, T = int(image_sequence.shape[0]), int(image_sequence.shape[1])
+        if need_numerical:
+            if numerical_sequence is None or numerical_sequence.dim() != 3 or \
+                    tuple(numerical_sequence.shape[:2]) != (B, T) or numerical_sequence.shape[2] != self.numerical_feature_dim:
+                raise ValueError(f"numerical_sequence must be [{B},{T},{self.numerical_feature_dim}]")
+
+    def _run(self, image_sequence, numerical_sequence):
+        params = [p for p in self.parameters()]
+        return _ClipFunction.apply(self, image_sequence, numerical_sequence, *params)
+
+
+class _ClipFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, images, numerical, *params):
+        # (grad mode is off inside Function.forward; `needs_input_grad` tells whether a backward may follow)
+        keep = any(ctx.needs_input_grad[3:])
+        with torch.cuda.device(images.device):
+            logits = owner._forward_impl(images, numerical, keep)
+        ctx.owner = owner
+        ctx.fwd_id = owner._fwd_counter
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        owner = ctx.owner
+        if ctx.fwd_id != owner._fwd_counter:
+            raise QtError("backward() after a later forward() on the same model: one set of activations is kept")
+        with torch.cuda.device(dlogits.device):
+            grads = owner._backward_impl(dlogits.contiguous().float())
+        return (None, None, None, *grads)
+
+
+class _Head:
+    """f32 dense tail shared by the two clip models: [image features | LSTM branch] -> classifier"""
+
+    @staticmethod
+    def linear_fwd(x, x_ld, x_off, lin, rows, out, out_ld, out_off, relu):
+        ops().linear(x, x_ld, x_off, lin.weight.detach(), lin.bias.detach(), rows, out, out_ld, out_off, relu)
+
+    @staticmethod
+    def linear_bwd(dy, dy_ld, dy_off, x, x_ld, x_off, lin, rows, want_dx, dx=None, dx_ld=0, dx_off=0):
+        o = ops()
+        W = lin.weight.detach()
+        N, K = W.shape
+        dev = W.device
+        dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev)
+        # dW[n][k] = sum_r dy[r][dy_off + n] * x[r][x_off + k]: A = dy^T (row stride 1, k stride dy_ld)
+        d = _GemmDesc(N, K, rows, _lib.QT_F32, _lib.QT_F32, _lib.QT_F32, 1, dy_ld, 1, x_ld, K, 0, 0)
+        o.check(o.L.qt_gemm_small(_c.byref(d), _ptr(dy, dy_off * 4), _ptr(x, x_off * 4), None, _ptr(dW), _lib.stream_ptr()),
+                "qt_gemm_small")
+        o.check(o.L.qt_col_sum(_lib.QT_F32, _ptr(dy, dy_off * 4), _c.c_longlong(rows), N, dy_ld, _ptr(db), 0, _lib.stream_ptr()),
+                "qt_col_sum")
+        if want_dx:   # dx[r][dx_off + k] = sum_n dy[r][dy_off + n] * W[n][k]
+            d = _GemmDesc(rows, K, N, _lib.QT_F32, _lib.QT_F32, _lib.QT_F32, dy_ld, 1, 1, K, dx_ld, 0, 0)
+            o.check(o.L.qt_gemm_small(_c.byref(d), _ptr(dy, dy_off * 4), _ptr(W), None, _ptr(dx, dx_off * 4), _lib.stream_ptr()),
+                    "qt_gemm_small")
+        return dW, db
+
+    @staticmethod
+    def relu_dropout_bwd(g, act, n, mul=1.0):
+        """g = act > 0 ? g * mul : 0 (ReLU followed by dropout: `act` is the dropped output, mul = 1/(1-p))"""
+        o = ops()
+        o.check(o.L.qt_relu_mask_scale(_lib.QT_F32, _ptr(g), _ptr(act), _c.c_longlong(n), _c.c_float(mul), _lib.stream_ptr()),
+                "qt_relu_mask_scale")
+
+
+class Quadtree3DCNN(_ClipModel):
+    """/root/reference/3dcnn/models.py:96-214."""
+
+    def __init__(self, num_classes, sequence_length=8, cnn_3d_feature_dim=1024, numerical_feature_dim=47, dropout_rate=0.6,
+                 mode='quadtree_3d_fusion', compute_dtype=None):
+        super().__init__()
+        self.mode = mode
+        self.num_classes = num_classes
+        self.sequence_length = sequence_length
+        self.cnn_3d_feature_dim = cnn_3d_feature_dim
+        self.numerical_feature_dim = numerical_feature_dim
+        self.dropout_rate = dropout_rate
+        if cnn_3d_feature_dim % 64:
+            raise ValueError("cnn_3d_feature_dim must be a multiple of 64 for the gfx950 kernels (reference default 1024)")
+
+        def block(cin, cout, pool):
+            layers = [M.Conv3d(cin, cout, 3, padding=1), M.BatchNorm3d(cout), M.ReLU(inplace=True)]
+            if pool:
+                layers.append(M.MaxPool3d(pool, pool))
+            return nn.Sequential(*layers)
+        self.conv3d_block1 = block(3, 32, (1, 2, 2))
+        self.conv3d_block2 = block(32, 64, (2, 2, 2))
+        self.conv3d_block3 = block(64, 128, (2, 2, 2))
+        self.conv3d_block4_new = block(128, 256, (1, 2, 2))
+        self.conv3d_final_features = block(256, cnn_3d_feature_dim, None)
+        self.global_avg_pool_3d = M.AdaptiveAvgPool3d((1, 1, 1))
+        self.numerical_lstm = M.LSTM(numerical_feature_dim, numerical_feature_dim * 4, num_layers=2, batch_first=True,
+                                     dropout=dropout_rate)
+        self.numerical_lstm_output_dim = numerical_feature_dim * 4
+        self.numerical_projection = nn.Sequential(M.Linear(self.numerical_lstm_output_dim, cnn_3d_feature_dim // 2),
+                                                  M.ReLU(inplace=True), M.Dropout(dropout_rate))
+        self.numerical_final_dim = cnn_3d_feature_dim // 2
+        if mode == 'quadtree_3d_fusion':
+            self.final_classifier_input_dim = cnn_3d_feature_dim + self.numerical_final_dim
+        elif mode == 'quadtree_3d_image_only':
+            self.final_classifier_input_dim = cnn_3d_feature_dim
+        else:
+            raise ValueError(f"Invalid mode for Quadtree3DCNN: {mode}. Choose from 'quadtree_3d_fusion', "
+                             "'quadtree_3d_image_only'.")
+        w = self.final_classifier_input_dim
+        self.classifier = nn.Sequential(M.Linear(w, w // 2), M.ReLU(inplace=True), M.Dropout(dropout_rate),
+                                        M.Linear(w // 2, num_classes))
+        self.gradients = None
+        self.activations = None
+        self._fwd_counter = 0
+        self._init_clip_state(compute_dtype)
+        if self.numerical_lstm_output_dim not in (256, 188, 64):
+            raise ValueError("the gfx950 LSTM kernel is instantiated for hidden sizes 256, 188 (= 4 x 47) and 64")
+
+    def save_gradient_hook(self, module, grad_input, grad_output):
+        self.gradients = grad_output[0]
+
+    def save_activation_hook(self, module, input, output):
+        self.activations = output
+
+    def _conv_blocks(self):
+        seqs = (self.conv3d_block1, self.conv3d_block2, self.conv3d_block3, self.conv3d_block4_new, self.conv3d_final_features)
+        pools = (1, 2, 2, 1, 0)
+        return [_ConvBlock(s[0], s[1], p, i == 0) for i, (s, p) in enumerate(zip(seqs, pools))]
+
+    def forward(self, image_sequence_input, numerical_sequence_input):
+        fusion = self.mode == 'quadtree_3d_fusion'
+        if fusion and numerical_sequence_input is not None:
+            numerical_sequence_input = numerical_sequence_input.to(image_sequence_input.device)
+        self._check_inputs(image_sequence_input, numerical_sequence_input, fusion)
+        return self._run(image_sequence_input.contiguous().float(),
+                         numerical_sequence_input.contiguous().float() if fusion else None)
+
+    # ---- the graph --------------------------------------------------------------------------------------------
+    def _forward_impl(self, images, numerical, keep):
+        o, dev, dt = ops(), images.device, self.compute_dtype
+        B, T, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[3]), int(images.shape[4])
+        training = self.training
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
+        blocks = self._conv_blocks()
+        x = torch.empty(T * B * H * W, 128, dtype=dt, device=dev)
+        o.check(o.L.qt_pack_clip27(_lib.qt_dtype(dt), _ptr(images), _ptr(x), B, T, H, W, _lib.stream_ptr()), "qt_pack_clip27")
+        saved_blocks = []
+        t, h, w = T, H, W
+        for blk in blocks:
+            blk.pack(dt, keep)
+            x, (t, h, w), sv = blk.forward(dt, x, t, B, h, w, training, keep)
+            saved_blocks.append(sv)
+        F_img = self.cnn_3d_feature_dim
+        fusion = self.mode == 'quadtree_3d_fusion'
+        ld = self.final_classifier_input_dim
+        fused = torch.empty(B, ld, dtype=torch.float32, device=dev)
+        o.check(o.L.qt_avgpool_tb(_lib.qt_dtype(dt), _ptr(x), _ptr(fused), t, B, h * w, blocks[-1].cout_p, ld, 0,
+                                  _lib.stream_ptr()), "qt_avgpool_tb")
+        p = self.dropout_rate if training else 0.0
+        lstm = last = None
+        if fusion:
+            lstm = _Lstm(self.numerical_lstm)
+            hout = lstm.forward(numerical.view(B * T, -1), B, T, training, seed)
+            Hn = lstm.H
+            last = hout.view(B, T, Hn)[:, -1, :].contiguous()
+            _Head.linear_fwd(last, Hn, 0, self.numerical_projection[0], B, fused, ld, F_img, 1)
+            if p > 0:
+                o.dropout(fused, B, self.numerical_final_dim, ld, F_img, seed + 1, p)
+        hid = torch.empty(B, ld // 2, dtype=torch.float32, device=dev)
+        _Head.linear_fwd(fused, ld, 0, self.classifier[0], B, hid, ld // 2, 0, 1)
+        if p > 0:
+            o.dropout(hid, B, ld // 2, ld // 2, 0, seed + 2, p)
+        logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=dev)
+        _Head.linear_fwd(hid, ld // 2, 0, self.classifier[3], B, logits, self.num_classes, 0, 0)
+        self._fwd_counter += 1
+        self._saved = (blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, last, p) if keep else None
+        return logits
+
+    def _backward_impl(self, dlogits):
+        o, dt = ops(), self.compute_dtype
+        blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, last, p = self._saved
+        dev = dlogits.device
+        ld, F_img = self.final_classifier_input_dim, self.cnn_3d_feature_dim
+        mul = 1.0 / (1.0 - p) if p > 0 else 1.0
+        g = {}
+        dhid = torch.empty(B, ld // 2, dtype=torch.float32, device=dev)
+        g["classifier.3.weight"], g["classifier.3.bias"] = _Head.linear_bwd(
+            dlogits, self.num_classes, 0, hid, ld // 2, 0, self.classifier[3], B, True, dhid, ld // 2, 0)
+        _Head.relu_dropout_bwd(dhid, hid, B * (ld // 2), mul)
+        dfused = torch.empty(B, ld, dtype=torch.float32, device=dev)
+        g["classifier.0.weight"], g["classifier.0.bias"] = _Head.linear_bwd(
+            dhid, ld // 2, 0, fused, ld, 0, self.classifier[0], B, True, dfused, ld, 0)
+        if lstm is not None:
+            Hn, Fn = lstm.H, self.numerical_final_dim
+            dproj = dfused[:, F_img:].contiguous()
+            _Head.relu_dropout_bwd(dproj, fused[:, F_img:].contiguous(), B * Fn, mul)
+            dlast = torch.empty(B, Hn, dtype=torch.float32, device=dev)
+            g["numerical_projection.0.weight"], g["numerical_projection.0.bias"] = _Head.linear_bwd(
+                dproj, Fn, 0, last, Hn, 0, self.numerical_projection[0], B, True, dlast, Hn, 0)
+            lg = lstm.backward(dlast, B, T)
+            for k in range(lstm.layers):
+                for j, nm in enumerate(("weight_ih", "weight_hh", "bias_ih", "bias_hh")):
+                    g[f"numerical_lstm.{nm}_l{k}"] = lg[4 * k + j]
+        # image branch
+        C_last = blocks[-1].cout_p
+        dout = torch.empty(t * B * h * w, C_last, dtype=dt, device=dev)
+        o.check(o.L.qt_avgpool_tb_bwd(_lib.qt_dtype(dt), _ptr(dfused), _ptr(dout), t, B, h * w, C_last, ld, 0, _lib.stream_ptr()),
+                "qt_avgpool_tb_bwd")
+        names = ("conv3d_block1", "conv3d_block2", "conv3d_block3", "conv3d_block4_new", "conv3d_final_features")
+        for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), reversed(names)):
+            dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
+            g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
+        self._saved = None
+        return [g.get(n) for n, _ in self.named_parameters()]
+
+
+class Ji3DCNN(_ClipModel):
+    """/root/reference/cnn+lstm/models.py:93-142."""
+
+    def __init__(self, num_classes, sequence_length=4, numerical_feature_dim=47, dropout_rate=0.5, compute_dtype=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.sequence_length = sequence_length
+        self.numerical_feature_dim = numerical_feature_dim
+        self.dropout_rate = dropout_rate
+
+        def conv_3d_block(cin, cout):
+            return nn.Sequential(M.Conv3d(cin, cout, 3, padding=1), M.BatchNorm3d(cout), M.ReLU(inplace=True))
+        self.visual_stream = nn.Sequential(
+            conv_3d_block(3, 32), M.MaxPool3d((1, 2, 2)), conv_3d_block(32, 64), M.MaxPool3d((2, 2, 2)),
+            conv_3d_block(64, 128), M.AdaptiveAvgPool3d((1, 1, 1)))
+        self.numerical_lstm = M.LSTM(numerical_feature_dim, 64, num_layers=1, batch_first=True)
+        self.classifier = nn.Sequential(M.Linear(128 + 64, 128), M.ReLU(), M.Dropout(dropout_rate), M.Linear(128, num_classes))
+        self._fwd_counter = 0
+        self._init_clip_state(compute_dtype)
+
+    def _conv_blocks(self):
+        vs = self.visual_stream
+        return [_ConvBlock(vs[0][0], vs[0][1], 1, True), _ConvBlock(vs[2][0], vs[2][1], 2, False),
+                _ConvBlock(vs[4][0], vs[4][1], 0, False)]
+
+    def forward(self, image_sequence, numerical_sequence):
+        numerical_sequence = numerical_sequence.to(image_sequence.device)
+        self._check_inputs(image_sequence, numerical_sequence, True)
+        return self._run(image_sequence.contiguous().float(), numerical_sequence.contiguous().float())
+
+    def _forward_impl(self, images, numerical, keep):
+        o, dev, dt = ops(), images.device, self.compute_dtype
+        B, T, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[3]), int(images.shape[4])
+        training = self.training
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
+        blocks = self._conv_blocks()
+        x = torch.empty(T * B * H * W, 128, dtype=dt, device=dev)
+        o.check(o.L.qt_pack_clip27(_lib.qt_dtype(dt), _ptr(images), _ptr(x), B, T, H, W, _lib.stream_ptr()), "qt_pack_clip27")
+        saved_blocks = []
+        t, h, w = T, H, W
+        for blk in blocks:
+            blk.pack(dt, keep)
+            x, (t, h, w), sv = blk.forward(dt, x, t, B, h, w, training, keep)
+            saved_blocks.append(sv)
+        ld = 128 + 64
+        fused = torch.empty(B, ld, dtype=torch.float32, device=dev)
+        o.check(o.L.qt_avgpool_tb(_lib.qt_dtype(dt), _ptr(x), _ptr(fused), t, B, h * w, blocks[-1].cout_p, ld, 0,
+                                  _lib.stream_ptr()), "qt_avgpool_tb")
+        lstm = _Lstm(self.numerical_lstm)
+        hout = lstm.forward(numerical.view(B * T, -1), B, T, training, seed)
+        fused[:, 128:].copy_(hout.view(B, T, 64)[:, -1, :])      # torch.cat((v_out, n_out), dim=1)
+        p = self.dropout_rate if training else 0.0
+        hid = torch.empty(B, 128, dtype=torch.float32, device=dev)
+        _Head.linear_fwd(fused, ld, 0, self.classifier[0], B, hid, 128, 0, 1)
+        if p > 0:
+            o.dropout(hid, B, 128, 128, 0, seed + 2, p)
+        logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=dev)
+        _Head.linear_fwd(hid, 128, 0, self.classifier[3], B, logits, self.num_classes, 0, 0)
+        self._fwd_counter += 1
+        self._saved = (blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, p) if keep else None
+        return logits
+
+    def _backward_impl(self, dlogits):
+        o, dt = ops(), self.compute_dtype
+        blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, p = self._saved
+        dev = dlogits.device
+        ld = 128 + 64
+        mul = 1.0 / (1.0 - p) if p > 0 else 1.0
+        g = {}
+        dhid = torch.empty(B, 128, dtype=torch.float32, device=dev)
+        g["classifier.3.weight"], g["classifier.3.bias"] = _Head.linear_bwd(
+            dlogits, self.num_classes, 0, hid, 128, 0, self.classifier[3], B, True, dhid, 128, 0)
+        _Head.relu_dropout_bwd(dhid, hid, B * 128, mul)
+        dfused = torch.empty(B, ld, dtype=torch.float32, device=dev)
+        g["classifier.0.weight"], g["classifier.0.bias"] = _Head.linear_bwd(
+            dhid, 128, 0, fused, ld, 0, self.classifier[0], B, True, dfused, ld, 0)
+        lg = lstm.backward(dfused[:, 128:].contiguous(), B, T)
+        for j, nm in enumerate(("weight_ih", "weight_hh", "bias_ih", "bias_hh")):
+            g[f"numerical_lstm.{nm}_l0"] = lg[j]
+        C_last = blocks[-1].cout_p
+        dout = torch.empty(t * B * h * w, C_last, dtype=dt, device=dev)
+        o.check(o.L.qt_avgpool_tb_bwd(_lib.qt_dtype(dt), _ptr(dfused), _ptr(dout), t, B, h * w, C_last, ld, 0, _lib.stream_ptr()),
+                "qt_avgpool_tb_bwd")
+        for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), ("visual_stream.4", "visual_stream.2", "visual_stream.0")):
+            dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
+            g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
+        self._saved = None
+        return [g.get(n) for n, _ in self.named_parameters()]

@@ -26,6 +26,8 @@ What each function follows:
   StandardResNetCNN     resnet/models.py:7-65
   AttentionHierarchicalCNN  Quadtree_from scratch/models.py:6-101 (attention_forward; its state_dict has no
                         base_cnn.* keys, see attention_sd_to_base)
+  Quadtree3DCNN         3dcnn/models.py:96-214 (quadtree3d_forward), Ji3DCNN cnn+lstm/models.py:93-142 (ji3d_forward):
+                        Conv3d / BatchNorm3d / MaxPool3d through torch's CPU kernels, LSTM written out gate by gate
   CnnLstm               cnn+lstm/models.py:14-89 (cnn_lstm_forward; keys via cnn_lstm_sd_to_base); the LSTM
                         cell is written out gate by gate (torch.nn.LSTM semantics: gate rows i,f,g,o,
                         c' = f*c + i*g, h' = o*tanh(c'), dropout on layer 0's outputs as layer 1's input)
@@ -252,6 +254,74 @@ def cnn_lstm_forward(sd, image_sequence, numerical_sequence, train=False, dropou
     hdn = F.relu(F.linear(final, sd["classifier.0.weight"], sd["classifier.0.bias"]))
     hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
     return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
+def _lstm_named(sd, prefix, layer, x):
+    """_lstm_layer with another parameter prefix (numerical_lstm.*)"""
+    view = {f"lstm.{n}_l{layer}": sd[f"{prefix}.{n}_l{layer}"] for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+    return _lstm_layer(view, layer, x)
+
+
+def _conv3d_block(sd, prefix, x, train, pool):
+    """Conv3d(3x3x3, padding 1, bias) + BatchNorm3d + ReLU (+ MaxPool3d(pool)): `prefix`.0 = conv, `prefix`.1 = bn"""
+    x = F.conv3d(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"], stride=1, padding=1)
+    x = F.batch_norm(x, sd[f"{prefix}.1.running_mean"], sd[f"{prefix}.1.running_var"], sd[f"{prefix}.1.weight"],
+                     sd[f"{prefix}.1.bias"], training=train, momentum=0.1, eps=1e-5)
+    x = F.relu(x)
+    return F.max_pool3d(x, pool, pool) if pool else x
+
+
+def quadtree3d_forward(sd, image_sequence, numerical_sequence, mode="quadtree_3d_fusion", train=False, dropout_p=0.6,
+                       masks=None, taps=None):
+    """logits[B,C] of Quadtree3DCNN (3dcnn/models.py:184-214): image_sequence [B,T,3,H,W], numerical_sequence [B,T,47]."""
+    x = image_sequence.permute(0, 2, 1, 3, 4)                                                   # :189
+    for prefix, pool in (("conv3d_block1", (1, 2, 2)), ("conv3d_block2", (2, 2, 2)), ("conv3d_block3", (2, 2, 2)),
+                         ("conv3d_block4_new", (1, 2, 2)), ("conv3d_final_features", None)):     # :191-196
+        x = _conv3d_block(sd, prefix, x, train, pool)
+        if taps is not None:
+            taps[prefix] = x
+    feats = F.adaptive_avg_pool3d(x, (1, 1, 1)).flatten(1)                                        # :198
+    if mode == "quadtree_3d_fusion":
+        h0 = _lstm_named(sd, "numerical_lstm", 0, numerical_sequence)                             # :201
+        h1 = _lstm_named(sd, "numerical_lstm", 1, _dropout(h0, dropout_p, train, masks, "lstm"))
+        z = F.relu(F.linear(h1[:, -1, :], sd["numerical_projection.0.weight"], sd["numerical_projection.0.bias"]))
+        z = _dropout(z, dropout_p, train, masks, "projection")                                    # :203
+        feats = torch.cat((feats, z), dim=1)                                                      # :206
+    elif mode != "quadtree_3d_image_only":
+        raise ValueError(f"Invalid mode during forward pass: {mode}")
+    if taps is not None:
+        taps["fused"] = feats
+    hdn = F.relu(F.linear(feats, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
+    return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])                     # :212
+
+
+def ji3d_forward(sd, image_sequence, numerical_sequence, train=False, dropout_p=0.5, masks=None, taps=None):
+    """logits[B,C] of Ji3DCNN (cnn+lstm/models.py:126-142)."""
+    x = image_sequence.permute(0, 2, 1, 3, 4)                                                    # :131
+    for prefix, pool in (("visual_stream.0", (1, 2, 2)), ("visual_stream.2", (2, 2, 2)), ("visual_stream.4", None)):
+        x = _conv3d_block(sd, prefix, x, train, None)      # (the pools are modules of their own here: :101,103)
+        if taps is not None:
+            taps[prefix] = x
+        if pool:
+            x = F.max_pool3d(x, pool, pool)
+    v_out = F.adaptive_avg_pool3d(x, (1, 1, 1)).flatten(1)                                        # :132
+    n_out = _lstm_named(sd, "numerical_lstm", 0, numerical_sequence)[:, -1, :]                    # :135-136
+    fused = torch.cat((v_out, n_out), dim=1)                                                      # :139
+    hdn = F.relu(F.linear(fused, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    hdn = _dropout(hdn, dropout_p, train, masks, "classifier")
+    return F.linear(hdn, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
+def clip_params(sd):
+    """requires_grad leaf copies of every parameter of a clip model's state_dict (buffers cloned plain)"""
+    out = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if t.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
 
 
 def unique_params(sd, keys):

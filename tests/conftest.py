@@ -38,3 +38,9 @@ def golden_attn():
 def golden_cnn_lstm():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "cnn_lstm_b2t3.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_clip3d():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "clip3d.npz"))

@@ -18,6 +18,8 @@ Usage (from the repo root):  python tests/golden/make_golden.py            (eval
                                                                             Quadtree_from scratch/models.py:6-101)
                              python tests/golden/make_golden.py cnn_lstm   (cnn_lstm_b2t3.npz: CnnLstm,
                                                                             cnn+lstm/models.py:14-89)
+                             python tests/golden/make_golden.py clip3d     (clip3d.npz: Quadtree3DCNN 3dcnn/models.py:96-214
+                                                                            and Ji3DCNN cnn+lstm/models.py:93-142)
 """
 import importlib
 import importlib.util
@@ -276,8 +278,74 @@ def main_cnn_lstm():
     print("cnn_lstm_b2t3.npz:", len(out), "arrays")
 
 
+def clip_case(m, images, feats, labels, out, prefix, conv_names):
+    """eval logits + taps, then a dropout-free train step (all gradients, running statistics) of a clip model"""
+    taps = {}
+    hs = [dict(m.named_modules())[n].register_forward_hook(lambda _m, _i, o, n=n: taps.__setitem__(n, o.detach()))
+          for n in conv_names]
+    m.eval()
+    with torch.no_grad():
+        logits = m(images, feats)
+    for h in hs:
+        h.remove()
+    out[f"{prefix}/eval/logits"] = logits.numpy()
+    for k, v in taps.items():
+        put(out, f"{prefix}/eval/tap/{k}", v)
+    m.train()
+    set_dropout_p(m, 0.0)
+    m.numerical_lstm.dropout = 0.0
+    logits = m(images, feats)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out[f"{prefix}/train/logits"] = logits.detach().numpy()
+    out[f"{prefix}/train/loss"] = np.float64(loss.item())
+    names = []
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(name)
+            put(out, f"{prefix}/train/grad/{name}", p.grad)
+    out[f"{prefix}/train/grad_names"] = np.array(names)
+    for name, b in m.named_buffers():
+        if name.endswith(("running_mean", "running_var")):
+            put(out, f"{prefix}/train/buf/{name}", b, full_below=0)
+    out[f"{prefix}/meta/state_dict_keys"] = np.array(list(m.state_dict().keys()))
+    out[f"{prefix}/meta/param_names"] = np.array([n for n, _ in m.named_parameters()])
+    out[f"{prefix}/meta/trainable"] = np.int64(sum(p.numel() for p in m.parameters() if p.requires_grad))
+
+
+def main_clip3d():
+    """3-D clip models run by the reference's own classes: Quadtree3DCNN (3dcnn/models.py:96-214; T = 8 at 112x112 and
+    the trainer's SEQUENCE_LENGTH = 5 at 64x64: odd length, frames dropped by the floor-mode pools) and Ji3DCNN
+    (cnn+lstm/models.py:93-142; T = 4 at 64x64)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    q3 = load_ref(os.path.join(REF, "3dcnn", "models.py"), "ref_3d_models")
+    cl = load_ref(os.path.join(REF, "cnn+lstm", "models.py"), "ref_cl_models")
+    C = 12
+    out = {}
+    blocks = ["conv3d_block1", "conv3d_block2", "conv3d_block3", "conv3d_block4_new", "conv3d_final_features"]
+    for tag, B, T, HW, mode in (("q3_t8", 2, 8, 112, "quadtree_3d_fusion"), ("q3_t5", 2, 5, 64, "quadtree_3d_fusion"),
+                                ("q3_img_t8", 2, 8, 64, "quadtree_3d_image_only")):
+        m = q3.get_model(C, "cpu", mode=mode, sequence_length=T, print_num_params=False)
+        m.load_state_dict(synth.synth_state_dict(m))
+        images = synth.synth_images(B * T, salt=31, size=HW).view(B, T, 3, HW, HW)
+        feats = synth.synth_pose_features(B * T, salt=31, realistic=True).view(B, T, 47)
+        clip_case(m, images, feats, synth.synth_labels(B, C, salt=31), out, tag, blocks)
+    m = cl.get_model("3d_cnn", C, "cpu", seq_len=4)
+    m.load_state_dict(synth.synth_state_dict(m))
+    B, T, HW = 2, 4, 64
+    images = synth.synth_images(B * T, salt=32, size=HW).view(B, T, 3, HW, HW)
+    feats = synth.synth_pose_features(B * T, salt=32, realistic=True).view(B, T, 47)
+    clip_case(m, images, feats, synth.synth_labels(B, C, salt=32), out, "ji_t4",
+              ["visual_stream.0", "visual_stream.2", "visual_stream.4"])
+    np.savez_compressed(os.path.join(HERE, "clip3d.npz"), **out)
+    print("clip3d.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "attention":
+    if len(sys.argv) > 1 and sys.argv[1] == "clip3d":
+        main_clip3d()
+    elif len(sys.argv) > 1 and sys.argv[1] == "attention":
         main_attention()
     elif len(sys.argv) > 1 and sys.argv[1] == "cnn_lstm":
         main_cnn_lstm()

@@ -1,0 +1,306 @@
+"""GPU parity of the 3-D clip models (BASELINE config 4): Quadtree3DCNN
+(/root/reference/3dcnn/models.py:96-214) and Ji3DCNN (/root/reference/cnn+lstm/models.py:93-142) on the HIP kernels.
+
+* op level through the C ABI: MaxPool3d (1,2,2) / (2,2,2) forward + backward, BatchNorm3d statistics, the 27-tap clip
+  packing, AdaptiveAvgPool3d -- against torch CPU;
+* whole models against the vectors the reference classes produced (tests/golden/clip3d.npz): eval logits + block outputs,
+  a dropout-free train step (loss, every gradient, running statistics); f32 build: logits <= 1e-3, head / LSTM gradients
+  <= 1e-3, conv gradients by the ReLU-flip-aware rule of tests/test_model_gpu.py; bf16 build: stated loose bounds;
+* BASELINE config 4 at its own size (T = 8 frames of 224x224) against the CPU oracle run on the box;
+* the drop-in `from models import get_model` of 3dcnn/ and cnn+lstm/ ('3d_cnn') with the trainer's loop body, including
+  clip_grad_norm_ (3dcnn/train_3D_Quadtree_cnn_model.py:111-125).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import PKG, ROOT, check_summary, pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = {torch.float32: 1e-3, torch.bfloat16: 6e-2}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _oracle():
+    sys.path.insert(0, ROOT)
+    import oracle.quadtree_oracle as o
+    return o
+
+
+def _cos(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
+def _inputs(B, T, HW, salt):
+    synth = pkg("synth")
+    return (synth.synth_images(B * T, salt=salt, size=HW).view(B, T, 3, HW, HW),
+            synth.synth_pose_features(B * T, salt=salt, realistic=True).view(B, T, 47), synth.synth_labels(B, 12, salt=salt))
+
+
+def _to_tb(x_ncthw):
+    """[B][C][T][H][W] -> time-major NHWC [T][B][H][W][C]"""
+    return x_ncthw.permute(2, 0, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pt,T,H", [(1, 3, 10), (2, 5, 9), (2, 4, 8)])
+def test_maxpool3d_forward_backward(dt, pt, T, H):
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    B, C, W = 2, 16, H + 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, T, H, W, generator=g).to(dt).float().requires_grad_(True)
+    ref = F.max_pool3d(x, (pt, 2, 2), (pt, 2, 2))
+    dref = torch.randn(ref.shape, generator=g).to(dt).float()
+    ref.backward(dref)
+    To, Ho, Wo = T // pt, H // 2, W // 2
+    xd = _to_tb(x.detach()).to(dev, dt)
+    out = torch.empty(To, B, Ho, Wo, C, dtype=dt, device=dev)
+    arg = torch.empty(To, B, Ho, Wo, C, dtype=torch.uint8, device=dev)
+    L.check(lib.qt_pool3d_max(L.qt_dtype(dt), L.ptr(xd), L.ptr(out), L.ptr(arg), T, B, H, W, C, pt, L.stream_ptr()), "pool")
+    assert torch.equal(out.float().cpu(), _to_tb(ref.detach()))
+    dd = _to_tb(dref).to(dev, dt)
+    dx = torch.full((T, B, H, W, C), 9.0, dtype=dt, device=dev)
+    L.check(lib.qt_pool3d_max_bwd(L.qt_dtype(dt), L.ptr(dd), L.ptr(arg), L.ptr(dx), T, B, H, W, C, pt, L.stream_ptr()), "pool bwd")
+    assert torch.equal(dx.float().cpu(), _to_tb(x.grad))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_bn_stats_pack_and_avgpool(dt):
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    lib.qt_bn_stats_rows.argtypes = [ctypes.c_longlong, ctypes.c_int]
+    g = torch.Generator().manual_seed(6)
+    for M, C in ((70001, 64), (513, 1024), (255, 8)):
+        y = torch.randn(M, C, generator=g).to(dt)
+        rows = lib.qt_bn_stats_rows(M, C)
+        part = torch.zeros(rows, 2, C, device=dev)
+        L.check(lib.qt_bn_stats(L.qt_dtype(dt), L.ptr(y.to(dev)), ctypes.c_longlong(M), C, L.ptr(part), L.stream_ptr()), "bn_stats")
+        s = part.sum(0).cpu()
+        yd = y.double()
+        assert rel_err(s[0], yd.sum(0)) <= 1e-4 and rel_err(s[1], (yd * yd).sum(0)) <= 1e-5
+    # clip packing: [B][T][3][H][W] -> [T][B][H][W][128] = the 27 taps x 3 channels of a pixel
+    B, T, H, W = 2, 3, 6, 5
+    clips = torch.randn(B, T, 3, H, W, generator=g)
+    dst = torch.empty(T, B, H, W, 128, dtype=dt, device=dev)
+    L.check(lib.qt_pack_clip27(L.qt_dtype(dt), L.ptr(clips.to(dev)), L.ptr(dst), B, T, H, W, L.stream_ptr()), "pack")
+    xp = F.pad(clips.permute(0, 2, 1, 3, 4), (1, 1, 1, 1, 1, 1))            # [B][3][T+2][H+2][W+2]
+    ref = torch.zeros(T, B, H, W, 128)
+    for kt in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                k0 = ((kt * 3 + kh) * 3 + kw) * 3
+                ref[..., k0:k0 + 3] = xp[:, :, kt:kt + T, kh:kh + H, kw:kw + W].permute(2, 0, 3, 4, 1)
+    assert torch.equal(dst.float().cpu(), ref.to(dt).float())
+    # AdaptiveAvgPool3d((1,1,1)) + flatten into columns of an f32 matrix, and its backward
+    T, B, HW, C, ld, col0 = 2, 3, 12, 64, 100, 20
+    x = torch.randn(T, B, HW, C, generator=g).to(dt)
+    out = torch.zeros(B, ld, device=dev)
+    L.check(lib.qt_avgpool_tb(L.qt_dtype(dt), L.ptr(x.to(dev)), L.ptr(out), T, B, HW, C, ld, col0, L.stream_ptr()), "avgpool_tb")
+    assert rel_err(out[:, col0:col0 + C].cpu(), x.float().mean((0, 2))) <= 1e-5
+    d = torch.randn(B, ld, generator=g)
+    gx = torch.empty(T, B, HW, C, dtype=dt, device=dev)
+    L.check(lib.qt_avgpool_tb_bwd(L.qt_dtype(dt), L.ptr(d.to(dev)), L.ptr(gx), T, B, HW, C, ld, col0, L.stream_ptr()), "avgpool_tb_bwd")
+    want = (d[:, col0:col0 + C] / (T * HW)).view(1, B, 1, C).expand(T, B, HW, C)
+    assert rel_err(gx.float().cpu(), want) <= (1e-6 if dt == torch.float32 else 1e-2)
+
+
+CASES = [("q3_t8", 2, 8, 112, "quadtree_3d_fusion", 31), ("q3_t5", 2, 5, 64, "quadtree_3d_fusion", 31),
+         ("q3_img_t8", 2, 8, 64, "quadtree_3d_image_only", 31), ("ji_t4", 2, 4, 64, None, 32)]
+
+
+def _build(mode, T, dt, dropout=0.0):
+    P, synth = pkg(), pkg("synth")
+    m = P.Ji3DCNN(12, sequence_length=T, dropout_rate=dropout, compute_dtype=dt) if mode is None else \
+        P.Quadtree3DCNN(12, sequence_length=T, mode=mode, dropout_rate=dropout, compute_dtype=dt)
+    m.load_state_dict(synth.synth_state_dict(m))
+    return m
+
+
+def _is_conv_bias_before_bn(name):
+    return name.endswith(".0.bias") and (name.startswith("conv3d_") or name.startswith("visual_stream."))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag,B,T,HW,mode,salt", CASES)
+def test_clip_models_match_reference_golden(dt, tag, B, T, HW, mode, salt, golden_clip3d):
+    dev = _dev()
+    g = golden_clip3d
+    x, f, y = _inputs(B, T, HW, salt)
+    m = _build(mode, T, dt).to(dev).eval()
+    with torch.no_grad():
+        logits = m(x.to(dev), f.to(dev))
+    assert rel_err(logits.cpu(), g[f"{tag}/eval/logits"]) <= LOGIT_TOL[dt]
+    m.train()
+    out = m(x.to(dev), f.to(dev))
+    loss = F.cross_entropy(out, y.to(dev))
+    loss.backward()
+    assert rel_err(out.detach().cpu(), g[f"{tag}/train/logits"]) <= LOGIT_TOL[dt]
+    assert abs(loss.item() - float(g[f"{tag}/train/loss"])) <= (1e-3 if dt == torch.float32 else 6e-2) * max(1.0, abs(float(g[f"{tag}/train/loss"])))
+    params = dict(m.named_parameters())
+    for name in [str(n) for n in g[f"{tag}/train/grad_names"]]:
+        grad = params[name].grad
+        assert grad is not None and torch.isfinite(grad).all(), name
+        gold_s = g[f"{tag}/train/grad/{name}/sample"]
+        if _is_conv_bias_before_bn(name):   # exactly zero in exact arithmetic (the batch mean removes the bias): bounded
+            wmax = float(np.abs(g[f"{tag}/train/grad/{name[:-4]}weight/sample"]).max())
+            assert float(grad.abs().max()) <= (1e-2 if dt == torch.float32 else 2e-1) * wmax + 1e-5, name
+            continue
+        fl = grad.detach().double().flatten().cpu()
+        stride = max(1, fl.numel() // 256)
+        smp = fl[::stride][:256].numpy()
+        head = name.split(".")[0] in ("classifier", "numerical_projection", "numerical_lstm")
+        if dt == torch.float32:
+            # (conv gradients pass ReLU / max-pool decisions: a flipped decision moves everything below it)
+            assert _cos(smp, gold_s) >= (0.9999 if head else 0.999), (name, _cos(smp, gold_s))
+            assert float(np.abs(smp - gold_s).max()) <= (2e-3 if head else 6e-2) * max(float(np.abs(gold_s).max()), 1e-30), name
+        else:
+            assert _cos(smp, gold_s) >= (0.98 if head else 0.8), (name, _cos(smp, gold_s))
+    bufs = dict(m.named_buffers())
+    for k in g.files:
+        if k.startswith(f"{tag}/train/buf/") and k.endswith("/shape"):
+            n = k[len(f"{tag}/train/buf/"):-len("/shape")]
+            check_summary(bufs[n].cpu(), g, f"{tag}/train/buf/{n}", 1e-4 if dt == torch.float32 else 3e-2)
+
+
+def test_quadtree3d_config4_size_matches_oracle():
+    """BASELINE config 4 at its own size: clips of T = 8 frames of 224x224 (f32 build against the CPU oracle on the box;
+    bf16 build: stated bound) -- eval logits and the dropout-free train step's loss."""
+    dev = _dev()
+    o = _oracle()
+    B, T, HW = 2, 8, 224
+    x, f, y = _inputs(B, T, HW, 77)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    m = _build("quadtree_3d_fusion", T, torch.float32)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = o.quadtree3d_forward(sd0, x, f)
+    sd = o.clip_params(sd0)
+    ref_loss = F.cross_entropy(o.quadtree3d_forward(sd, x, f, train=True, dropout_p=0.0), y)
+    for dt in (torch.float32, torch.bfloat16):
+        mm = _build("quadtree_3d_fusion", T, dt).to(dev).eval()
+        with torch.no_grad():
+            got = mm(x.to(dev), f.to(dev)).cpu()
+        assert rel_err(got, ref) <= LOGIT_TOL[dt], (dt, rel_err(got, ref))
+        mm.train()
+        loss = F.cross_entropy(mm(x.to(dev), f.to(dev)), y.to(dev))
+        loss.backward()
+        assert abs(loss.item() - ref_loss.item()) <= (1e-3 if dt == torch.float32 else 6e-2) * max(1.0, abs(ref_loss.item()))
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mm.parameters())
+        del mm
+        torch.cuda.empty_cache()
+
+
+def test_dropout_train_mode_and_eval_backward_and_errors():
+    dev = _dev()
+    P = pkg()
+    QtError = pkg("_lib").QtError
+    B, T, HW = 2, 4, 32
+    x, f, y = _inputs(B, T, HW, 5)
+    m = _build("quadtree_3d_fusion", T, torch.bfloat16, dropout=0.6).to(dev).train()
+    out = m(x.to(dev), f.to(dev))
+    F.cross_entropy(out, y.to(dev)).backward()
+    assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    with pytest.raises(QtError):
+        m(x, f)                                            # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        m(x.to(dev)[:, :, :2], f.to(dev))                  # not 3 channels
+    with pytest.raises(ValueError):
+        P.Quadtree3DCNN(12, mode="bogus")
+    # the numerical sequence may arrive on the CPU (3dcnn/train_3D_Quadtree_cnn_model.py:113 moves only the clips)
+    m.eval()
+    with torch.no_grad():
+        a = m(x.to(dev), f)
+        b = m(x.to(dev), f.to(dev))
+    assert torch.equal(a, b)
+
+
+class _sibling_models:
+    def __init__(self, sub):
+        self.dir = os.path.join(ROOT, PKG, sub)
+
+    def __enter__(self):
+        import importlib
+        sys.modules.pop("models", None)
+        sys.path.insert(0, self.dir)
+        return importlib.import_module("models")
+
+    def __exit__(self, *exc):
+        sys.path.remove(self.dir)
+        sys.modules.pop("models", None)
+
+
+def test_dropin_3dcnn_trainer_loop(monkeypatch, tmp_path, capsys):
+    """3dcnn/train_3D_Quadtree_cnn_model.py:80-86,111-125: get_model(mode=..., sequence_length=...), zero_grad, forward,
+    CrossEntropyLoss, backward, clip_grad_norm_(model.parameters(), 1.0), Adam step; then cnn+lstm's '3d_cnn'."""
+    dev = _dev()
+    o = _oracle()
+    synth = pkg("synth")
+    monkeypatch.setenv("QTCNN_DTYPE", "f32")
+    B, T, HW = 2, 5, 64
+    x, f, y = _inputs(B, T, HW, 31)
+    with _sibling_models("threed_cnn") as models:
+        model = models.get_model(num_classes=12, device=dev, mode="quadtree_3d_fusion", sequence_length=T)
+        assert "(Mode: quadtree_3d_fusion)" in capsys.readouterr().out
+        for mod in model.modules():
+            if type(mod).__name__ == "Dropout":
+                mod.p = 0.0
+        model.dropout_rate = 0.0
+        model.numerical_lstm.dropout = 0.0
+        model.load_state_dict({k: v.to(dev) for k, v in synth.synth_state_dict(model).items()})
+        sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        criterion = torch.nn.CrossEntropyLoss()
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        model.train()
+        losses = []
+        for _ in range(2):
+            optimizer.zero_grad()
+            outputs = model(x.to(dev), f)          # (the trainer leaves the numerical sequence where the loader put it)
+            loss = criterion(outputs, y.to(dev))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            optimizer.step()
+            losses.append(loss.item())
+        sd = o.clip_params(sd0)
+        opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-4, weight_decay=1e-4)
+        ref = []
+        for _ in range(2):
+            opt.zero_grad()
+            l = F.cross_entropy(o.quadtree3d_forward(sd, x, f, train=True, dropout_p=0.0), y)
+            l.backward()
+            torch.nn.utils.clip_grad_norm_([v for v in sd.values() if v.requires_grad], 1.0)
+            opt.step()
+            ref.append(l.item())
+        assert abs(losses[0] - ref[0]) <= 1e-3 * max(1.0, abs(ref[0]))
+        assert abs(losses[1] - ref[1]) <= 3e-2 * max(1.0, abs(ref[1]))
+        path = os.path.join(tmp_path, "m.pth")
+        torch.save(model.state_dict(), path)
+        fresh = models.get_model(num_classes=12, device=dev, mode="quadtree_3d_fusion", sequence_length=T, print_num_params=False)
+        fresh.load_state_dict(torch.load(path, map_location=dev))
+        model.eval(); fresh.eval()
+        with torch.no_grad():
+            assert torch.equal(model(x.to(dev), f), fresh(x.to(dev), f))
+        for bad in ("resnet_3d_video_only", "hybrid_quadtree_3d_fusion"):
+            with pytest.raises(NotImplementedError):
+                models.get_model(num_classes=12, device=dev, mode=bad)
+    with _sibling_models("cnn_lstm") as models:
+        ji = models.get_model("3d_cnn", 12, dev, seq_len=4)
+        assert type(ji).__name__ == "Ji3DCNN"
+        xj, fj, yj = _inputs(2, 4, 64, 32)
+        ji.eval()
+        with torch.no_grad():
+            assert ji(xj.to(dev), fj.to(dev)).shape == (2, 12)

@@ -155,3 +155,59 @@ def test_numpy_float64_restatement_agrees_with_reference(golden_eval):
     gold = golden_eval["qs_quadtree_eval/logits"].astype(np.float64)
     # the reference ran in fp32: allow fp32 rounding through 20 layers
     assert float(np.abs(logits - gold).max() / np.abs(gold).max()) <= 2e-5
+
+
+# ---- 3-D clip models: the oracle's restatement against vectors the reference classes produced ----
+CLIP_CASES = [("q3_t8", 2, 8, 112, "quadtree_3d_fusion", 31), ("q3_t5", 2, 5, 64, "quadtree_3d_fusion", 31),
+              ("q3_img_t8", 2, 8, 64, "quadtree_3d_image_only", 31), ("ji_t4", 2, 4, 64, None, 32)]
+
+
+def _is_conv_bias_before_bn(name):
+    return name.endswith(".0.bias") and (name.startswith("conv3d_") or name.startswith("visual_stream."))
+
+
+def _clip_inputs(B, T, HW, salt):
+    synth = pkg("synth")
+    return (synth.synth_images(B * T, salt=salt, size=HW).view(B, T, 3, HW, HW),
+            synth.synth_pose_features(B * T, salt=salt, realistic=True).view(B, T, 47), synth.synth_labels(B, 12, salt=salt))
+
+
+@pytest.mark.parametrize("tag,B,T,HW,mode,salt", CLIP_CASES)
+def test_clip3d_oracle_matches_reference_golden(tag, B, T, HW, mode, salt, golden_clip3d):
+    import oracle.quadtree_oracle as o
+    P, synth = pkg(), pkg("synth")
+    g = golden_clip3d
+    m = P.Ji3DCNN(12, sequence_length=T) if mode is None else P.Quadtree3DCNN(12, sequence_length=T, mode=mode)
+    sd0 = synth.synth_state_dict(m)
+    # same keys, same parameter order, same trainable count as the reference class
+    assert list(sd0.keys()) == [str(k) for k in g[f"{tag}/meta/state_dict_keys"]]
+    assert [n for n, _ in m.named_parameters()] == [str(k) for k in g[f"{tag}/meta/param_names"]]
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == int(g[f"{tag}/meta/trainable"])
+    x, f, y = _clip_inputs(B, T, HW, salt)
+    fwd = (lambda sd, **kw: o.ji3d_forward(sd, x, f, **kw)) if mode is None else \
+        (lambda sd, **kw: o.quadtree3d_forward(sd, x, f, mode=mode, **kw))
+    with torch.no_grad():
+        taps = {}
+        logits = fwd(sd0, taps=taps)
+    assert rel_err(logits, g[f"{tag}/eval/logits"]) <= 2e-5
+    for name, t in taps.items():
+        if f"{tag}/eval/tap/{name}/shape" in g.files:
+            check_summary(t, g, f"{tag}/eval/tap/{name}", 2e-5)
+    sd = o.clip_params(sd0)
+    out = fwd(sd, train=True, dropout_p=0.0)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert rel_err(out.detach(), g[f"{tag}/train/logits"]) <= 2e-5
+    assert abs(loss.item() - float(g[f"{tag}/train/loss"])) <= 2e-5 * max(1.0, abs(float(g[f"{tag}/train/loss"])))
+    for name in [str(n) for n in g[f"{tag}/train/grad_names"]]:
+        if _is_conv_bias_before_bn(name):
+            # a bias in front of a train-mode BatchNorm has an exactly zero gradient (the batch mean removes it): what
+            # either side holds is rounding noise, so it is bounded against the weight gradient instead of compared
+            wmax = float(np.abs(g[f"{tag}/train/grad/{name[:-4]}weight/sample"]).max())
+            assert float(sd[name].grad.abs().max()) <= 1e-3 * wmax + 1e-6, name
+            continue
+        check_summary(sd[name].grad, g, f"{tag}/train/grad/{name}", 5e-4)
+    for k in g.files:
+        if k.startswith(f"{tag}/train/buf/") and k.endswith("/shape"):
+            n = k[len(f"{tag}/train/buf/"):-len("/shape")]
+            check_summary(sd[n], g, f"{tag}/train/buf/{n}", 2e-5)
