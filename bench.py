@@ -90,10 +90,11 @@ def parse():
                     help="--model quadtree: the resnet/ variant of the reference (resnet/models.py:77-78: base_cnn frozen, "
                          "train-mode BatchNorm statistics still updated); a secondary line, 3.9454 GFLOP/image")
     ap.add_argument("--seq-len", type=int, default=16, help="--model cnn_lstm: frames per sequence (BASELINE config 5: 16)")
-    ap.add_argument("--model", default="quadtree", choices=["quadtree", "attention", "cnn_lstm"],
+    ap.add_argument("--model", default="quadtree", choices=["quadtree", "attention", "cnn_lstm", "quadtree3d"],
                     help="quadtree = QuadtreeCNN (BASELINE config 2/3, the headline); attention = AttentionHierarchicalCNN "
                          "(reference models.py:6-101, SURVEY.md 8f rank 2), cnn_lstm = CnnLstm (cnn+lstm/models.py:14-89, "
-                         "rank 3; --batch counts FRAMES per GPU) as secondary lines")
+                         "rank 3; --batch counts FRAMES per GPU), quadtree3d = Quadtree3DCNN (3dcnn/models.py:96-214, rank 4, "
+                         "BASELINE config 4: clips of --seq-len 8 frames; --batch counts FRAMES per GPU) as secondary lines")
     ap.add_argument("--forward-only", action="store_true", help="time eval-mode forward instead of the train step")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="Adam(lr 1e-4, wd 1e-4) by the package's FusedAdam kernel (default) or torch.optim.Adam(fused=True)")
@@ -315,9 +316,13 @@ def main():
     dp = importlib.import_module(PKG + ".dp")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     C, B = 12, args.batch
-    if args.model == "cnn_lstm":
-        if B % args.seq_len:
-            raise SystemExit("--batch (frames) must be a multiple of --seq-len")
+    if args.model == "quadtree3d" and args.seq_len == 16:
+        args.seq_len = 8   # (the default of --seq-len is config 5's 16; config 4 quotes T = 8)
+    if args.model in ("cnn_lstm", "quadtree3d") and B % args.seq_len:
+        raise SystemExit("--batch (frames) must be a multiple of --seq-len")
+    if args.model == "quadtree3d":
+        model = P.Quadtree3DCNN(C, sequence_length=args.seq_len, compute_dtype=dt)
+    elif args.model == "cnn_lstm":
         model = P.CnnLstm(C, sequence_length=args.seq_len, compute_dtype=dt, max_batch=B)
     elif args.model == "attention":
         model = P.AttentionHierarchicalCNN(C, compute_dtype=dt, max_batch=B)
@@ -333,6 +338,8 @@ def main():
         opt = P.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-4, model=model)
     elif args.model == "cnn_lstm":
         opt = P.FusedAdam(trainable, lr=1e-4, model=model)  # cnn+lstm/training.py:93: Adam(lr 1e-4), no weight decay
+    elif args.model == "quadtree3d":
+        opt = P.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-4)  # multi-tensor Adam kernel (no plan behind this model)
     elif args.optimizer == "fused":
         # the package's Adam: same update rule, run inside the one-launch weight re-packing (csrc/pack.hip)
         opt = P.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-4, model=model)
@@ -343,7 +350,7 @@ def main():
     images = torch.randn(B, 3, 224, 224, device=dev, generator=g)
     feats = torch.randn(B, 47, device=dev, generator=g)
     labels = torch.randint(0, C, (B,), device=dev, generator=g)
-    if args.model == "cnn_lstm":
+    if args.model in ("cnn_lstm", "quadtree3d"):
         S, T = B // args.seq_len, args.seq_len
         images, feats, labels = images.view(S, T, 3, 224, 224), feats.view(S, T, 47), labels[:S].contiguous()
 
@@ -384,7 +391,7 @@ def main():
 
     # ---- roofline of the MFMA kernels: per-launch HIP events in extra steps ----
     roofline = None
-    eng = model._engine
+    eng = getattr(model, "_engine", None)
     if eng is not None and args.profile_steps > 0:
         L = eng.L
         L.qt_plan_profile_begin.argtypes = [ctypes.c_void_p]
@@ -477,7 +484,7 @@ def main():
             t = torch.tensor([ft], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ft = float(t.item())
-        fwd_gflop = {"quadtree": FWD_GFLOP_PER_IMAGE, "attention": 3.9765, "cnn_lstm": 3.6311}[args.model]
+        fwd_gflop = {"quadtree": FWD_GFLOP_PER_IMAGE, "attention": 3.9765, "cnn_lstm": 3.6311, "quadtree3d": 3.3814}[args.model]
         fps = B * world * nf / ft
         forward = {"metric": "images/sec eval forward (fused BN/ReLU/residual epilogues), same model and batch",
                    "value": round(fps, 1), "unit": "images/s", "ms_per_batch": round(1e3 * ft / nf, 3), "passes": nf,
@@ -510,6 +517,14 @@ def main():
         name = "CnnLstm"
         what = (f"CnnLstm ({B // args.seq_len} sequences x {args.seq_len} frames per GPU, frozen per-frame ResNet-18 + pose MLP "
                 "+ 2-layer LSTM(640->256) + classifier), images = frames; ")
+    if args.model == "quadtree3d":
+        # 2*MAC of the five Conv3d (3dcnn/models.py:108-139) on a T = 8 clip of 224x224: 2.081 + 11.098 + 5.549 + 2.774 +
+        # 5.549 = 27.051 GFLOP per clip forward (+ LSTM / heads ~0.002); backward = 2 x forward - block1's data gradient
+        gflop_img = 3.3814 if args.forward_only else 9.8843
+        name = "Quadtree3DCNN"
+        what = (f"Quadtree3DCNN (BASELINE config 4: {B // args.seq_len} clips x {args.seq_len} frames of 224x224 per GPU, five "
+                "Conv3d 3x3x3 + BatchNorm3d + ReLU + MaxPool3d as 2-D MFMA launches over time-major clips, LSTM(47->188) "
+                "branch, 1536->768->12 head), images = frames; ")
     out = {
         "metric": f"images/sec fwd {name} 224x224" if args.forward_only
         else f"images/sec fwd+bwd {name} 224x224 bs256",
@@ -519,7 +534,7 @@ def main():
         "data": "synthetic (randn images / pose vectors resident in HBM, deterministic synthetic weights)",
         "config": {"workload": what
                                + ("eval forward" if args.forward_only else
-                                  ("train step fwd+bwd+Adam; " if (args.freeze_backbone or args.model == "cnn_lstm") else
+                                  ("train step fwd+bwd+Adam; " if (args.freeze_backbone or args.model in ("cnn_lstm", "quadtree3d")) else
                                    "train step fwd+bwd+Adam, all parameters trainable; ") + "Adam(lr 1e-4, wd 1e-4) by "
                                   + ("the package's FusedAdam (csrc/pack.hip)" if args.optimizer == "fused"
                                      else "torch.optim.Adam(fused=True)")),

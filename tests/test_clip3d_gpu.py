@@ -164,6 +164,9 @@ def test_clip_models_match_reference_golden(dt, tag, B, T, HW, mode, salt, golde
         stride = max(1, fl.numel() // 256)
         smp = fl[::stride][:256].numpy()
         head = name.split(".")[0] in ("classifier", "numerical_projection", "numerical_lstm")
+        if float(np.abs(gold_s).max()) == 0.0:   # (frame taps that never see a source frame, T = 1: exactly zero)
+            assert float(np.abs(smp).max()) == 0.0, name
+            continue
         if dt == torch.float32:
             # (conv gradients pass ReLU / max-pool decisions: a flipped decision moves everything below it)
             assert _cos(smp, gold_s) >= (0.9999 if head else 0.999), (name, _cos(smp, gold_s))
