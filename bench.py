@@ -45,7 +45,7 @@ FWD_BWD_GFLOP_PER_IMAGE = 11.0792   # BASELINE.md section 3 (all parameters trai
 FWD_GFLOP_PER_IMAGE = 3.7718
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
 # kernel families (scripts/summarize_profiles.py) behind roofline.achieved: forward + data-gradient conv launches
-ROOFLINE_FAMILIES = ("conv_igemm_kernel", "conv_pp_kernel", "conv_l1_ring_kernel", "conv_stem_kernel")
+ROOFLINE_FAMILIES = ("conv_igemm_kernel", "conv_pt_kernel", "conv_l1_ring_kernel", "conv_stem_kernel")
 
 
 def kernel_sources_sha1():
