@@ -10,7 +10,7 @@
  *   - the caller owns every buffer (including workspaces); the library allocates
  *     nothing persistent on the device.  Process-wide state is limited to (i) the
  *     kernel-selection switches qt_set_patch_conv / qt_set_pt_conv / qt_set_stem_conv /
- *     qt_set_wgrad_patch_min_width and the QTCNN_* environment variables they mirror
+ *     qt_set_wgrad_patch_min_width / qt_set_wgrad_patch_variant and the QTCNN_* environment variables they mirror
  *     (read once; DESIGN.md section 5 lists them) -- they pick between kernels that
  *     compute the same result, set them before the first launch -- and (ii) the
  *     per-device "LDS limit raised" bits of the large-LDS kernels;
@@ -150,6 +150,10 @@ int qt_conv2d_wgrad_oihw(const qt_conv_desc* desc, const void* dy, const void* x
  * streaming kernel (csrc/conv_wgrad_patch.hip: one workgroup accumulates all nine taps of a
  * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default. */
 void qt_set_wgrad_patch_min_width(int min_width);
+/* Which streaming kernel those shapes take: 3 = tile-resident (a tile of 128-256 padded positions + halo double
+ * buffered in LDS, fragment reads two taps ahead of the MFMAs, source offsets from a table in LDS; default),
+ * 0 / 2 = the round-1 ring kernel with one / two wave groups.  <0 = default; env QTCNN_WP_VARIANT. */
+void qt_set_wgrad_patch_variant(int variant);
 
 /* ------------------------------------------------------------------------
  * Layout packing (HBM-bound).

@@ -604,8 +604,12 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
           }
         }
       }
+      // One store instruction per j, spelled out: the counted vmcnt(4) at the next tile's barrier relies on exactly four
+      // vector-memory operations being issued here, which a predicated / merged compiler store would not guarantee.
       bf16x8* out = live ? reinterpret_cast<bf16x8*>(dst + off) : reinterpret_cast<bf16x8*>(&l1_store_sink[tid]);
-      *out = o;
+      // (s_nop: a store of more than 8 bytes needs wait states before its data registers are written again -- the
+      // compiler pads its own stores, not ours)
+      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(out), "v"(o) : "memory");
     }
   }
 

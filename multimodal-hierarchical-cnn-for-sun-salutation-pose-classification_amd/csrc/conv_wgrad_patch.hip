@@ -87,7 +87,7 @@ constexpr int WP_CH = 32;  // positions per MFMA K-step
 // holds two waves that cover each other's LDS reads and address arithmetic.  The groups' partial
 // filters are summed through LDS before they leave the workgroup.
 template <int G, int D, int NX, int ND>
-__global__ __launch_bounds__(256 * G) void conv_wgrad_patch_kernel(WPArgs p) {
+__global__ __launch_bounds__(256 * G, 2 / G) void conv_wgrad_patch_kernel(WPArgs p) {
   static_assert((NX & (NX - 1)) == 0 && (ND & (ND - 1)) == 0, "rings are powers of two");
   static_assert(G == 1 || G == 2, "one or two wave groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -271,6 +271,301 @@ __global__ __launch_bounds__(256 * G) void conv_wgrad_patch_kernel(WPArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile-resident variant (round 2).  What bounded the ring kernel above (PMC): nothing of the machine --
+// 28 % MFMA-busy with no LDS conflicts and 9 GB/s of DMA per CU -- but the instruction stream of its single wave per
+// SIMD: a barrier per 32 positions with the fragment reads behind it (their latency exposed 100+ times per workgroup),
+// ~100 vector instructions of position walking and ring wrapping per 36 MFMAs, all in issue order.  Here
+//   * a TILE of NT*32 consecutive padded positions (+ PW+1 rows of X on either side) is resident in LDS, double
+//     buffered: one barrier per tile (288 MFMAs per wave pair), every fragment address is a per-lane base + an
+//     immediate (no ring to wrap), and the fragment reads run three taps ahead of the MFMAs, the next chunk's dY
+//     fragments four taps ahead -- the kernel never waits on a read it has just issued;
+//   * the source offset of a padded position comes from a table in LDS (PP + 8 words per operand, built once per
+//     workgroup: byte offset inside the image or an out-of-range marker for pad positions): a DMA instruction costs
+//     one table read and one v_add3 per lane, image index and remainder of its first row are scalar arithmetic;
+//     pad rows and rows past the tensor are zero-filled by the buffer range check;
+//   * 8 waves, two per SIMD: group g of four waves contracts chunks g, g+2, ... of the tile (the hardware interleaves
+//     the two waves of a SIMD); the groups' partial filters are exchanged through LDS as in the G = 2 ring kernel.
+// ---------------------------------------------------------------------------------------------
+struct WTArgs {
+  WPArgs p;
+  int HL;                      // rows of X kept on each side of a tile (multiple of 8, >= PW + 1)
+  unsigned xb, bufb, tab;      // bytes of a buffer's X region / of a buffer; LDS byte address of the offset tables
+  unsigned x_bytes, dy_bytes;  // extents of the two tensors (buffer resources)
+};
+
+template <int NT>
+__global__ __launch_bounds__(512) void conv_wgrad_tile_kernel(WTArgs a) {
+  static_assert(NT % 2 == 0 && NT >= 2 && NT <= 8, "chunks per tile");
+  constexpr int NJ = NT / 2;  // chunks per wave group and tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WPArgs& p = a.p;
+  if (lds_addr_of(smem) != 0) return;  // no static LDS in this kernel; addresses below are absolute
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = wave >> 2, wq = wave & 3;
+
+  int split, tile;
+  if ((p.nsplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / p.tiles) * 8 + xcd;
+    tile = slot % p.tiles;
+  } else {
+    split = blockIdx.x % p.nsplit;
+    tile = blockIdx.x / p.nsplit;
+  }
+  const int tc = tile % p.tilesC, tn = tile / p.tilesC;
+  const int n0 = tn * 64, c0 = tc * 64;
+  const int p0 = split * p.pps;
+  if (p0 >= p.total) return;
+  const int pend = min(p.total, p0 + p.pps);
+  const int nch = (pend - p0 + WP_CH - 1) / WP_CH;
+  const int ntiles = (nch + NT - 1) / NT;
+
+  // ---- offset tables: entry r < PP is padded position r of an image, entries PP..PP+7 are the first positions of
+  // the NEXT image (an 8-row DMA unit may straddle two images) ----
+  const int tabn = p.PP + 8;
+  {
+    unsigned* tx = reinterpret_cast<unsigned*>(smem + a.tab);
+    unsigned* ty = tx + tabn;
+    for (int r = tid; r < tabn; r += 512) {
+      const int rr = r >= p.PP ? r - p.PP : r;
+      const int ph = (int)fdiv((unsigned)rr, p.div_pw), pw = rr - ph * p.PW;
+      const bool ok = ph >= 1 && pw >= 1;
+      const unsigned nx = r >= p.PP ? (unsigned)p.x_is * 2u : 0u, ny = r >= p.PP ? (unsigned)p.dy_is * 2u : 0u;
+      tx[r] = ok ? (unsigned)((ph - 1) * p.x_rs + (pw - 1) * p.x_ps) * 2u + nx : kOob;
+      ty[r] = ok ? (unsigned)((ph - 1) * p.dy_rs + (pw - 1) * p.dy_ps) * 2u + ny : kOob;
+    }
+  }
+
+  // ---- DMA side: a unit = 8 rows = 1 KiB; lane = (row of the unit, 16-byte LDS slot); swizzle on the source ----
+  const i32x4 rx = make_rsrc(p.x, a.x_bytes), ry = make_rsrc(p.dy, a.dy_bytes);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const int dkey = (drow >> 1) & 3;
+  const unsigned lane_c = (unsigned)((((dslot >> 1) ^ dkey) << 1) | (dslot & 1)) * 16u;
+  const unsigned x_is2 = (unsigned)p.x_is * 2u, y_is2 = (unsigned)p.dy_is * 2u;
+
+  // This wave's share of a tile: units wave, wave + 8, ... of the X region and of the dY region.  A walk keeps the
+  // (scalar) image base and remainder of its unit's first row: 64 positions further per step, at most one image wrap
+  // (PP >= 64), and this lane's table entry of its pending unit.  A slot has NO branch (a branch makes the compiler
+  // drain every outstanding fragment read with lgkmcnt(0) at the join, three times per chunk): when the walk has
+  // nothing left the transfer goes through a resource of zero records (no memory traffic) into a spare KiB of LDS.
+  int x_left = 0, y_left = 0;                   // units still to issue
+  unsigned x_rem = 0, x_base = 0, x_dst = 0;    // first row's position inside its image, image base + channel offset
+  unsigned y_rem = 0, y_base = 0, y_dst = 0;    // (bytes), LDS address of the unit
+  unsigned x_tv = 0, y_tv = 0;                  // this lane's table entry of the pending unit of either walk
+  const unsigned tab_x = a.tab + (unsigned)drow * 4u, tab_y = tab_x + (unsigned)tabn * 4u;
+  const unsigned spare = a.tab + 2u * (unsigned)tabn * 4u;
+  auto sgpr = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+#define QT_WALK_BEGIN(W, units, pos0, is2, coff, dst0)                                        \
+  {                                                                                           \
+    const int u_ = (units);                                                                   \
+    W##_left = __builtin_amdgcn_readfirstlane(u_ > wave ? (u_ - wave + 7) >> 3 : 0);          \
+    const unsigned g_ = (unsigned)((pos0) + 8 * wave + p.PP);                                 \
+    const unsigned q_ = fdiv(g_, p.div_pp);                                                   \
+    W##_rem = sgpr(g_ - q_ * (unsigned)p.PP);                                                 \
+    W##_base = sgpr((q_ - 1u) * (is2) + (coff));                                              \
+    W##_dst = sgpr((dst0) + (unsigned)wave * 1024u);                                          \
+  }
+#define QT_WALK_ISSUE(W, tv_, rsrc, bytes, is2)                                               \
+  {                                                                                           \
+    const bool any_ = W##_left > 0;                                                           \
+    i32x4 r_ = rsrc;                                                                          \
+    r_.z = (int)sgpr(any_ ? (bytes) : 0u);                                                    \
+    blds16(r_, (tv_) + W##_base + lane_c, 0u, sgpr(any_ ? W##_dst : spare));                  \
+    const unsigned r1_ = W##_rem + 64u;                                                       \
+    const bool wrap_ = r1_ >= (unsigned)p.PP;                                                 \
+    W##_left = __builtin_amdgcn_readfirstlane(W##_left - (any_ ? 1 : 0));                     \
+    W##_dst = sgpr(W##_dst + 8192u);                                                          \
+    W##_rem = sgpr(wrap_ ? r1_ - (unsigned)p.PP : r1_);                                       \
+    W##_base = sgpr(wrap_ ? W##_base + (is2) : W##_base);                                     \
+  }
+  auto tile_begin = [&](int k) {  // tile k -> buffer k & 1
+    const int nt = min(NT, nch - k * NT);
+    const int q0 = p0 + k * NT * WP_CH;
+    const unsigned bufbase = (unsigned)(k & 1) * a.bufb;
+    QT_WALK_BEGIN(x, (nt * WP_CH + 2 * a.HL) >> 3, q0 - a.HL, x_is2, (unsigned)c0 * 2u, bufbase)
+    QT_WALK_BEGIN(y, nt * (WP_CH / 8), q0, y_is2, (unsigned)n0 * 2u, bufbase + a.xb)
+    x_tv = *reinterpret_cast<const unsigned*>(smem + tab_x + x_rem * 4u);
+    y_tv = *reinterpret_cast<const unsigned*>(smem + tab_y + y_rem * 4u);
+  };
+  // One slot: the transfer of the walk's pending unit, then the table entry of the one after it.  The read is pinned
+  // here (sched_barrier) so that it is OLD when the next slot of the walk consumes it: LDS returns in order, a wait for
+  // a fresh read would wait for every fragment read issued before it.
+  auto dma_x = [&]() {
+    QT_WALK_ISSUE(x, x_tv, rx, a.x_bytes, x_is2)
+    x_tv = *reinterpret_cast<const unsigned*>(smem + tab_x + x_rem * 4u);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto dma_y = [&]() {
+    QT_WALK_ISSUE(y, y_tv, ry, a.dy_bytes, y_is2)
+    y_tv = *reinterpret_cast<const unsigned*>(smem + tab_y + y_rem * 4u);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto dma_rest = [&]() {   // whatever the slots of a tile did not cover (the first tile; short tiles, wide halos)
+    while (x_left > 0) dma_x();
+    while (y_left > 0) dma_y();
+  };
+#undef QT_WALK_BEGIN
+#undef QT_WALK_ISSUE
+
+  // ---- MFMA side ----
+  const int li = lane & 15, lg = lane >> 4;
+  const int qq = li >> 2, pp = li & 3;
+  const int lrow = 4 * lg + qq;  // second transposing read: lrow + 16 (same swizzle key)
+  unsigned a_base[4], b_base[9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    a_base[i] = a.xb + (unsigned)(group * WP_CH + lrow) * 128u + ((unsigned)(i ^ ((lrow >> 1) & 3)) << 5) + pp * 8;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int r = a.HL + (t / 3 - 1) * p.PW + (t % 3 - 1) + group * WP_CH + lrow;  // >= 0: HL >= PW + 1
+    b_base[t] = (unsigned)r * 128u + ((unsigned)(wq ^ ((r >> 1) & 3)) << 5) + pp * 8;
+  }
+  auto frag = [&](unsigned addr) -> uint4 {   // one 16-byte MFMA operand: rows lrow and lrow + 16 of a chunk
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(addr));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_tr_ptr(addr + 2048));
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+  };
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // tables visible, then tile 0 into buffer 0
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  tile_begin(0);
+  dma_rest();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // One barrier per tile; inside it a wave runs its NJ chunks as one software pipeline: the fragments of X two taps
+  // ahead of the MFMAs, the next chunk's dY fragments one per tap, a DMA slot of the next tile on taps 0 and 4 (X) and
+  // 7 (dY).  (A barrier-separated ping-pong of the two groups -- fragment reads of one under the MFMAs of the other --
+  // measured SLOWER here, 71-76 us against 58-62: its load segment is paced by the LDS (26 transposing reads x 4 waves
+  // ~ 500 cycles) and every DMA instruction costs the segment that issues it ~65 cycles, so neither segment fits under
+  // the 576 cycles of the other's MFMAs.)
+  for (int k = 0; k < ntiles; ++k) {
+    const int nt = min(NT, nch - k * NT);
+    const int nj = (nt - group + 1) >> 1;  // chunks group, group + 2, ... < nt
+    if (k + 1 < ntiles) {
+      tile_begin(k + 1);
+    } else {
+      x_left = y_left = 0;
+    }
+    constexpr unsigned boff = 0;  // the fragment bases point into the tile's buffer (moved at the end of the tile)
+    uint4 fa[2][4], fb[3];
+    if (nj > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[0][i] = frag(a_base[i] + boff);
+      fb[0] = frag(b_base[0] + boff);
+      fb[1] = frag(b_base[1] + boff);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      if (jj < nj) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          constexpr int kStride = 2 * WP_CH * 128;  // bytes between a group's consecutive chunks
+          const int s2 = jj * 9 + t + 2;            // fragment of X two taps ahead (a third costs 4 registers)
+          if (s2 / 9 < NJ) fb[s2 % 3] = frag(b_base[s2 % 9] + boff + (unsigned)(s2 / 9) * kStride);
+          if (t >= 2 && t < 6 && jj + 1 < NJ)       // the next chunk's dY fragments, one per tap
+            fa[(jj + 1) & 1][t - 2] = frag(a_base[t - 2] + boff + (unsigned)(jj + 1) * kStride);
+          if (t == 0 || t == 4) dma_x();            // 2 NJ slots for X, NJ for dY (exactly its share when the next
+          if (t == 7) dma_y();                      // tile is full)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[jj & 1][i]),
+                                                                __builtin_bit_cast(bf16x8, fb[(jj * 9 + t) % 3]),
+                                                                acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+    dma_rest();
+    {  // fragment bases -> the other buffer (in place: a second set of 13 registers is what the kernel cannot afford
+       // next to the small kernels of the main stream, see the launcher)
+      const unsigned delta = (k & 1) ? 0u - a.bufb : a.bufb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a_base[i] += delta;
+        asm volatile("" : "+v"(a_base[i]));
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        b_base[t] += delta;
+        asm volatile("" : "+v"(b_base[t]));
+      }
+    }
+    // the next tile has landed (this wave's share; the barrier makes it everybody's) and nobody reads this buffer again
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  // ---- group 1 hands o-blocks 0,1 to group 0 and takes o-blocks 2,3 from it ----
+  {
+    f32x4* xch = reinterpret_cast<f32x4*>(smem) + (wq * 18) * 64 + lane;  // [wq][18][lane] x 16 B
+    if (group == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xch[(i * 9 + t) * 64] = acc[i][t];
+    }
+    __syncthreads();
+    if (group == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] += xch[(i * 9 + t) * 64];
+    }
+    __syncthreads();
+    if (group == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xch[(i * 9 + t) * 64] = acc[2 + i][t];
+    }
+    __syncthreads();
+    if (group == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[2 + i][t] += xch[(i * 9 + t) * 64];
+    }
+  }
+
+  // ---- accumulate: lane holds o = 16*i + 4*lg + r, input channel 16*wq + li of every tap ----
+  const int cc = c0 + wq * 16 + li;
+  auto flush = [&](int i, const f32x4 (&v)[9]) {
+    if (p.part) {
+      float* base = p.part + (long long)split * p.N * 9 * p.KC;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + i * 16 + lg * 4 + r;
+        float* row = base + (long long)n * 9 * p.KC + cc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) row[t * p.KC] = v[t][r];
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + i * 16 + lg * 4 + r;
+      float* row = p.dw + (long long)n * 9 * p.KC + cc;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(row + t * p.KC, v[t][r]);
+    }
+  };
+  if (group == 0) {
+    flush(0, acc[0]);
+    flush(1, acc[1]);
+  } else {
+    flush(2, acc[2]);
+    flush(3, acc[3]);
+  }
+}
+
 // dw[j] += sum over ranges of part[range][j].  A block sums JQ = 256/SG float4 columns; thread
 // group g adds its contiguous share of the ranges in ascending order and the groups are added in
 // ascending order, so the result does not depend on timing.  SG is chosen so that a thread has
@@ -378,11 +673,94 @@ int launch_patch(WPArgs a, size_t part_bytes, int oihw, hipStream_t stream) {
   return QT_OK;
 }
 
+// geometry of the tile-resident kernel for this image size: chunks per tile (0 = does not fit), halo rows, LDS bytes
+struct TileGeo {
+  int nt, hl;
+  unsigned xb, bufb, tab, lds;
+};
+TileGeo tile_geometry(int PW, int PP) {
+  TileGeo g{0, (PW + 1 + 7) / 8 * 8, 0, 0, 0, 0};
+  if (g.hl > PP) return g;
+  static int lds_kb = -1;  // LDS the kernel may take: what it leaves is what the main stream's small kernels find
+  if (lds_kb < 0) {
+    const char* e = getenv("QTCNN_WT_LDS_KB");
+    lds_kb = e ? atoi(e) : 160;
+    if (lds_kb < 80 || lds_kb > 160) lds_kb = 160;
+  }
+  for (int nt = 8; nt >= 4; nt -= 2) {
+    const unsigned xb = (unsigned)(nt * WP_CH + 2 * g.hl) * 128u, bufb = xb + (unsigned)nt * WP_CH * 128u;
+    const unsigned lds = 2u * bufb + 2u * (unsigned)(PP + 8) * 4u + 1024u;  // tables + the spare KiB of empty DMA slots
+    if (lds <= (unsigned)lds_kb * 1024u && 2u * bufb >= 4u * 18u * 64u * 16u) {
+      g.nt = nt; g.xb = xb; g.bufb = bufb; g.tab = 2u * bufb; g.lds = lds;
+      return g;
+    }
+  }
+  return g;
+}
+
+template <int NT>
+int launch_tile_nt(const WTArgs& t, unsigned lds, hipStream_t stream) {
+  auto kern = conv_wgrad_tile_kernel<NT>;
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds, lds_limit_set)) return rc;
+  hipLaunchKernelGGL(kern, dim3(t.p.tiles * t.p.nsplit), dim3(512), lds, stream, t);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+// -1: the shape is not for the tile kernel (caller takes the ring kernel), else a status
+int launch_tile(WPArgs a, size_t part_bytes, int oihw, hipStream_t stream) {
+  const TileGeo g = tile_geometry(a.PW, a.PP);
+  const unsigned long long xbytes = (unsigned long long)a.B * (unsigned long long)a.x_is * 2ull;
+  const unsigned long long ybytes = (unsigned long long)a.B * (unsigned long long)a.dy_is * 2ull;
+  if (!g.nt || xbytes >= (1ull << 30) || ybytes >= (1ull << 30)) return -1;
+  int real_split;
+  split_ranges(a.total, a.tiles, WP_CH, &a.pps, &real_split);
+  a.nsplit = real_split;
+  if (a.nsplit >= 6 && (a.nsplit & 7)) a.nsplit = qt_cdiv(a.nsplit, 8) * 8;  // empty tail ranges exit at once
+  const size_t filt = (size_t)a.N * 9 * a.KC;
+  if (a.part && part_bytes < (size_t)real_split * filt * 4) a.part = nullptr;  // too small: atomics
+  if (oihw && !a.part) {
+    qt_set_error("qt_conv2d_wgrad_oihw: workspace of %zu bytes needed", (size_t)real_split * filt * 4);
+    return QT_ERR_INVALID_ARG;
+  }
+  WTArgs t;
+  t.p = a;
+  t.HL = g.hl; t.xb = g.xb; t.bufb = g.bufb; t.tab = g.tab;
+  t.x_bytes = (unsigned)xbytes; t.dy_bytes = (unsigned)ybytes;
+  int rc = g.nt == 8 ? launch_tile_nt<8>(t, g.lds, stream)
+         : g.nt == 6 ? launch_tile_nt<6>(t, g.lds, stream) : launch_tile_nt<4>(t, g.lds, stream);
+  if (rc != QT_OK) return rc;
+  if (a.part) {
+    const int nq = (int)(filt / 4);
+    if (real_split > 16)
+      hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, a.part, a.dw, nq,
+                         real_split, (long long)nq, a.KC, oihw);
+    else
+      hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, a.part, a.dw, nq,
+                         real_split, (long long)nq, a.KC, oihw);
+    QT_CHECK_LAUNCH();
+  }
+  return QT_OK;
+}
+
+int g_wp_variant = -1;  // 3: tile-resident kernel (default), 0: ring kernel, one wave group, 2: ring kernel, two groups
+int wp_variant() {
+  if (g_wp_variant < 0) {
+    const char* e = getenv("QTCNN_WP_VARIANT");
+    g_wp_variant = e ? atoi(e) : 3;
+  }
+  return g_wp_variant;
+}
+
 }  // namespace
 
 // Smallest image width whose 3x3 stride-1 weight gradients take the streaming kernel
 // (0 = never; default 14 = every eligible layer, env QTCNN_WGRAD_PATCH_MIN_W).
 extern "C" void qt_set_wgrad_patch_min_width(int w) { g_wgrad_patch_min_w = w < 0 ? 14 : w; }
+// Which streaming kernel: 3 = tile-resident (default), 0 = ring with one wave group, 2 = ring with two (env
+// QTCNN_WP_VARIANT; negative = default).  Same sums in a different order: results agree to f32 rounding.
+extern "C" void qt_set_wgrad_patch_variant(int v) { g_wp_variant = v < 0 ? 3 : v; }
 
 bool qt_wgrad_patch_eligible(const qt_conv_desc* d) {
   const int mw = min_w();
@@ -422,11 +800,7 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   a.tilesC = a.KC / 64;
   a.tiles = (a.N / 64) * a.tilesC;
   a.adv_h = a.adv_w = a.pps = a.nsplit = 0;
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("QTCNN_WP_VARIANT");
-    variant = e ? atoi(e) : 0;
-  }
+  const int variant = wp_variant();
   static int use_ws = -1;
   if (use_ws < 0) {
     const char* e = getenv("QTCNN_WGRAD_WS");
@@ -440,6 +814,10 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   // for any of their waves: short kernels then queue behind whole workgroups.  One group per
   // workgroup (one wave per SIMD, 96 KB LDS) keeps half of every CU's registers free and measures
   // 1.7 % faster per step (7.43 vs 7.56 ms); 48 KB of LDS with a shallower ring measures slower (7.60).
+  if (variant == 3) {
+    const int rc = launch_tile(a, workspace_bytes, oihw, s);
+    if (rc >= 0) return rc;
+  }
   if (variant == 2) return launch_patch<2, 2, 8, 4>(a, workspace_bytes, oihw, s);
   return launch_patch<kGroups, 4, 16, 8>(a, workspace_bytes, oihw, s);
 }

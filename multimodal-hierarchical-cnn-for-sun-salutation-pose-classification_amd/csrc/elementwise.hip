@@ -29,6 +29,8 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) { QtVec8<f
 // all sixteen loads issued before the first add: the kernels below are a chain of dependent
 // launches on the critical path of every BatchNorm, and a one-row-per-trip loop costs one
 // memory latency per 16 rows (9-13 us per launch at 256-1024 rows instead of ~4).
+constexpr int kFinC = 16;  // channels per block of the finalize kernels (x 16 row groups)
+
 __device__ __forceinline__ void sum_partial_rows(const float* __restrict__ partial, int rows, int C, int c, int rl,
                                                  double& s1, double& s2) {
   int r = rl;
@@ -51,13 +53,16 @@ __device__ __forceinline__ void sum_partial_rows(const float* __restrict__ parti
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+__global__ __launch_bounds__(16 * kFinC) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long long* num_batches_tracked,
                                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  // kFinC channels x 16 row groups = 256 threads, 4 KB of LDS: one wave per SIMD and <= 64 VGPRs, so that the launch
+  // finds room on a CU whose LDS and registers a weight-gradient workgroup of the side stream is holding (as a
+  // 1024-thread / 16 KB block it waited 40-50 us per BatchNorm for one of those to retire)
+  __shared__ double red[2][16][kFinC];
+  const int cl = threadIdx.x % kFinC, rl = threadIdx.x / kFinC;
+  const int c = blockIdx.x * kFinC + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) sum_partial_rows(partial, rows, C, c, rl, s1, s2);
   red[0][rl][cl] = s1;
@@ -255,12 +260,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = sum_g/M, coef[2][c] = sum_gxhat/M
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+__global__ __launch_bounds__(16 * kFinC) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* dgamma, float* dbeta, int accumulate, float* coef) {
-  __shared__ double red[2][16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ double red[2][16][kFinC];  // small on purpose: see bn_finalize_kernel
+  const int cl = threadIdx.x % kFinC, rl = threadIdx.x / kFinC;
+  const int c = blockIdx.x * kFinC + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) sum_partial_rows(partial, rows, C, c, rl, s1, s2);
   red[0][rl][cl] = s1;
@@ -781,7 +786,7 @@ __global__ void col_sum_kernel(const T* __restrict__ x, long long rows, int cols
 
 // Long row counts are first folded 256:1 into the spare rows behind `rows`.
 static int fold_partial(float*& partial, int& rows, int C, hipStream_t s) {
-  if (rows <= 1024) return QT_OK;  // the 1024-thread finalize kernels cover this directly
+  if (rows <= 1024) return QT_OK;  // the finalize kernels (16 row groups) cover this directly
   const int S = qt_cdiv(rows, kFold);
   hipLaunchKernelGGL(stats_stage1_kernel, dim3(qt_cdiv(C, 64), S), dim3(256), 0, s, partial, rows, C);
   QT_CHECK_LAUNCH();
@@ -800,7 +805,7 @@ extern "C" int qt_bn_finalize(float* partial, int rows, int C, long long count, 
                "qt_bn_finalize: bad argument");
   QT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "qt_bn_finalize: running stats must come in pairs");
   if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(1024), 0, static_cast<hipStream_t>(stream), partial,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(qt_cdiv(C, kFinC)), dim3(16 * kFinC), 0, static_cast<hipStream_t>(stream), partial,
                      rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      mean, invstd, scale, shift);
   QT_CHECK_LAUNCH();
@@ -890,7 +895,7 @@ extern "C" int qt_bn_bwd_finalize(float* partial, int rows, int C, long long cou
                                   void* stream) {
   QT_CHECK_ARG(partial && rows > 0 && C > 0 && count >= 0 && invstd && coef, "qt_bn_bwd_finalize: bad argument");
   if (int st = fold_partial(partial, rows, C, static_cast<hipStream_t>(stream))) return st;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qt_cdiv(C, 64)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qt_cdiv(C, kFinC)), dim3(16 * kFinC), 0, static_cast<hipStream_t>(stream),
                      partial, rows, C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
   QT_CHECK_LAUNCH();
   return QT_OK;

@@ -125,6 +125,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
       : "v"(gsrc), "s"(lds_addr)
       : "memory");
 }
+// LDS-DMA through a buffer resource: 64 lanes x 16 B from  base + voff (per lane, bytes) + soff (wave-uniform)  to the
+// 1 KiB at LDS byte address `lds_addr`.  Lanes whose voff is outside [0, num_records) write ZEROS (hardware range check
+// of raw buffers; soff does not take part in it): halo rows and rows past the tensor need no second pointer, and a
+// transfer costs no vector instruction -- the per-lane offsets are loop invariants, tap / chunk offsets are scalar.
+// (Issued from inline asm, like glds16: the compiler neither counts it in vmcnt nor fences LDS reads with vmcnt(0).)
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+constexpr unsigned kOob = 0x80000000u;   // a per-lane offset no tensor here reaches (< 2 GiB, checked by the launcher)
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));   // stride 0: raw buffer
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;                                                  // 32-bit data format, no swizzle (gfx94x / gfx950)
+  return r;
+}
+__device__ __forceinline__ void blds16(const i32x4& rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)p);
 }

@@ -88,6 +88,12 @@ if __name__ == "__main__":
             bench("wgrad", B, 56, 64, 64, 3, 1, 1, workspace=w)
             bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=w)
             bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=w)
+    if which == "wgp":   # streaming weight-gradient kernel alone, partial-filter workspace (QTCNN_WP_VARIANT / PMC runs)
+        L.lib().qt_set_wgrad_patch_min_width(7)
+        bench("wgrad", B, 56, 64, 64, 3, 1, 1, workspace=True)
+        bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=True)
+        bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=True)
+        bench("wgrad", B, 7, 512, 512, 3, 1, 1, workspace=True)
     if which == "igemm":   # forward / dgrad of the 3x3 stride-1 layers (QTCNN_IGEMM_VARIANT experiments)
         for kind in ("fwd", "dgrad"):
             bench(kind, B, 28, 128, 128, 3, 1, 1)
@@ -185,3 +191,8 @@ if __name__ == "__main__" and which == "pt3":   # forward of the three stage sha
         bench("fwd", B, 28, 128, 128, 3, 1, 1)
         bench("fwd", B, 14, 256, 256, 3, 1, 1)
         bench("fwd", B, 7, 512, 512, 3, 1, 1)
+if __name__ == "__main__" and which == "wg3":   # tile-resident weight-gradient kernel on the three NT = 8 shapes (the NT = 8 instantiation)
+    L.lib().qt_set_wgrad_patch_min_width(7)
+    bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=True)
+    bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=True)
+    bench("wgrad", B, 7, 512, 512, 3, 1, 1, workspace=True)

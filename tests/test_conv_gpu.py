@@ -260,11 +260,14 @@ def test_conv_wgrad(dt, cfg):
     (300, 64, 64, 14),    # more ranges than workgroups' worth of images: ranges cut through images
     (6, 512, 512, 7),     # layer4: 9x9 padded positions, a 32-position step spans three padded rows
 ])
-def test_conv_wgrad_streaming_kernel(cfg):
+@pytest.mark.parametrize("variant", [3, 0, 2])
+def test_conv_wgrad_streaming_kernel(cfg, variant):
     """3x3 / stride 1 weight gradient with all nine taps accumulated by one workgroup
-    (csrc/conv_wgrad_patch.hip) against torch.nn.grad.conv2d_weight and against the generic kernel."""
+    (csrc/conv_wgrad_patch.hip: tile-resident kernel = 3, ring kernel with one / two wave groups = 0 / 2) against
+    torch.nn.grad.conv2d_weight and against the generic kernel."""
     dev = _dev()
     L = pkg("_lib")
+    L.lib().qt_set_wgrad_patch_variant(variant)
     dt = torch.bfloat16
     B, Cin, Cout, H = cfg
     g = torch.Generator().manual_seed(14)
@@ -298,6 +301,7 @@ def test_conv_wgrad_streaming_kernel(cfg):
                                          ctypes.c_size_t(nbytes), L.stream_ptr()), "qt_conv2d_wgrad_oihw")
     finally:
         lib.qt_set_wgrad_patch_min_width(-1)
+        lib.qt_set_wgrad_patch_variant(-1)
     torch.cuda.synchronize()
     assert rel_err(g_oihw.cpu(), ref) <= 3e-5
     assert torch.equal(g_oihw, dw_ws.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2))
@@ -306,6 +310,36 @@ def test_conv_wgrad_streaming_kernel(cfg):
         assert rel_err(got, ref) <= 3e-5, name
     assert rel_err(dw.cpu(), dw_generic.cpu()) <= 3e-5
     assert torch.equal(dw_ws, dw_ws2)  # partial filters are summed in a fixed order: bit-reproducible
+
+
+@pytest.mark.parametrize("cfg", [
+    (7, 64, 64, 12, 20),    # rectangular maps, ranges end inside a tile
+    (3, 128, 64, 9, 31),    # odd width: a DMA unit of 8 rows straddles padded rows and images
+    (1, 64, 64, 7, 7),      # one image: fewer positions than one tile, most workgroups exit at once
+    (33, 64, 128, 30, 8),
+])
+def test_conv_wgrad_tile_kernel_shapes(cfg):
+    """Tile-resident weight-gradient kernel on map sizes the models do not use (offset table + 8-row DMA units)."""
+    dev = _dev()
+    L = pkg("_lib")
+    dt = torch.bfloat16
+    B, Cin, Cout, H, W = cfg
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dt).float()
+    dy = torch.randn(B, Cout, H, W, generator=g).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, 1, 1)
+    xd, dyd = nhwc(x).to(dev, dt), nhwc(dy).to(dev, dt)
+    try:
+        L.lib().qt_set_wgrad_patch_min_width(7)
+        L.lib().qt_set_wgrad_patch_variant(3)
+        dw = run_wgrad(L, dt, dyd, xd, B, (H, W), (H, W), Cin, Cout, 3, 3, 1, 1)
+        dw_ws = run_wgrad(L, dt, dyd, xd, B, (H, W), (H, W), Cin, Cout, 3, 3, 1, 1, workspace=True)
+    finally:
+        L.lib().qt_set_wgrad_patch_min_width(-1)
+        L.lib().qt_set_wgrad_patch_variant(-1)
+    for name, t in (("atomic", dw), ("workspace", dw_ws)):
+        got = t.cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        assert rel_err(got, ref) <= 3e-5, name
 
 
 def test_conv_wgrad_streaming_kernel_channel_slice():
