@@ -382,6 +382,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_issue = time.perf_counter() - t0   # host time to ISSUE the K steps (no sync): close to `elapsed` = host-bound
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -530,6 +531,7 @@ def main():
         else f"images/sec fwd+bwd {name} 224x224 bs256",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic (randn images / pose vectors resident in HBM, deterministic synthetic weights)",
         "config": {"workload": what

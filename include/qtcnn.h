@@ -148,7 +148,8 @@ int qt_conv2d_wgrad_oihw(const qt_conv_desc* desc, const void* dy, const void* x
                          size_t workspace_bytes, void* stream);
 /* bf16 3x3 / stride 1 / pad 1 weight gradients of images at least `min_width` wide take the
  * streaming kernel (csrc/conv_wgrad_patch.hip: one workgroup accumulates all nine taps of a
- * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default. */
+ * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default (7: every stage of the
+ * model).  Env QTCNN_WGRAD_PATCH_MIN_W. */
 void qt_set_wgrad_patch_min_width(int min_width);
 /* Which streaming kernel those shapes take: 3 = tile-resident (a tile of 128-256 padded positions + halo double
  * buffered in LDS, fragment reads two taps ahead of the MFMAs, source offsets from a table in LDS; default),

@@ -273,19 +273,25 @@ __global__ __launch_bounds__(256 * G, 2 / G) void conv_wgrad_patch_kernel(WPArgs
 
 // ---------------------------------------------------------------------------------------------
 // Tile-resident variant (round 2).  What bounded the ring kernel above (PMC): nothing of the machine --
-// 28 % MFMA-busy with no LDS conflicts and 9 GB/s of DMA per CU -- but the instruction stream of its single wave per
-// SIMD: a barrier per 32 positions with the fragment reads behind it (their latency exposed 100+ times per workgroup),
-// ~100 vector instructions of position walking and ring wrapping per 36 MFMAs, all in issue order.  Here
+// 28 % MFMA-busy with no LDS conflicts and 9 GB/s of DMA per CU -- but its instruction stream: a barrier per 32
+// positions with the fragment reads behind it (their latency exposed 100+ times per workgroup), ~100 vector
+// instructions of position walking and ring wrapping per 36 MFMAs, and, with one wave group and 512 registers to
+// allocate from, 208 v_accvgpr copies per iteration (fixed by the launch bound above).  Here
 //   * a TILE of NT*32 consecutive padded positions (+ PW+1 rows of X on either side) is resident in LDS, double
 //     buffered: one barrier per tile (288 MFMAs per wave pair), every fragment address is a per-lane base + an
-//     immediate (no ring to wrap), and the fragment reads run three taps ahead of the MFMAs, the next chunk's dY
-//     fragments four taps ahead -- the kernel never waits on a read it has just issued;
+//     immediate (no ring to wrap), and the fragment reads run two taps ahead of the MFMAs, the next chunk's dY
+//     fragments four taps ahead -- the kernel rarely waits on a read it has just issued;
 //   * the source offset of a padded position comes from a table in LDS (PP + 8 words per operand, built once per
 //     workgroup: byte offset inside the image or an out-of-range marker for pad positions): a DMA instruction costs
 //     one table read and one v_add3 per lane, image index and remainder of its first row are scalar arithmetic;
 //     pad rows and rows past the tensor are zero-filled by the buffer range check;
-//   * 8 waves, two per SIMD: group g of four waves contracts chunks g, g+2, ... of the tile (the hardware interleaves
-//     the two waves of a SIMD); the groups' partial filters are exchanged through LDS as in the G = 2 ring kernel.
+//   * 8 waves, two per SIMD: group g of four waves contracts chunks g, g+2, ... of the tile; the groups' partial
+//     filters are exchanged through LDS as in the G = 2 ring kernel;
+//   * 222 VGPRs and (by default) up to 160 KB of LDS.  Measured alone (B = 256, the 13 layers of the model): 58-70 us
+//     per launch against 86-93 (ring, one group) and 75-84 (ring, two groups); 42-50 % MFMA-busy.  What is left: the
+//     two waves of a SIMD share one matrix pipe and their streams do not interleave (fragment reads, DMA slots and
+//     MFMAs measured additive: 9 + 7 + 28 us of a 50 us loop), ~12 us of prologue (table, first tile) and epilogue
+//     (exchange, 37.7 MB of partial filters), and the launch that sums the partial filters (8-12 us).
 // ---------------------------------------------------------------------------------------------
 struct WTArgs {
   WPArgs p;
@@ -618,7 +624,7 @@ int g_wgrad_patch_min_w = -1;  // smallest image width routed here; 0 = off
 int min_w() {
   if (g_wgrad_patch_min_w < 0) {
     const char* e = getenv("QTCNN_WGRAD_PATCH_MIN_W");
-    g_wgrad_patch_min_w = e ? atoi(e) : 14;
+    g_wgrad_patch_min_w = e ? atoi(e) : 7;
   }
   return g_wgrad_patch_min_w;
 }
@@ -756,8 +762,8 @@ int wp_variant() {
 }  // namespace
 
 // Smallest image width whose 3x3 stride-1 weight gradients take the streaming kernel
-// (0 = never; default 14 = every eligible layer, env QTCNN_WGRAD_PATCH_MIN_W).
-extern "C" void qt_set_wgrad_patch_min_width(int w) { g_wgrad_patch_min_w = w < 0 ? 14 : w; }
+// (0 = never; default 7 = every eligible layer of the model, the 7x7 stage included; env QTCNN_WGRAD_PATCH_MIN_W).
+extern "C" void qt_set_wgrad_patch_min_width(int w) { g_wgrad_patch_min_w = w < 0 ? 7 : w; }
 // Which streaming kernel: 3 = tile-resident (default), 0 = ring with one wave group, 2 = ring with two (env
 // QTCNN_WP_VARIANT; negative = default).  Same sums in a different order: results agree to f32 rounding.
 extern "C" void qt_set_wgrad_patch_variant(int v) { g_wp_variant = v < 0 ? 3 : v; }
