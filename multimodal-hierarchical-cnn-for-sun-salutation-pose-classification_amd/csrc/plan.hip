@@ -1010,8 +1010,11 @@ struct Bwd : Exec {
   // conv is run as four stride-1 gathers, one per parity class of the destination pixel, so no
   // MFMA work is spent on taps that cannot reach a pixel (a dense gather would waste 3/4).
   // returns the number of partial rows each link received
+  // sparse: (1x1 stride 2 as `c`) leave the three parity classes the conv does not reach unwritten instead of zeroing
+  // the map; (3x3 stride 2 as `c`) `resid` is such a map: only class (0,0) adds it.  Saves a fill of the block input's
+  // size and three quarters of the residual reads per transition.
   int dgrad(const ConvL& c, void* dst, const void* resid, const void* mask, const BnLink* links = nullptr,
-            int nlinks = 0) {
+            int nlinks = 0, bool sparse = false) {
     if (c.stride == 1) {
       const qt_conv_desc d = conv_desc(c, QT_CONV_DGRAD);
       igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, -1, links, nlinks);
@@ -1025,7 +1028,7 @@ struct Bwd : Exec {
         qt_set_error("dgrad: 1x1 stride-2 with residual/mask/links is not wired");
         return 0;
       }
-      run(zero(dst, (size_t)B * c.hin * c.hin * c.cin * p->esz, stream));
+      if (!sparse) run(zero(dst, (size_t)B * c.hin * c.hin * c.cin * p->esz, stream));
     }
     int rows = 0;
     for (int cls = 0; cls < 4 && ok(); ++cls) {
@@ -1043,8 +1046,8 @@ struct Bwd : Exec {
         l2[k] = links[k];
         l2[k].partial = links[k].partial + (size_t)rows * 2 * c.cin;  // each class appends its tile rows
       }
-      igemm(d, at(c.gy), at<unsigned char>(c.w_dgrad) + (size_t)c.cls_off[cls] * p->esz, dst, nullptr, nullptr, resid,
-            mask, nullptr, 0, 1, l2, nlinks);
+      igemm(d, at(c.gy), at<unsigned char>(c.w_dgrad) + (size_t)c.cls_off[cls] * p->esz, dst, nullptr, nullptr,
+            sparse && !empty_class && cls != 0 ? nullptr : resid, mask, nullptr, 0, 1, l2, nlinks);
       rows += qt_conv2d_stats_rows(&d);
     }
     return rows;
@@ -1343,11 +1346,15 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       e.wgrad(c1, f1, e.at(x), false);
       // gradient w.r.t. the block input = conv1 dgrad + identity path (+ quadrant head for layer3's output)
       const void* resid = e.at(blk.gout);
+      // the downsample's data gradient reaches one pixel in four: if nothing else reads the map densely (the region
+      // heads below do), leave the rest unwritten and let only that parity class of conv1's data gradient add it
+      const bool sparse_ds = blk.ds >= 0 && c1.stride == 2 && c1.k == 3 && !(bi == 4 && p->attention) &&
+                             !(bi == 6 && !p->standard && !p->attention);
       if (blk.ds >= 0) {
         const ConvL& cd = p->convs[blk.ds];
         e.bn_backward(cd, e.at(blk.gout), nullptr, rows_bn2 ? e.at<float>(p->stats_ds) : nullptr, rows_bn2);
         e.wgrad(cd, e.conv_desc(cd, QT_CONV_FWD), e.at(x), false);
-        e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr);
+        e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr, nullptr, 0, sparse_ds);
         resid = e.at(blk.gtmp);
       }
       if (bi == 4 && p->attention) {  // layer2's output also feeds the two heads
@@ -1380,7 +1387,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
           links[nlinks++] = {e.at(pcd.y), e.at<float>(pbd.mean), e.at<float>(pbd.invstd), e.at<float>(p->stats_ds)};
         }
       }
-      rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks);
+      rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks, sparse_ds);
       if (bi == 0) rows_bn2 = 0;
     }
     p->bwd_rows_bn2 = rows_bn2;

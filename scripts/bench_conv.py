@@ -196,3 +196,11 @@ if __name__ == "__main__" and which == "wg3":   # tile-resident weight-gradient 
     bench("wgrad", B, 28, 128, 128, 3, 1, 1, workspace=True)
     bench("wgrad", B, 14, 256, 256, 3, 1, 1, workspace=True)
     bench("wgrad", B, 7, 512, 512, 3, 1, 1, workspace=True)
+if __name__ == "__main__" and which == "trans":   # stride-2 transition convs and their 1x1 downsamples, alone (forward / dgrad / wgrad)
+    for kind in ("fwd", "dgrad", "wgrad"):
+        bench(kind, B, 56, 64, 128, 3, 2, 1)
+        bench(kind, B, 56, 64, 128, 1, 2, 0)
+        bench(kind, B, 28, 128, 256, 3, 2, 1)
+        bench(kind, B, 28, 128, 256, 1, 2, 0)
+        bench(kind, B, 14, 256, 512, 3, 2, 1)
+        bench(kind, B, 14, 256, 512, 1, 2, 0)
