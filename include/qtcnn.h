@@ -85,6 +85,13 @@ typedef struct qt_conv_desc {
    * relu_mask are read at the same place.  Used to run the data gradient of a stride-2 conv as
    * four stride-1 gathers, one per output-pixel parity class (qt_pack_dgrad_s2). */
   int dst_sub, dst_h, dst_w, dst_off_h, dst_off_w;
+  /* dst_merge = C > 0 (with dst_sub = 2, n_out = 4*C): the n_out channels of a row are the FOUR parity classes of a
+   * stride-2 data gradient at once -- channel n is channel n % C of pixel (2*oh + (n/C >> 1), 2*ow + (n/C & 1)) of the
+   * dst_h x dst_w image with C channels; residual / relu_mask / BatchNorm links are read there and the link sums
+   * are written as 4 partial rows of C channels per pixel tile.  One 2x2-tap launch over the gradient map instead of
+   * four gathers that each re-read it (weight operand: qt_pack_dgrad_s2_merged). */
+  int dst_merge;
+  int dst_merge_res0;  /* with dst_merge: the residual is added to class (0,0) only (the other pixels of it are never read) */
 } qt_conv_desc;
 
 typedef struct qt_conv_io {
@@ -174,7 +181,9 @@ int qt_pack_conv_weight(int dtype, const float* w_oihw, void* w_fwd, void* w_dgr
                         void* stream);
 /* Every conv / linear weight of a model in one launch (LDS tile transposes): per item the same
  * result as qt_pack_conv_weight, or, with stride2_dgrad != 0 and k == 3, w_dgrad in the parity-class
- * layout of qt_pack_dgrad_s2.  O and I must be multiples of 32 (k = 3) or 64 (k = 1); at most 32 items. */
+ * layout of qt_pack_dgrad_s2 (stride2_dgrad = 1) or the merged layout of qt_pack_dgrad_s2_merged (= 2; only the
+ * nine real taps are written: the zero slots of w_dgrad must have been zeroed once).  O and I must be multiples of
+ * 32 (k = 3) or 64 (k = 1); at most 32 items. */
 typedef struct qt_pack_item {
   const float* w_oihw;
   void* w_fwd;   /* nullable */
@@ -211,6 +220,12 @@ int qt_adam_pack_weights_batched(int dtype, const qt_pack_item* items, const qt_
  * classes are returned in class_offset[4], tap grid in class_kh[4] / class_kw[4] (host arrays). */
 int qt_pack_dgrad_s2(int dtype, const float* w_oihw, void* dst, int O, int I, int k, long long* class_offset,
                      int* class_kh, int* class_kw, void* stream);
+/* The same four classes as ONE operand [4*I][2*2][O] for a single 2x2-tap launch over the gradient map
+ * (qt_conv_desc.dst_merge = I, kh = kw = 2, pad 0, n_out = 4*I): row class*I + i, tap slot th*2 + tw with th / tw = 0
+ * the tap on the source row / column itself, 1 the tap on the next one; slots no tap maps to are zero.  k = 3 only;
+ * dst holds 16*O*I elements (9/16 of them non-zero: the launch reads the gradient map once instead of four times and
+ * needs no per-class launches, at 16/9 of the MFMA work). */
+int qt_pack_dgrad_s2_merged(int dtype, const float* w_oihw, void* dst, int O, int I, void* stream);
 /* [64][3][7][7] -> [64][taps][8][4] for the packed stem; taps = 7, or 8 (8th row zero)
  * when a 32-element tap is only half a K-step (bf16: desc.kh = 8) */
 int qt_pack_stem_weight(int dtype, const float* w_oihw, void* dst, int taps, void* stream);

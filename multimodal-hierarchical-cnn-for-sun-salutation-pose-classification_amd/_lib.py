@@ -37,6 +37,7 @@ class ConvDesc(ctypes.Structure):
         ("quad", ctypes.c_int), ("relu", ctypes.c_int),
         ("dst_sub", ctypes.c_int), ("dst_h", ctypes.c_int), ("dst_w", ctypes.c_int),
         ("dst_off_h", ctypes.c_int), ("dst_off_w", ctypes.c_int),
+        ("dst_merge", ctypes.c_int), ("dst_merge_res0", ctypes.c_int),
     ]
 
 

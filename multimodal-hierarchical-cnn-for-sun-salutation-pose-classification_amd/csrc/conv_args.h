@@ -33,6 +33,8 @@ struct ConvArgs {
   // destination row mapping (0 = dense): row m = (img, oh, ow) of the OHxOW grid is written to
   // pixel (oh*dst_sub + dst_oh, ow*dst_sub + dst_ow) of a dst_h x dst_w image
   int dst_sub, dst_h, dst_w, dst_oh, dst_ow;
+  int dst_merge_res0;       // residual only for class (0,0)
+  int dst_merge;            // C > 0: N = 4*C, the four parity classes of a stride-2 data gradient in one launch (qtcnn.h)
   FastDiv div_ohw, div_ow;
 };
 

@@ -323,6 +323,11 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   const int cg = tid % TPR, r0 = tid / TPR;
   const int nbase = n0 + cg * 8;
   const bool n_ok = nbase < p.N;  // N is a multiple of 8
+  // merged parity classes (dst_merge): this thread's 8 channels are channels cbase.. of class nbase / C
+  const int dN = p.dst_merge ? p.dst_merge : p.N;
+  const int mcls = p.dst_merge ? nbase / p.dst_merge : 0;
+  const int cbase = p.dst_merge ? nbase - mcls * p.dst_merge : nbase;
+  const int d_oh = p.dst_merge ? (mcls >> 1) : p.dst_oh, d_ow = p.dst_merge ? (mcls & 1) : p.dst_ow;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -336,13 +341,13 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   float mu0[8], is0[8], mu1[8], is1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    mu0[e] = (bwd_stats && n_ok) ? p.bn_mean[0][nbase + e] : 0.f;
-    is0[e] = (bwd_stats && n_ok) ? p.bn_invstd[0][nbase + e] : 0.f;
-    mu1[e] = (p.bn_y[1] && n_ok) ? p.bn_mean[1][nbase + e] : 0.f;
-    is1[e] = (p.bn_y[1] && n_ok) ? p.bn_invstd[1][nbase + e] : 0.f;
+    mu0[e] = (bwd_stats && n_ok) ? p.bn_mean[0][cbase + e] : 0.f;
+    is0[e] = (bwd_stats && n_ok) ? p.bn_invstd[0][cbase + e] : 0.f;
+    mu1[e] = (p.bn_y[1] && n_ok) ? p.bn_mean[1][cbase + e] : 0.f;
+    is1[e] = (p.bn_y[1] && n_ok) ? p.bn_invstd[1][cbase + e] : 0.f;
   }
   T* __restrict__ dst = static_cast<T*>(p.dst);
-  const T* __restrict__ res = static_cast<const T*>(p.residual);
+  const T* __restrict__ res = (p.dst_merge && p.dst_merge_res0 && mcls != 0) ? nullptr : static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
   // Passes run in batches of PB rows: the batch's memory operands (residual, ReLU mask, saved BatchNorm
   // inputs; 16 bytes per thread and row each) are all requested before the first row is finished, so a tile
@@ -371,9 +376,9 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         const unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
         const unsigned oh = fdiv(rem, p.div_ow);
         const unsigned ow = rem - oh * (unsigned)p.OW;
-        drow = ((long long)img * p.dst_h + oh * p.dst_sub + p.dst_oh) * p.dst_w + ow * p.dst_sub + p.dst_ow;
+        drow = ((long long)img * p.dst_h + oh * p.dst_sub + d_oh) * p.dst_w + ow * p.dst_sub + d_ow;
       }
-      offs[u] = drow * p.N + nbase;
+      offs[u] = drow * dN + cbase;
       if constexpr (PB > 1) {
         raw_res[u] = raw_msk[u] = raw_y0[u] = raw_y1[u] = make_uint4(0u, 0u, 0u, 0u);
         if (oks[u]) {
@@ -466,9 +471,9 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         const unsigned rem = (unsigned)m - img * (unsigned)(p.OH * p.OW);
         const unsigned oh = fdiv(rem, p.div_ow);
         const unsigned ow = rem - oh * (unsigned)p.OW;
-        drow = ((long long)img * p.dst_h + oh * p.dst_sub + p.dst_oh) * p.dst_w + ow * p.dst_sub + p.dst_ow;
+        drow = ((long long)img * p.dst_h + oh * p.dst_sub + d_oh) * p.dst_w + ow * p.dst_sub + d_ow;
       }
-      const long long off = drow * p.N + nbase;
+      const long long off = drow * dN + cbase;
       if (!bwd_stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -533,11 +538,16 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
       }
       if (n0 + tid < p.N) {
         float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
-        o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-        o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
+        // partial row of this pixel tile (merged parity classes: one row of C channels per class) and column
+        const int n = n0 + tid;
+        const int cls = p.dst_merge ? n / p.dst_merge : 0;
+        const long long row = p.dst_merge ? (long long)mt * (p.N / p.dst_merge) + cls : mt;
+        const int col = n - cls * (p.dst_merge ? p.dst_merge : 0);
+        o0[(row * 2 + 0) * dN + col] = a;
+        o0[(row * 2 + 1) * dN + col] = b;
         if (bwd_stats && p.bn_y[1]) {
-          p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-          p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
+          p.bn_partial[1][(row * 2 + 0) * dN + col] = a;
+          p.bn_partial[1][(row * 2 + 1) * dN + col] = c;
         }
       }
     }
@@ -630,7 +640,8 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
     a.src_img_stride = d->src_img_stride; a.src_row_stride = d->src_row_stride; a.src_pix_stride = d->src_pix_stride;
     if (qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
   }
-  return qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
+  const int rows = qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
+  return d->dst_merge > 0 ? rows * (d->n_out / d->dst_merge) : rows;  // merged parity classes: one row per class
 }
 
 extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
@@ -693,6 +704,12 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.stride = d->stride; a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.relu = d->relu;
   a.gridM = a.gridN = 0;
   a.dst_sub = d->dst_sub; a.dst_h = d->dst_h; a.dst_w = d->dst_w; a.dst_oh = d->dst_off_h; a.dst_ow = d->dst_off_w;
+  a.dst_merge = d->dst_merge; a.dst_merge_res0 = d->dst_merge_res0;
+  QT_CHECK_ARG(d->dst_merge == 0 || (d->dst_merge > 0 && d->dst_merge % 8 == 0 && d->dst_sub == 2 &&
+                                     d->n_out == 4 * d->dst_merge && d->dst_off_h == 0 && d->dst_off_w == 0 &&
+                                     !io->scale && !io->shift && d->mode == QT_CONV_FWD &&
+                                     d->dst_h >= 2 * d->out_h && d->dst_w >= 2 * d->out_w),
+               "qt_conv2d_igemm: dst_merge = C needs dst_sub = 2, n_out = 4 C, C %% 8 == 0, no offsets / affine");
   a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
   a.div_ow = make_fastdiv((unsigned)d->out_w);
   QT_CHECK_ARG(d->dst_sub == 0 || (d->dst_sub >= 1 && d->dst_h > 0 && d->dst_w > 0 && !io->stats_partial &&

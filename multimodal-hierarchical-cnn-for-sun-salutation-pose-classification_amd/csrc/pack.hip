@@ -116,7 +116,7 @@ template <> struct PackPair<bf16_t> {
 // one TO(o) x TI(i) x TAPS tile; `tile` holds it as [o][i*TAPS + tap] with an odd row stride
 template <typename T, int TAPS, int TO, int TI>
 __device__ __forceinline__ void pack_tile(float* tile, const float* w, T* __restrict__ fwd, T* __restrict__ dg,
-                                          int O, int I, int o0, int i0, bool s2, const AdamScalars& adam,
+                                          int O, int I, int o0, int i0, int s2, const AdamScalars& adam,
                                           const float* __restrict__ g, float* m, float* v) {
   constexpr int RUN = TI * TAPS, S = RUN + 1, TOTAL = TO * RUN;
   for (int e = threadIdx.x; e < TOTAL; e += 256) {
@@ -159,6 +159,8 @@ __device__ __forceinline__ void pack_tile(float* tile, const float* w, T* __rest
         const long long IO = (long long)I * O;
         const long long base = cls == 0 ? 0 : (cls == 1 ? IO : (cls == 2 ? 3 * IO : 5 * IO));
         dst = base + ((long long)(i0 + i) * (nh * nw) + th * nw + tw) * O + o0 + o;
+        // merged layout of pack_dgrad_s2m_kernel: rows (class, i), 2 x 2 tap slots (the unused ones stay zero)
+        if (s2 == 2) dst = (((long long)cls * I + i0 + i) * 4 + th * 2 + tw) * O + o0 + o;
       }
       PackPair<T>::store(dg + dst, t[0], t[S]);
     }
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(PackBatchArgs
                                   a.g[it], a.m[it], a.v[it]);
   } else {
     const int tiles_i = I >> 5;
-    pack_tile<T, 9, 32, 32>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) << 5, (b % tiles_i) << 5, a.s2[it] != 0, a.adam,
+    pack_tile<T, 9, 32, 32>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) << 5, (b % tiles_i) << 5, (int)a.s2[it], a.adam,
                             a.g[it], a.m[it], a.v[it]);
   }
 }
@@ -254,6 +256,25 @@ __global__ void pack_dgrad_s2_kernel(const float* __restrict__ w, T* __restrict_
       dst[base + idx] = qt_from_f32<T>(w[(((long long)o * I + i) * k + kh) * k + kw]);
     }
     base += total;
+  }
+}
+
+// all four parity classes as ONE operand of a 2x2-tap gather over the gradient map (qt_conv_desc.dst_merge):
+// dst[(class*I + i)][th*2 + tw][o]; th / tw = 0: the tap on the row / column itself (kh / kw = 1 on even, 2 on odd
+// pixels), 1: the tap on the next row / column (kh / kw = 0, odd pixels only).  Slots no tap maps to stay zero.
+template <typename T>
+__global__ void pack_dgrad_s2m_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I) {
+  const long long total = (long long)O * I * 9;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(idx % O);
+    const int tap = (int)((idx / O) % 9);
+    const int i = (int)(idx / ((long long)O * 9));
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int ph = kh != 1, pw = kw != 1;
+    const int th = ph ? (kh == 2 ? 0 : 1) : 0, tw = pw ? (kw == 2 ? 0 : 1) : 0;
+    const int cls = ph * 2 + pw;
+    dst[(((long long)cls * I + i) * 4 + th * 2 + tw) * O + o] = qt_from_f32<T>(w[(((long long)o * I + i) * 3 + kh) * 3 + kw]);
   }
 }
 
@@ -393,7 +414,7 @@ static int pack_batched(int dtype, const qt_pack_item* items, const qt_adam_item
                    "qt_adam_pack_weights_batched: item %d: optimizer state does not match the weight", j);
       a.g[j] = u.grad; a.m[j] = u.exp_avg; a.v[j] = u.exp_avg_sq;
     }
-    a.O[j] = q.O; a.I[j] = q.I; a.k[j] = (unsigned char)q.k; a.s2[j] = q.stride2_dgrad ? 1 : 0;
+    a.O[j] = q.O; a.I[j] = q.I; a.k[j] = (unsigned char)q.k; a.s2[j] = (unsigned char)(q.stride2_dgrad == 2 ? 2 : (q.stride2_dgrad ? 1 : 0));
     a.first_block[j] = blocks;
     blocks += (q.O / te) * (q.I / te);
   }
@@ -429,6 +450,24 @@ extern "C" int qt_pack_dgrad_s2(int dtype, const float* w_oihw, void* dst, int O
   else
     hipLaunchKernelGGL(pack_dgrad_s2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw,
                        static_cast<bf16_t*>(dst), O, I, k);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pack_dgrad_s2_merged(int dtype, const float* w_oihw, void* dst, int O, int I, void* stream) {
+  QT_CHECK_ARG(w_oihw && dst && O > 0 && I > 0, "qt_pack_dgrad_s2_merged: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pack_dgrad_s2_merged: bad dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t esz = dtype == QT_F32 ? 4 : 2;
+  if (hipMemsetAsync(dst, 0, (size_t)16 * O * I * esz, s) != hipSuccess) {
+    qt_set_error("qt_pack_dgrad_s2_merged: memset failed");
+    return QT_ERR_LAUNCH;
+  }
+  const long long total = (long long)O * I * 9;
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(pack_dgrad_s2m_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw, static_cast<float*>(dst), O, I);
+  else
+    hipLaunchKernelGGL(pack_dgrad_s2m_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w_oihw, static_cast<bf16_t*>(dst), O, I);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

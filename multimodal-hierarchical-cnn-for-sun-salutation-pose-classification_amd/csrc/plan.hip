@@ -23,6 +23,17 @@
 
 #include "qt_common.h"
 
+// QTCNN_S2_DGRAD_MERGED (default 1): the data gradient of a 3x3 stride-2 conv is one 2x2-tap launch over the gradient
+// map (qt_conv_desc.dst_merge) instead of four parity-class gathers (0: same-box A/B; identical sums up to f32 order)
+static bool merged_s2_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("QTCNN_S2_DGRAD_MERGED");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+
 namespace {
 
 constexpr int kImg = 224;
@@ -49,6 +60,7 @@ struct ConvL {
   // stride-2 data gradient as four parity-class gathers (qt_pack_dgrad_s2)
   long long cls_off[4];
   int cls_kh[4], cls_kw[4];
+  bool merged_dgrad = false;   // 3x3 stride 2: one 2x2-tap launch for all four parity classes
 };
 
 struct Block {
@@ -315,7 +327,10 @@ void layout_workspace(qt_plan* p) {
       qt_pack_dgrad_s2(p->d.dtype, reinterpret_cast<const float*>(8), nullptr, c.cout, c.cin, c.k, c.cls_off, c.cls_kh,
                        c.cls_kw, nullptr);
     c.w_fwd = ws.take(n * es);
-    c.w_dgrad = ws.take(n * es);
+    // 3x3 stride 2: the data-gradient operand holds all four parity classes with 2 x 2 tap slots each (16/9 of the
+    // filter, the unused slots zero: qt_pack_dgrad_s2_merged)
+    c.merged_dgrad = i > 0 && c.stride == 2 && c.k == 3 && merged_s2_enabled();
+    c.w_dgrad = ws.take((c.merged_dgrad ? (size_t)16 * c.cout * c.cin : n) * es);
   }
   // f32 [O][kh][kw][I] weight-gradient scratch of all convs, contiguous: zeroed by ONE memset per backward
   p->dw_begin = ws.off;
@@ -602,7 +617,8 @@ struct Exec {
     const double imgs = (double)d.batch * qt_quad_regions(d.quad);
     const double fwd_pixels = d.mode == QT_CONV_FWD ? (double)d.out_h * d.out_w : (double)d.in_h * d.in_w;
     const bool stem = d.k_per_tap == 32 && d.kw == 1 && d.stride == 2 && d.n_out == 64;
-    const double k = stem ? 147.0 : (double)d.kh * d.kw * d.k_per_tap;
+    // (merged parity classes: 4 C outputs x 4 tap slots stand for the C outputs x 9 taps of the stride-2 conv)
+    const double k = stem ? 147.0 : (d.dst_merge ? 9.0 / 4.0 : (double)d.kh * d.kw) * d.k_per_tap;
     return 2.0 * imgs * fwd_pixels * k * d.n_out;
   }
   int begin_timed(double flops, int kind, void* on = nullptr) {
@@ -668,7 +684,7 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
   Exec e{p, static_cast<unsigned char*>(workspace), T, stream, p->d.batch, p->d.dtype};
   // one launch for every conv / linear operand (plus the 9 K-element stem filter)
   std::vector<qt_pack_item> items;
-  auto add = [&](const float* w, void* fwd, void* dgrad, int O, int I, int k, bool s2) {
+  auto add = [&](const float* w, void* fwd, void* dgrad, int O, int I, int k, int s2) {
     qt_pack_item q;
     q.w_oihw = w; q.w_fwd = fwd; q.w_dgrad = dgrad; q.O = O; q.I = I; q.k = k; q.stride2_dgrad = s2;
     items.push_back(q);
@@ -679,7 +695,7 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
       if (i == 0)
         e.run(qt_pack_stem_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), e.stem_taps(), stream));
       else
-        add(e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2);
+        add(e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2 ? (c.merged_dgrad ? 2 : 1) : 0);
     }
   }
   if (!p->lstm)  // (CnnLstm's classifier is a thin f32 product: no packed copy)
@@ -707,7 +723,7 @@ int adam_step(qt_plan* p, void* workspace, void* const* T, float* const* G, floa
     for (int d = 0; d < p->tensors[idx].ndim; ++d) n *= p->tensors[idx].shape[d];
     return n;
   };
-  auto add = [&](int widx, void* fwd, void* dgrad, int O, int I, int k, bool s2) -> int {
+  auto add = [&](int widx, void* fwd, void* dgrad, int O, int I, int k, int s2) -> int {
     qt_pack_item q;
     q.w_oihw = e.tf(widx); q.w_fwd = fwd; q.w_dgrad = dgrad; q.O = O; q.I = I; q.k = k; q.stride2_dgrad = s2;
     if (G[widx]) {
@@ -726,7 +742,7 @@ int adam_step(qt_plan* p, void* workspace, void* const* T, float* const* G, floa
   if (p->has_image)
     for (size_t i = 1; i < p->convs.size(); ++i) {
       const ConvL& c = p->convs[i];
-      if (int st = add(c.w, e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2)) return st;
+      if (int st = add(c.w, e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2 ? (c.merged_dgrad ? 2 : 1) : 0)) return st;
     }
   if (!p->lstm)
     if (int st = add(p->cls0.w, e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1, false))
@@ -1018,6 +1034,18 @@ struct Bwd : Exec {
     if (c.stride == 1) {
       const qt_conv_desc d = conv_desc(c, QT_CONV_DGRAD);
       igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, -1, links, nlinks);
+      return qt_conv2d_stats_rows(&d);
+    }
+    if (c.merged_dgrad) {  // all four parity classes in one 2x2-tap launch over the gradient map
+      qt_conv_desc d;
+      memset(&d, 0, sizeof(d));
+      d.dtype = dt; d.mode = QT_CONV_FWD; d.batch = B;
+      d.in_h = d.in_w = c.hout; d.out_h = d.out_w = c.hin / 2;
+      d.k_per_tap = c.cout; d.n_out = 4 * c.cin;
+      d.kh = d.kw = 2; d.stride = 1; d.pad = 0;
+      d.src_pix_stride = c.cout; d.src_row_stride = c.hout * c.cout; d.src_img_stride = (long long)c.hout * c.hout * c.cout;
+      d.dst_sub = 2; d.dst_h = d.dst_w = c.hin; d.dst_merge = c.cin; d.dst_merge_res0 = sparse ? 1 : 0;
+      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, 1, links, nlinks);
       return qt_conv2d_stats_rows(&d);
     }
     bool empty_class = false;
@@ -1566,6 +1594,11 @@ extern "C" int qt_plan_init_workspace(qt_plan* p, void* workspace, void* stream)
   hipError_t e1 = hipMemcpyAsync(static_cast<unsigned char*>(workspace) + p->ones, one.data(), 2048 * 4,
                                  hipMemcpyHostToDevice, s);
   hipError_t e2 = hipMemsetAsync(static_cast<unsigned char*>(workspace) + p->zeros, 0, 2048 * 4, s);
+  // merged stride-2 data-gradient operands: the tap slots no filter tap maps to are zero for good (the packers write
+  // the nine real taps only)
+  for (const ConvL& c : p->convs)
+    if (c.merged_dgrad && e2 == hipSuccess)
+      e2 = hipMemsetAsync(static_cast<unsigned char*>(workspace) + c.w_dgrad, 0, (size_t)16 * c.cout * c.cin * p->esz, s);
   hipError_t e3 = hipStreamSynchronize(s);  // `one` is a host temporary
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     qt_set_error("qt_plan_init_workspace: HIP error");

@@ -383,6 +383,62 @@ def test_quadrant_wgrad(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 56), (3, 128, 256, 28), (5, 256, 512, 14), (1, 64, 64, 10)])
+def test_stride2_dgrad_merged_classes(dt, cfg):
+    """Data gradient of a 3x3 stride-2 conv as ONE 2x2-tap launch over the gradient map (qt_conv_desc.dst_merge,
+    qt_pack_dgrad_s2_merged): values (+ residual, ReLU mask) against torch.nn.grad.conv2d_input, and the
+    BatchNorm-backward link sums (4 partial rows per pixel tile) against the sums of the written gradient."""
+    dev = _dev()
+    L = pkg("_lib")
+    B, Cin, Cout, H = cfg
+    Ho = H // 2
+    g = torch.Generator().manual_seed(7)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cout * 9)) ** 0.5).to(dt).float()
+    dy = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    other = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    act = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    ybn = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    mean = torch.randn(Cin, generator=g) * 0.1
+    invstd = torch.rand(Cin, generator=g) + 0.5
+    ref = (torch.nn.grad.conv2d_input((B, Cin, H, H), w, dy, 2, 1) + other) * (act > 0)
+
+    lib = L.lib()
+    wd = torch.full((16 * Cout * Cin,), float("nan"), dtype=dt, device=dev)   # the packer zeroes the unused slots
+    L.check(lib.qt_pack_dgrad_s2_merged(L.qt_dtype(dt), L.ptr(w.to(dev)), L.ptr(wd), Cout, Cin, L.stream_ptr()),
+            "qt_pack_dgrad_s2_merged")
+    d = L.ConvDesc()
+    d.dtype, d.mode, d.batch = L.qt_dtype(dt), L.QT_CONV_FWD, B
+    d.in_h = d.in_w = Ho
+    d.out_h = d.out_w = Ho
+    d.k_per_tap, d.n_out = Cout, 4 * Cin
+    d.kh, d.kw, d.stride, d.pad = 2, 2, 1, 0
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = Ho * Ho * Cout, Ho * Cout, Cout
+    d.dst_sub, d.dst_h, d.dst_w, d.dst_off_h, d.dst_off_w, d.dst_merge = 2, H, H, 0, 0, Cin
+    rows = lib.qt_conv2d_stats_rows(ctypes.byref(d))
+    assert rows > 0 and rows % 4 == 0
+    part = torch.full((rows, 2, Cin), float("nan"), dtype=torch.float32, device=dev)
+    out = torch.full((B * H * H, Cin), float("nan"), dtype=dt, device=dev)   # every pixel belongs to one class
+    dyd = nhwc(dy).to(dev, dt)
+    res = nhwc(other).to(dev, dt).view(-1, Cin)
+    msk = nhwc(act).to(dev, dt).view(-1, Cin)
+    yb = nhwc(ybn).to(dev, dt).view(-1, Cin)
+    md, isd = mean.to(dev), invstd.to(dev)
+    io = L.ConvIO(L.ptr(dyd), L.ptr(wd), L.ptr(out), None, None, L.ptr(res), L.ptr(msk), None,
+                  L.ptr(yb), L.ptr(md), L.ptr(isd), L.ptr(part), None, None, None, None)
+    L.check(lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()), "qt_conv2d_igemm")
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(B, H, H, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= TOL[dt]
+    sums = part.sum(0).cpu()
+    xhat = (ybn - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    assert rel_err(sums[0], got.sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    assert rel_err(sums[1], (got * xhat).sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    # bad shapes are refused
+    d.n_out = 2 * Cin
+    assert lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(2, 64, 128, 56, 3), (2, 128, 256, 28, 1), (3, 256, 512, 14, 3)])
 def test_stride2_dgrad_by_parity_classes(dt, cfg):
     """Data gradient of a stride-2 conv as four stride-1 gathers with a strided destination."""
