@@ -161,7 +161,15 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
     w_ptr[i] = wgt + (long long)(w_ok[i] ? n : 0) * ktot + chunk * (16 / (int)sizeof(T));
   }
 
-  const int nk = (p.ntaps * p.KC) / BK;
+  // Merged parity classes (dst_merge): a class uses 1, 2, 2 or 4 of the four tap slots and the others hold zero weights:
+  // the K loop of this channel tile visits only the slots one of its classes uses (tmask; all slots otherwise).
+  unsigned tmask = 0xffffffffu;
+  if (p.dst_merge) {
+    const int c_lo = n0 / p.dst_merge, c_hi = (min(p.N, n0 + BN) - 1) / p.dst_merge;
+    tmask = 0u;
+    for (int c = c_lo; c <= c_hi; ++c) tmask |= ((c >> 1) ? 0x5u : 0x1u) * ((c & 1) ? 0x3u : 0x1u);
+  }
+  const int nk = __builtin_popcount(tmask & ((1u << p.ntaps) - 1u)) * p.KC / BK;
 
   // A K-step is 128 bytes of K per row.  Normally that is a slice of one tap
   // (tap uniform over the workgroup); when a tap is only 64 bytes (the packed
@@ -171,7 +179,19 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   const unsigned smem_base = lds_addr_of(smem);
   // uniform (tap, channel offset) of the NEXT stage to issue; stages are issued in order
   int nx_kh = 0, nx_kw = 0, nx_tap = 0, nx_c0 = 0;
+  auto next_tap = [&]() {  // the next tap slot this channel tile uses
+    do {
+      ++nx_tap;
+      if (++nx_kw == p.KW) {
+        nx_kw = 0;
+        ++nx_kh;
+      }
+    } while (nx_tap < p.ntaps && !((tmask >> nx_tap) & 1u));
+  };
+  if (!(tmask & 1u)) next_tap();
   auto dma_stage = [&](int ks, int buf) {
+    const long long woff = sub ? (long long)ks * BK : (long long)nx_tap * p.KC + nx_c0;  // K offset of this stage's weights
+
     const unsigned sa = smem_base + buf * STAGE_BYTES + wave * (8 * kRowBytes);  // LDS byte addresses
     const unsigned sw = sa + BM * kRowBytes;
     if (slow) {
@@ -205,15 +225,11 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
     nx_c0 += BK;
     if (nx_c0 >= p.KC) {
       nx_c0 = 0;
-      ++nx_tap;
-      if (++nx_kw == p.KW) {
-        nx_kw = 0;
-        ++nx_kh;
-      }
+      next_tap();
     }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      const T* g = w_ok[i] ? w_ptr[i] + (long long)ks * BK : zero_src;
+      const T* g = w_ok[i] ? w_ptr[i] + woff : zero_src;
       glds16(g, sw + i * (RG * kRowBytes));
     }
   };
