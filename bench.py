@@ -427,8 +427,9 @@ def main():
                 traffic_src = src + " (kernel sources sha1 " + rec["kernel_sources_sha1"][:12] + ")"
             else:
                 traffic_src = src
-            roofline = {"kernel": "forward + data-gradient conv launches (conv_igemm_kernel; conv_l1_ring_kernel for the "
-                                  "56x56 64->64 layers; conv_stem_kernel for conv1)",
+            roofline = {"kernel": "forward + data-gradient conv launches (conv_pt_kernel for the 3x3 stride-1 layers of "
+                                  "layer2-4; conv_l1_ring_kernel for the 56x56 64->64 layers; conv_igemm_kernel for the "
+                                  "stride-2 transitions; conv_stem_kernel for conv1)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(1e3 * (ms[0] + ms[1]) / nig, 2),
