@@ -378,9 +378,14 @@ int launch_patch_flip(const PatchArgs& a, hipStream_t stream) {
 // the L2->LDS path, and workgroup dispatch gaps / exposed prologues (what holds the one-tile-per-
 // workgroup kernel above back) disappear.
 // ---------------------------------------------------------------------------------------------
-constexpr int L1_PW = 58, L1_RING = 640, L1_WBYTES = 9 * 64 * kRowBytes, L1_RBYTES = L1_RING * kRowBytes;
-constexpr int L1_RED = L1_WBYTES + L1_RBYTES;           // [8 waves][2 i][4 fk][4 r][3] floats
-constexpr int L1_LDS = L1_RED + 8 * 2 * 4 * 4 * 3 * 4;
+// The ring is followed by a MIRROR of its first 48 rows: a lane's four 16-row tiles of a tap then sit at rr0, rr0 + 16,
+// rr0 + 32, rr0 + 48 with ONE wrap of rr0 per tap instead of one per fragment (the fragment addresses were 4.7 vector
+// instructions per MFMA, PMC: 22.1 M VALU beside 3.9 M MFMAs per launch).  The statistics scratch aliases the filter.
+constexpr int L1_PW = 58, L1_RING = 640, L1_MIRROR = 48, L1_WBYTES = 9 * 64 * kRowBytes;
+constexpr int L1_RBYTES = (L1_RING + L1_MIRROR) * kRowBytes;
+constexpr int L1_RED = 0;                               // [8 waves][2 i][4 fk][4 r][3] floats, over the (dead) filter
+constexpr int L1_LDS = L1_WBYTES + L1_RBYTES;
+static_assert(L1_LDS <= 160 * 1024 && 8 * 2 * 4 * 4 * 3 * 4 <= L1_WBYTES, "layer1 ring kernel LDS");
 
 // Halo positions of a tile store their (meaningless) 16 bytes here instead of branching around the store: every wave then
 // issues exactly four stores per tile, and the next tile's barrier can wait with a COUNTED vmcnt for the window fetch alone
@@ -427,6 +432,8 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
     }
     const int rrow = __builtin_amdgcn_readfirstlane(ub % L1_RING);
     glds16(g, smem_base + L1_WBYTES + (rrow + wave * 8) * kRowBytes);
+    if (rrow == 0 && wave < L1_MIRROR / 8)  // rows 0..47 also behind the ring (same source, same pass)
+      glds16(g, smem_base + L1_WBYTES + (L1_RING + wave * 8) * kRowBytes);
   };
 
   // ---- prologue: filter (LDS row t*64 + n) and the first window ----
@@ -467,6 +474,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
   const unsigned char* ring = smem + L1_WBYTES;
+  const int w_lane = (wn * 32 + frow) * kRowBytes + ((fk ^ (frow & 7)) << 4);  // this lane's filter fragment, tap 0 / tile 0 / kk 0
 
   int base = 0;  // (256*k) mod 640
   for (int k = 0; k < nt; ++k) {
@@ -523,20 +531,20 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
       constexpr int kPW = L1_PW;
       const int kh = t / 3, kw = t % 3;
       const int shift = FLIP ? (2 - kh) * kPW + (2 - kw) : kh * kPW + kw;
+      // first row of this lane's four tiles for the tap, wrapped once; (row & 7) = (frow + shift) & 7 for all of them
+      // (base, wm * 64, j * 16 and the ring size are multiples of 8): the swizzled 16-byte column is a per-tap constant
+      int rr0 = lane_row + shift;
+      rr0 = rr0 >= L1_RING ? rr0 - L1_RING : rr0;
+      const int a0 = rr0 * kRowBytes + ((fk ^ ((frow + shift) & 7)) << 4);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         uint4 fw[2], fa[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = t * 64 + wn * 32 + i * 16 + frow;
-          fw[i] = *reinterpret_cast<const uint4*>(smem + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
-        }
+        for (int i = 0; i < 2; ++i)   // filter row t*64 + wn*32 + i*16 + frow: (row & 7) = frow & 7
+          fw[i] = *reinterpret_cast<const uint4*>(smem + (w_lane ^ (kk << 6)) + (t * 64 + i * 16) * kRowBytes);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int rr = lane_row + j * 16 + shift;
-          rr = rr >= L1_RING ? rr - L1_RING : rr;
-          fa[j] = *reinterpret_cast<const uint4*>(ring + rr * kRowBytes + (((kk * 4 + fk) ^ (rr & 7)) << 4));
-        }
+        for (int j = 0; j < 4; ++j)
+          fa[j] = *reinterpret_cast<const uint4*>(ring + (a0 ^ (kk << 6)) + j * (16 * kRowBytes));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -627,6 +635,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
         }
       }
     float* red = reinterpret_cast<float*>(smem + L1_RED);  // [wave][i][fk][r][3]
+    __syncthreads();  // the scratch lies over the filter: every wave has issued its last MFMA
     if (frow == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
