@@ -424,15 +424,17 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       if (!oks[u]) continue;
       const long long off = offs[u];
-      if (!bwd_stats) {
+      if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           s1[e] += v[e];
           s2[e] += v[e] * v[e];
         }
       }
+if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+      }
       if (res) {
         float rv[8];
         operand(res, raw_res[u], off, rv);
@@ -490,15 +492,17 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         drow = ((long long)img * p.dst_h + oh * p.dst_sub + d_oh) * p.dst_w + ow * p.dst_sub + d_ow;
       }
       const long long off = drow * dN + cbase;
-      if (!bwd_stats) {
+      if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           s1[e] += v[e];
           s2[e] += v[e] * v[e];
         }
       }
+if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+      }
       if (res) {
         float rv[8];
         QtVec8<T>::load(res + off, rv);

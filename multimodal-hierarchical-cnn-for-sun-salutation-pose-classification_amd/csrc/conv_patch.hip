@@ -98,15 +98,17 @@ __device__ __forceinline__ void patch_epilogue(const PatchArgs& p, unsigned char
       const unsigned wp = rem - hp * (unsigned)p.PW;
       if (hp >= 1 && hp <= (unsigned)p.H && wp >= 1 && wp <= (unsigned)p.W) {
         const long long off = ((((long long)img * p.H + (hp - 1)) * p.W + (wp - 1))) * p.N + nbase;
-        if (!bwd_stats) {
+        if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             s1[e] += v[e];
             s2[e] += v[e] * v[e];
           }
         }
+if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        }
         if (res) {
           float rv[8];
           QtVec8<T>::load(res + off, rv);
@@ -569,15 +571,17 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (!bwd_stats) {
+        if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             s1[i][r] += lm * v[r];
             s2[i][r] += lm * v[r] * v[r];
           }
         }
+if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[i][r] + sh[i][r];
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[i][r] + sh[i][r];
+        }
         if (OPS && res) {
           float rv[4];
           bf4(i ? pre_res[j].z : pre_res[j].x, i ? pre_res[j].w : pre_res[j].y, rv);

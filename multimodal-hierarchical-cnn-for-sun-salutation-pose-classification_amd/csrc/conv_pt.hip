@@ -384,15 +384,17 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
                       acc[2 * pi + 1][j][0], acc[2 * pi + 1][j][1], acc[2 * pi + 1][j][2], acc[2 * pi + 1][j][3]};
         if (!ok[u]) continue;
         const long long off = (long long)drow[j] * p.N + c0;
-        if (!bwd_stats) {
+        if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             s1[e] += v[e];
             s2[e] += v[e] * v[e];
           }
         }
+if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        }
         if (res) {
           float rv[8];
           rres[u].get(rv);
