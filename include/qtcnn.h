@@ -486,6 +486,9 @@ int qt_plan_profile_end(qt_plan* plan, double* flops3, double* ms3, int* launche
  * all-reduce stream), make it wait for the side stream with qt_plan_side_fence (and for the
  * caller's stream as usual).  The last phase joins the side stream into the caller's stream. */
 int qt_plan_side_fence(qt_plan* plan, void* waiting_stream);
+/* Once per workspace, before the first qt_plan_pack_weights: the constant vectors of the identity BatchNorm affine and the
+ * zero tap slots of the merged stride-2 data-gradient operands (qt_pack_dgrad_s2_merged: the packers write the nine real
+ * taps only).  Synchronises `stream`. */
 int qt_plan_init_workspace(qt_plan* plan, void* workspace, void* stream);
 int qt_plan_pack_weights(qt_plan* plan, void* workspace, void* const* tensors, int for_backward, void* stream);
 /* Optimizer step fused with the re-packing (replaces optimizer.step() + qt_plan_pack_weights of a
