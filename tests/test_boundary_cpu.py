@@ -169,6 +169,28 @@ def test_plan_tensor_table_matches_module_tree():
     assert b"dtype" in L.qt_last_error()
 
 
+def test_conv_descriptor_validation_needs_no_device():
+    """qt_conv2d_igemm refuses an inconsistent destination mapping (merged stride-2 data gradient, qtcnn.h) with a
+    message and before any HIP call: runs on the CPU box, the pointers are never dereferenced."""
+    Lm = pkg("_lib")
+    L = Lm.lib()
+    L.qt_last_error.restype = ctypes.c_char_p
+    d = Lm.ConvDesc()
+    d.dtype, d.mode, d.batch = Lm.qt_dtype(torch.bfloat16), Lm.QT_CONV_FWD, 2
+    d.in_h = d.in_w = d.out_h = d.out_w = 14
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = 128, 4 * 64, 2, 2, 1, 0
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = 14 * 14 * 128, 14 * 128, 128
+    d.dst_sub, d.dst_h, d.dst_w, d.dst_merge = 2, 28, 28, 64
+    fake = ctypes.c_void_p(4096)
+    io = Lm.ConvIO(fake, fake, fake, None, None, None, None, None)
+    for field, bad in (("n_out", 2 * 64), ("dst_merge", 60), ("dst_sub", 1), ("dst_h", 20)):
+        good = getattr(d, field)
+        setattr(d, field, bad)
+        assert L.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), None) != 0, field
+        assert b"dst" in L.qt_last_error(), field
+        setattr(d, field, good)
+
+
 def test_missing_pretrained_weights_are_loud(monkeypatch):
     """The reference always starts from ImageNet weights (resnet18(weights=IMAGENET1K_V1), models.py:221); offline they
     are absent, and a frozen random backbone must not go unnoticed: one UserWarning naming QTCNN_RESNET18_WEIGHTS,
