@@ -489,7 +489,7 @@ def test_stride2_dgrad_by_parity_classes(dt, cfg):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_batched_weight_pack_matches_per_layer_packing(dt):
     """qt_pack_weights_batched (one launch, LDS tile transposes) must reproduce qt_pack_conv_weight and
-    the parity-class layout of qt_pack_dgrad_s2 bit for bit."""
+    the parity-class / merged layouts of qt_pack_dgrad_s2 / qt_pack_dgrad_s2_merged bit for bit."""
     dev = _dev()
     L = pkg("_lib")
     lib = L.lib()
@@ -499,7 +499,9 @@ def test_batched_weight_pack_matches_per_layer_packing(dt):
                     ("O", ctypes.c_int), ("I", ctypes.c_int), ("k", ctypes.c_int), ("s2", ctypes.c_int)]
 
     g = torch.Generator().manual_seed(31)
-    shapes = [(64, 64, 3, 0), (128, 64, 3, 1), (128, 64, 1, 1), (512, 256, 3, 1), (128, 192, 1, 0), (2688, 5376, 1, 0)]
+    # (O, I, k, stride2_dgrad): 1 = parity-class layout, 2 = merged layout (3x3 only; zero tap slots zeroed beforehand)
+    shapes = [(64, 64, 3, 0), (128, 64, 3, 1), (128, 64, 1, 1), (512, 256, 3, 1), (128, 192, 1, 0), (2688, 5376, 1, 0),
+              (128, 64, 3, 2), (512, 256, 3, 2)]
     qdt = L.qt_dtype(dt)
     st = L.stream_ptr()
     items = (Item * len(shapes))()
@@ -507,9 +509,12 @@ def test_batched_weight_pack_matches_per_layer_packing(dt):
     for j, (O, I, k, s2) in enumerate(shapes):
         w = torch.randn(O, I, k, k, generator=g).to(dev)
         fwd = torch.zeros(O * k * k * I, dtype=dt, device=dev)
-        dg = torch.zeros(O * k * k * I, dtype=dt, device=dev)
+        dg = torch.zeros((16 if s2 == 2 else k * k) * O * I, dtype=dt, device=dev)
         rf, rd = torch.zeros_like(fwd), torch.zeros_like(dg)
-        if s2:
+        if s2 == 2:
+            L.check(lib.qt_pack_conv_weight(qdt, L.ptr(w), L.ptr(rf), None, O, I, k, k, st), "qt_pack_conv_weight")
+            L.check(lib.qt_pack_dgrad_s2_merged(qdt, L.ptr(w), L.ptr(rd), O, I, st), "qt_pack_dgrad_s2_merged")
+        elif s2:
             L.check(lib.qt_pack_conv_weight(qdt, L.ptr(w), L.ptr(rf), None, O, I, k, k, st), "qt_pack_conv_weight")
             L.check(lib.qt_pack_dgrad_s2(qdt, L.ptr(w), L.ptr(rd), O, I, k, None, None, None, st), "qt_pack_dgrad_s2")
         else:
