@@ -8,6 +8,7 @@ Metric: max|x - ref| / max|ref|.  The f32-MFMA build must meet
 against a looser, stated bound (bf16 has 8 significand bits: 4e-2).
 """
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -524,3 +525,17 @@ def test_eval_mode_backward_through_trainable_backbone(kind):
             assert _cos(got, ref_s) >= 0.999 and err <= 6e-2, (n, err, _cos(got, ref_s))
         else:
             assert err <= 1e-4, (n, err)
+
+
+@pytest.mark.parametrize("env", [{"QTCNN_S2_DGRAD_MERGED": "0"}, {"QTCNN_WP_VARIANT": "0", "QTCNN_PT_CONV": "0"}])
+def test_alternate_kernel_selections_keep_train_step_parity(env):
+    """The kernel-selection switches are read once per process: the round-1 forms they keep reachable (four parity-class
+    gathers for the stride-2 data gradients; ring weight-gradient kernel and generic 3x3 convs) are exercised by running
+    the reference-golden train-step test of the f32 parity build in a child process with the switch set."""
+    import subprocess
+    child_env = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_train_step_matches_reference_golden and qs_quadtree_train"],
+                       env=child_env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]
