@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256 * G, 2 / G) void conv_wgrad_patch_kernel(WPArgs
 //     pad rows and rows past the tensor are zero-filled by the buffer range check;
 //   * 8 waves, two per SIMD: group g of four waves contracts chunks g, g+2, ... of the tile; the groups' partial
 //     filters are exchanged through LDS as in the G = 2 ring kernel;
-//   * 222 VGPRs and (by default) up to 160 KB of LDS.  Measured alone (B = 256, the 13 layers of the model): 58-70 us
+//   * 222 VGPRs (allocated: 224 -- two such waves leave 64 registers per SIMD, one wave of the main stream's BatchNorm
+//     kernels; with the X fragments three taps ahead it is 226 -> 232 and the step is 2 % slower, 6.45 vs 6.33 ms, at the
+//     same kernel time) and (by default) up to 160 KB of LDS.  Measured alone (B = 256, the 13 layers of the model): 58-70 us
 //     per launch against 86-93 (ring, one group) and 75-84 (ring, two groups); 42-50 % MFMA-busy.  What is left: the
 //     two waves of a SIMD share one matrix pipe and their streams do not interleave (fragment reads, DMA slots and
 //     MFMAs measured additive: 9 + 7 + 28 us of a 50 us loop), ~12 us of prologue (table, first tile) and epilogue
