@@ -270,14 +270,15 @@ class _ConvBlock:
         else:
             da = dout
         dy, dgamma, dbeta = o.bn_backward(dt, da, a, y, stats, self.gamma_p, rows, self.cout_p, dev, training)
-        # conv bias gradient = column sums of dy: slab sums by the statistics kernel (one streaming pass at HBM rate),
-        # then the few hundred partial rows (qt_col_sum over 12.8 M rows took 0.64 ms per layer, 15 % of the step)
-        db = torch.empty(self.cout_p, dtype=torch.float32, device=dev)
-        prow = o.L.qt_bn_stats_rows(_c.c_longlong(rows), self.cout_p)
-        part = torch.empty(prow, 2, self.cout_p, dtype=torch.float32, device=dev)
-        o.check(o.L.qt_bn_stats(_lib.qt_dtype(dt), _ptr(dy), _c.c_longlong(rows), self.cout_p, _ptr(part), _lib.stream_ptr()),
-                "qt_bn_stats")
-        o.col_sum(torch.float32, part, prow, self.cout_p, 2 * self.cout_p, db)
+        # conv bias gradient = column sums of dy.  No pass over dy is needed (it was 0.5 ms of the step): with
+        # dy = ca (g - cb - xhat cc), ca = gamma invstd, the sum over positions is ca (sum g - M cb - cc sum xhat);
+        # under batch statistics cb = sum g / M and sum xhat = 0: the gradient of a bias in front of a train-mode
+        # BatchNorm is zero (the reference's autograd returns rounding noise there); under running statistics
+        # cb = cc = 0 and it is gamma invstd sum g = gamma invstd dbeta.
+        if training:
+            db = torch.zeros(self.cout_p, dtype=torch.float32, device=dev)
+        else:
+            db = self.gamma_p.detach().float() * stats[1] * dbeta
         dW = torch.empty_like(self.conv.weight)
         dx = None
         if self.first:
