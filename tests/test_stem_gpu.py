@@ -213,3 +213,35 @@ def test_stem_conv_pool_fused_eval_kernel(B):
     torch.cuda.synchronize()
     assert torch.equal(pooled, pooled2)                       # same MFMA order, same rounding: bit-identical
     assert rel_err(pooled.float().cpu().permute(0, 3, 1, 2), ref) <= 4e-3
+
+
+def test_stem_conv_pool_negative_zero_is_not_a_maximum():
+    """The fused kernel pools the ReLU tile with a packed SIGNED 16-bit maximum on the raw bf16 words: a -0 (zero input,
+    negative scale, zero shift give -0 conv outputs) must not beat a +0 or a small positive value."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    dt = torch.bfloat16
+    qdt = L.qt_dtype(dt)
+    B = 1
+    image = torch.zeros(B, 3, 224, 224)
+    image[0, :, 100:110, 100:110] = 1.0                       # a patch of positive responses in a field of -0
+    w = torch.full((64, 3, 7, 7), 0.01).to(dt).float()
+    scale = torch.full((64,), -1.0)
+    scale[::2] = 1.0
+    shift = torch.zeros(64)
+    ref = F.max_pool2d(F.relu(F.conv2d(image, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1)
+    st = L.stream_ptr()
+    imd, wd, sc, sh = image.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    xpad = torch.empty(B, 230, 232, 4, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_input(qdt, L.ptr(imd), L.ptr(xpad), B, st), "qt_pack_stem_input")
+    wp = torch.empty(64, 8, 32, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_weight(qdt, L.ptr(wd), L.ptr(wp), 8, st), "qt_pack_stem_weight")
+    pooled = torch.full((B, 56, 56, 64), float("nan"), device=dev, dtype=dt)
+    L.check(lib.qt_stem_conv_pool(qdt, L.ptr(xpad), L.ptr(wp), 8, L.ptr(sc), L.ptr(sh), L.ptr(pooled), B, st), "qt_stem_conv_pool")
+    torch.cuda.synchronize()
+    got = pooled.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all() and (got >= 0).all()
+    assert (got[:, 1::2] == 0).all()                           # negative scale: relu(-x) = 0 everywhere, never a stray -0 win
+    assert rel_err(got, ref) <= 4e-3
+    assert (pooled.view(torch.int16) >= 0).all()               # no sign bit in the result: +0, not -0
