@@ -166,6 +166,43 @@ def cpu_baseline(args, num_classes=12):
                 "kind": "port",
                 "sample": f"{iters} train steps of {S} sequences x {T} frames, torch {torch.__version__} CPU fp32, "
                           f"oracle/quadtree_oracle.py::cnn_lstm_forward"}
+    if args.model == "quadtree3d":
+        # BASELINE config 4: the oracle's Quadtree3DCNN (oracle/quadtree_oracle.py::quadtree3d_forward restates
+        # /root/reference/3dcnn/models.py:184-214) on clips of T frames of 224x224: fwd+bwd+Adam, then an eval-forward leg
+        T = 8 if args.seq_len == 16 else args.seq_len
+        holder = P.Quadtree3DCNN(num_classes, sequence_length=T)
+        sd = o.clip_params({k: v.clone() for k, v in synth.synth_state_dict(holder).items()})
+        params = [v for v in sd.values() if v.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-4)
+        S = max(1, args.cpu_batch // T)
+        g = torch.Generator().manual_seed(1234)
+        x, f = torch.randn(S, T, 3, 224, 224, generator=g), torch.randn(S, T, 47, generator=g)
+        y = torch.randint(0, num_classes, (S,), generator=g)
+
+        def step3d():
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(o.quadtree3d_forward(sd, x, f, train=True), y).backward()
+            opt.step()
+
+        step3d()  # warm-up
+        iters, t0 = 0, time.perf_counter()
+        while iters < 2 or (time.perf_counter() - t0 < 10.0 and iters < 20):
+            step3d()
+            iters += 1
+        dt = time.perf_counter() - t0
+        out = {"value": round(S * T * iters / dt, 2), "unit": "frames/s", "cores": cores, "cores_source": cores_source,
+               "kind": "port",
+               "sample": f"{iters} train steps (fwd+bwd+Adam) of {S} clips x {T} frames of 224x224, torch {torch.__version__} "
+                         f"CPU fp32, oracle/quadtree_oracle.py::quadtree3d_forward"}
+        with torch.no_grad():
+            o.quadtree3d_forward(sd, x, f)
+            k, t1 = 0, time.perf_counter()
+            while k < 1 or (time.perf_counter() - t1 < 5.0 and k < 20):
+                o.quadtree3d_forward(sd, x, f)
+                k += 1
+            out["legs"] = [{"what": f"Quadtree3DCNN eval forward, {S} clips x {T} frames", "unit": "frames/s", "iterations": k,
+                            "value": round(S * T * k / (time.perf_counter() - t1), 2)}]
+        return out
     if args.model == "attention":
         holder = P.AttentionHierarchicalCNN(num_classes)  # parameter tree only (CPU tensors), never called
         sd0 = o.attention_sd_to_base(synth.synth_state_dict(holder))
@@ -404,7 +441,11 @@ def main():
         torch.cuda.synchronize()
         fl, ms, ln = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int * 3)()
         L.qt_plan_profile_end(eng.handle, fl, ms, ln)
-        kinds = ["conv_igemm_kernel fwd", "conv_igemm_kernel dgrad", "conv_wgrad_kernel"]
+        # what the plan's three timing kinds aggregate (csrc/plan.hip begin_timed): every forward conv / linear launch,
+        # every data-gradient launch, every weight-gradient launch -- whichever kernel family serves the layer
+        kinds = ["forward conv launches (conv_stem / conv_l1_ring / conv_s2 / conv_pt / conv_igemm / linear_splitk)",
+                 "data-gradient conv launches (conv_l1_ring / conv_pt / conv_igemm merged stride-2 / linear_splitk)",
+                 "weight-gradient launches (conv_wgrad_tile + partial sums / conv_wgrad generic)"]
         per = {}
         for k in range(3):
             if ln[k]:

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
     tmask = 0u;
     for (int c = c_lo; c <= c_hi; ++c) tmask |= ((c >> 1) ? 0x5u : 0x1u) * ((c & 1) ? 0x3u : 0x1u);
   }
-  const int nk = __builtin_popcount(tmask & ((1u << p.ntaps) - 1u)) * p.KC / BK;
+  const int nk = __builtin_popcount(tmask & (p.ntaps >= 32 ? ~0u : (1u << p.ntaps) - 1u)) * p.KC / BK;
 
   // A K-step is 128 bytes of K per row.  Normally that is a slice of one tap
   // (tap uniform over the workgroup); when a tap is only 64 bytes (the packed
@@ -728,8 +728,10 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG(d->dst_merge == 0 || (d->dst_merge > 0 && d->dst_merge % 8 == 0 && d->dst_sub == 2 &&
                                      d->n_out == 4 * d->dst_merge && d->dst_off_h == 0 && d->dst_off_w == 0 &&
                                      !io->scale && !io->shift && d->mode == QT_CONV_FWD &&
+                                     d->kh == 2 && d->kw == 2 && d->stride == 1 && d->pad == 0 &&
                                      d->dst_h >= 2 * d->out_h && d->dst_w >= 2 * d->out_w),
-               "qt_conv2d_igemm: dst_merge = C needs dst_sub = 2, n_out = 4 C, C %% 8 == 0, no offsets / affine");
+               "qt_conv2d_igemm: dst_merge = C needs a 2x2 / stride 1 / pad 0 gather, dst_sub = 2, n_out = 4 C, C %% 8 == 0, "
+               "no offsets / affine");
   a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
   a.div_ow = make_fastdiv((unsigned)d->out_w);
   QT_CHECK_ARG(d->dst_sub == 0 || (d->dst_sub >= 1 && d->dst_h > 0 && d->dst_w > 0 && !io->stats_partial &&

@@ -20,6 +20,47 @@ QtError = importlib.import_module(_PKG + "._lib").QtError
 
 StandardResNetCNN = _impl.StandardResNetCNN
 
+import torch as _torch
+import torch.nn.functional as _F
+
+
+class FocalLoss(_torch.nn.Module):
+    """Counterpart of /root/reference/3dcnn/models.py:8-47 (a public name of that file; its trainer does not use it).
+    A torch-level loss like CrossEntropyLoss -- it sits above the hot path and stays PyTorch:
+        loss_i = -alpha[t_i] * (1 - p_i)^gamma * log p_i,   p_i = softmax(logits_i)[t_i]
+    `alpha`: a list of per-class weights (len == num_classes), or a float a, stored as [a, 1 - a] exactly as the reference
+    does (usable for two classes only).  The reference leaves `alpha_t` unbound for every other combination and dies with
+    UnboundLocalError; here that case is a ValueError naming the cause."""
+
+    def __init__(self, alpha=0.25, gamma=2.0, reduction='mean', num_classes=None):
+        super().__init__()
+        self.gamma = gamma
+        self.reduction = reduction
+        self.num_classes = num_classes
+        if isinstance(alpha, (float, int)):
+            alpha = _torch.tensor([alpha, 1 - alpha])
+        elif isinstance(alpha, list):
+            alpha = _torch.tensor(alpha)
+        self.alpha = alpha
+
+    def forward(self, inputs, targets):
+        logp = _F.log_softmax(inputs, dim=-1).gather(1, targets.view(-1, 1)).squeeze()
+        p = logp.exp()
+        a = self.alpha
+        if _torch.is_tensor(a) and a.dim() > 1:
+            alpha_t = a[targets]
+        elif _torch.is_tensor(a) and a.dim() == 1 and a.size(0) == self.num_classes:
+            alpha_t = a.to(targets.device)[targets]
+        else:
+            raise ValueError("FocalLoss: alpha must hold one weight per class (len == num_classes); the reference leaves "
+                             "alpha_t undefined for this configuration")
+        loss = -alpha_t * (1 - p).pow(self.gamma) * logp
+        if self.reduction == 'mean':
+            return loss.mean()
+        if self.reduction == 'sum':
+            return loss.sum()
+        return loss
+
 
 class Quadtree3DCNN(_v3d.Quadtree3DCNN):
     def __init__(self, num_classes, sequence_length=8, cnn_3d_feature_dim=1024, numerical_feature_dim=47, dropout_rate=0.6,

@@ -392,7 +392,19 @@ class _ClipModel(nn.Module):
                     tuple(numerical_sequence.shape[:2]) != (B, T) or numerical_sequence.shape[2] != self.numerical_feature_dim:
                 raise ValueError(f"numerical_sequence must be [{B},{T},{self.numerical_feature_dim}]")
 
+    def _check_hooks(self):
+        """The whole forward / backward is one autograd node that never calls the leaf modules: a hook registered on a
+        submodule (the reference's Grad-CAM API targets `conv3d_final_features`, 3dcnn/models.py:181-182) would silently
+        never fire.  Same policy as the 2-D models (quadtree.py::_check_hooks): raise instead of staying dead."""
+        for name, mod in self.named_modules():
+            if mod is self:
+                continue
+            if mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks:
+                raise QtError(f"hook registered on submodule {name!r}: the clip models run as one fused autograd node and "
+                              "serve no submodule hooks (hooks on the model itself work); they would never fire")
+
     def _run(self, image_sequence, numerical_sequence):
+        self._check_hooks()
         params = [p for p in self.parameters()]
         return _ClipFunction.apply(self, image_sequence, numerical_sequence, *params)
 
@@ -415,6 +427,22 @@ class _ClipFunction(torch.autograd.Function):
             raise QtError("backward() after a later forward() on the same model: one set of activations is kept")
         with torch.cuda.device(dlogits.device):
             grads = owner._backward_impl(dlogits.contiguous().float())
+            sync = getattr(owner, "_grad_sync", None)
+            if sync is not None:
+                # data parallelism (dp.attach_data_parallel): there is no plan with phase buckets behind the clip models,
+                # so every gradient of the step is averaged over the ranks as ONE flat f32 bucket at the end of backward
+                live = [g for g in grads if g is not None]
+                if live:
+                    flat = torch.cat([g.reshape(-1).float() for g in live])
+                    sync(flat, 1)
+                    sync(None, 0)   # join: the compute stream sees the averaged bucket
+                    outs, off = [], 0
+                    for g in live:
+                        n = g.numel()
+                        outs.append(flat[off:off + n].view_as(g).to(g.dtype))
+                        off += n
+                    it = iter(outs)
+                    grads = [None if g is None else next(it) for g in grads]
         return (None, None, None, *grads)
 
 

@@ -23,16 +23,31 @@ def main():
     synth = importlib.import_module(PKG + ".synth")
     dp = importlib.import_module(PKG + ".dp")
     dev = torch.device("cuda:0")
+    kind = sys.argv[6] if len(sys.argv) > 6 else "quadtree"
     try:
-        model = P.QuadtreeCNN(12, dropout_rate=0.0, compute_dtype=torch.float32)
+        G = per_rank * world
+        b, e = dp.shard_range(G, rank, world)
+        if kind == "quadtree":
+            model = P.QuadtreeCNN(12, dropout_rate=0.0, compute_dtype=torch.float32)
+            x, f = synth.synth_images(G, salt=500), synth.synth_pose_features(G, salt=500)
+        elif kind == "quadtree3d":     # BASELINE config 4's model; clips of T = 4 frames of 64x64 (per_rank clips per rank)
+            T, HW = 4, 64
+            model = P.Quadtree3DCNN(12, sequence_length=T, dropout_rate=0.0, compute_dtype=torch.float32)
+            x = synth.synth_images(G * T, salt=500, size=HW).view(G, T, 3, HW, HW)
+            f = synth.synth_pose_features(G * T, salt=500).view(G, T, 47)
+        elif kind == "cnn_lstm":       # BASELINE config 5's per-GPU size: per_rank (6) sequences of T = 16 frames
+            T = 16
+            model = P.CnnLstm(12, sequence_length=T, dropout_rate=0.0, compute_dtype=torch.float32, max_batch=per_rank * T)
+            x = synth.synth_images(G * T, salt=500).view(G, T, 3, 224, 224)
+            f = synth.synth_pose_features(G * T, salt=500).view(G, T, 47)
+        else:
+            raise SystemExit(f"unknown model kind {kind}")
+        y = synth.synth_labels(G, 12, salt=500)
         # rank 0 holds the weights; the others start from a different fill and must receive rank 0's by broadcast
         model.load_state_dict(synth.synth_state_dict(model, salt=0 if rank == 0 else 7))
         model = model.to(dev).train()
         dp.attach_data_parallel(model)
-        G = per_rank * world
-        x, f, y = synth.synth_images(G, salt=500), synth.synth_pose_features(G, salt=500), synth.synth_labels(G, 12, salt=500)
-        b, e = dp.shard_range(G, rank, world)
-        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        opt = torch.optim.SGD([p_ for p_ in model.parameters() if p_.requires_grad], lr=1e-2)
         opt.zero_grad()
         loss = torch.nn.functional.cross_entropy(model(x[b:e].to(dev), f[b:e].to(dev)), y[b:e].to(dev))
         loss.backward()
@@ -43,7 +58,8 @@ def main():
         params = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
         torch.save({"loss": loss.item(), "grads": grads, "params": params, "shard": (b, e),
                     "bytes_reduced": model._grad_sync.bytes_reduced,
-                    "running_mean": model.base_cnn.bn1.running_mean.cpu()}, os.path.join(out, f"rank{rank}.pt"))
+                    "running_mean": next(b_ for n_, b_ in model.named_buffers() if n_.endswith("running_mean")).cpu()},
+                   os.path.join(out, f"rank{rank}.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
