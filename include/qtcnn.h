@@ -133,6 +133,47 @@ void qt_set_pt_conv(int mode);
  * workgroup).  1 (default) on, 0 generic implicit GEMM. */
 void qt_set_stem_conv(int mode);
 int qt_conv2d_stats_rows(const qt_conv_desc* desc);
+/* ---------------------------------------------------------------------------
+ * The stride-2 transition of a ResNet stage in ONE launch (csrc/conv_s2.hip): conv1 of layerN.0 (3x3 / stride 2 / pad 1,
+ * no bias) and its downsample (1x1 / stride 2, no bias) computed from one staged input patch -- torchvision BasicBlock
+ * with `downsample`, i.e. the nn.Conv2d calls behind /root/reference/Quadtree_from scratch/models.py:
+ * 228-229,241 (layer2.0, layer3.0, layer4.0) and resnet/models.py:86-88,99.  Replaces two qt_conv2d_igemm launches.
+ *   y_conv = epi_conv(conv3x3s2(x, w_conv)),  y_down = epi_down(conv1x1s2(x, w_down)),
+ *   epi(v) = relu?(v * scale[c] + shift[c]) with every part optional; stats_* (optional) receive per (pixel tile, wave row)
+ *   sums and sums of squares of the RAW v per channel: [qt_conv_s2_pair_stats_rows][2][c_out] f32 (qt_bn_finalize's input).
+ * x: NHWC [batch][in_h][in_w][c_in]; w_conv: [c_out][3][3][c_in] (qt_pack_conv_weight's forward operand); w_down:
+ * [c_out][c_in]; y_*: NHWC [batch][in_h/2][in_w/2][c_out].  Supported (qt_conv_s2_pair_supported): in_h == in_w in
+ * {56, 28, 14}, c_in a multiple of 64 (bf16) / 32 (f32), c_out a multiple of 128, batch >= 16 (a multiple of 4 for
+ * 14x14 inputs); other problems take qt_conv2d_igemm.  Same arithmetic as the generic path (f32 accumulation on MFMA)
+ * in another K order.  QTCNN_S2_CONV=0 / qt_set_conv_s2(0): report "unsupported" (same-box A/B against the generic pair).
+ * ------------------------------------------------------------------------ */
+typedef struct qt_conv_s2_desc {
+  int dtype;            /* qt_dtype of x, the weights and both outputs */
+  int batch;
+  int in_h, in_w;
+  int c_in, c_out;
+  int relu_conv, relu_down;
+} qt_conv_s2_desc;
+typedef struct qt_conv_s2_io {
+  const void* src;
+  const void* w_conv;
+  const void* w_down;
+  void* y_conv;
+  void* y_down;
+  const float* scale_conv;  /* [c_out] or NULL */
+  const float* shift_conv;
+  const float* scale_down;
+  const float* shift_down;
+  float* stats_conv;        /* or NULL */
+  float* stats_down;
+} qt_conv_s2_io;
+int qt_conv_s2_pair_supported(const qt_conv_s2_desc* desc);
+int qt_conv_s2_pair_stats_rows(const qt_conv_s2_desc* desc);
+int qt_conv_s2_pair(const qt_conv_s2_desc* desc, const qt_conv_s2_io* io, void* stream);
+void qt_set_conv_s2(int mode);
+/* tests: cap the persistent grid (0 = one workgroup per CU) so that small batches exercise several items per workgroup */
+void qt_set_conv_s2_max_workgroups(int n);
+
 int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream);
 
 /* Weight gradient of the convolution described by `desc` (mode QT_CONV_FWD):

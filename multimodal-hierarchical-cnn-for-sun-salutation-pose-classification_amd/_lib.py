@@ -55,6 +55,19 @@ class ConvIO(ctypes.Structure):
     ]
 
 
+class ConvS2Desc(ctypes.Structure):   # qt_conv_s2_desc
+    _fields_ = [("dtype", ctypes.c_int), ("batch", ctypes.c_int), ("in_h", ctypes.c_int), ("in_w", ctypes.c_int),
+                ("c_in", ctypes.c_int), ("c_out", ctypes.c_int), ("relu_conv", ctypes.c_int), ("relu_down", ctypes.c_int)]
+
+
+class ConvS2IO(ctypes.Structure):     # qt_conv_s2_io
+    _fields_ = [("src", ctypes.c_void_p), ("w_conv", ctypes.c_void_p), ("w_down", ctypes.c_void_p),
+                ("y_conv", ctypes.c_void_p), ("y_down", ctypes.c_void_p),
+                ("scale_conv", ctypes.c_void_p), ("shift_conv", ctypes.c_void_p),
+                ("scale_down", ctypes.c_void_p), ("shift_down", ctypes.c_void_p),
+                ("stats_conv", ctypes.c_void_p), ("stats_down", ctypes.c_void_p)]
+
+
 _lib = None
 
 

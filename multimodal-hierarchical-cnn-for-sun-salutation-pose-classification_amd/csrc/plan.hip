@@ -656,6 +656,48 @@ struct Exec {
     }
     // eval: scale / shift of every BatchNorm were set by eval_affines() at the start of the forward
   }
+  // conv1 (3x3 / stride 2) and the downsample (1x1 / stride 2) of a transition block from ONE staged input patch
+  // (csrc/conv_s2.hip); false: the problem is not covered (small batches, QTCNN_S2_CONV=0) -> the two generic launches.
+  // training as conv_bn_stats: 0 = eval epilogues (conv1 -> bn1 -> ReLU into blk.a1, downsample -> its BatchNorm into
+  // cd.y), 1 = raw outputs + batch statistics of both, 2 = raw outputs
+  bool transition_pair(const Block& blk, const void* x, int training) {
+    if (!ok() || blk.ds < 0) return false;
+    const ConvL& c1 = p->convs[blk.conv1];
+    const ConvL& cd = p->convs[blk.ds];
+    if (c1.k != 3 || c1.stride != 2 || c1.pad != 1 || cd.k != 1 || cd.stride != 2 || cd.pad != 0) return false;
+    qt_conv_s2_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dt; d.batch = B; d.in_h = d.in_w = c1.hin; d.c_in = c1.cin; d.c_out = c1.cout;
+    if (!qt_conv_s2_pair_supported(&d)) return false;
+    BnL& b1 = p->bns[c1.bn];
+    BnL& bd = p->bns[cd.bn];
+    qt_conv_s2_io io;
+    memset(&io, 0, sizeof(io));
+    io.src = x; io.w_conv = at(c1.w_fwd); io.w_down = at(cd.w_fwd);
+    io.y_conv = training == 0 ? at(blk.a1) : at(c1.y);
+    io.y_down = at(cd.y);
+    if (training == 0) {
+      d.relu_conv = 1;
+      io.scale_conv = at<float>(b1.scale); io.shift_conv = at<float>(b1.shift);
+      io.scale_down = at<float>(bd.scale); io.shift_down = at<float>(bd.shift);
+    } else if (training == 1) {
+      io.stats_conv = at<float>(p->stats);
+      io.stats_down = at<float>(p->stats_ds);
+    }
+    const int slot = begin_timed(conv_flops(conv_desc(c1, QT_CONV_FWD)) + conv_flops(conv_desc(cd, QT_CONV_FWD)), 0);
+    run(qt_conv_s2_pair(&d, &io, stream));
+    end_timed(slot);
+    if (training == 1 && ok()) {
+      const int rows = qt_conv_s2_pair_stats_rows(&d);
+      run(qt_bn_finalize(at<float>(p->stats), rows, b1.C, rows_of(c1), tf(b1.gamma), tf(b1.beta), tf(b1.rmean), tf(b1.rvar),
+                         static_cast<long long*>(T[b1.nbt]), p->d.bn_momentum, p->d.bn_eps, at<float>(b1.mean),
+                         at<float>(b1.invstd), at<float>(b1.scale), at<float>(b1.shift), stream));
+      run(qt_bn_finalize(at<float>(p->stats_ds), rows, bd.C, rows_of(cd), tf(bd.gamma), tf(bd.beta), tf(bd.rmean), tf(bd.rvar),
+                         static_cast<long long*>(T[bd.nbt]), p->d.bn_momentum, p->d.bn_eps, at<float>(bd.mean),
+                         at<float>(bd.invstd), at<float>(bd.scale), at<float>(bd.shift), stream));
+    }
+    return true;
+  }
   // eval mode: running statistics -> scale / shift of all BatchNorms in one launch
   void eval_affines(bool for_backward) {
     std::vector<qt_bn_eval_item> items;
@@ -865,7 +907,9 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
       const BnL& b2 = p->bns[c2.bn];
       const qt_conv_desc d1 = e.conv_desc(c1, QT_CONV_FWD), d2 = e.conv_desc(c2, QT_CONV_FWD);
       const long long M = e.rows_of(c2);
-      if (blk.ds >= 0) {
+      // a transition block: conv1 and the downsample in one launch where the fused kernel covers the problem
+      const bool pair = blk.ds >= 0 && e.transition_pair(blk, e.at(x), training);
+      if (blk.ds >= 0 && !pair) {
         const ConvL& cd = p->convs[blk.ds];
         const BnL& bd = p->bns[cd.bn];
         const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
@@ -877,11 +921,11 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
                     nullptr, nullptr, 0);
         });
       }
-      e.conv_bn_stats(c1, d1, e.at(x), training);
+      if (!pair) e.conv_bn_stats(c1, d1, e.at(x), training);
       if (unf) {
         e.run(qt_bn_act(dt, e.at(c1.y), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr, nullptr, nullptr, 1,
                         e.at(blk.a1), M, c1.cout, stream));
-      } else {
+      } else if (!pair) {
         e.igemm(d1, e.at(x), e.at(c1.w_fwd), e.at(blk.a1), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr,
                 nullptr, nullptr, 1);
       }
@@ -893,7 +937,7 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         const qt_conv_desc dd = e.conv_desc(cd, QT_CONV_FWD);
         // (fork happened before conv1, see below)
         e.conv_bn_stats(c2, d2, e.at(blk.a1), training);
-        e.join();
+        if (!pair) e.join();   // (the fused pair ran on this stream: a head branch forked earlier keeps running beside layer4)
         if (unf) {
           e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(cd.y),
                           e.at<float>(bd.scale), e.at<float>(bd.shift), 1, e.at(blk.out), M, c2.cout, stream));

@@ -126,8 +126,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
       : "memory");
 }
 // LDS-DMA through a buffer resource: 64 lanes x 16 B from  base + voff (per lane, bytes) + soff (wave-uniform)  to the
-// 1 KiB at LDS byte address `lds_addr`.  Lanes whose voff is outside [0, num_records) write ZEROS (hardware range check
-// of raw buffers; soff does not take part in it): halo rows and rows past the tensor need no second pointer, and a
+// 1 KiB at LDS byte address `lds_addr`.  Lanes whose voff + soff is outside [0, num_records) write ZEROS (hardware range
+// check of raw buffers; measured in round 3: the scalar offset DOES take part -- a tile-sized num_records with the tile's
+// origin in soff zeroed every tile but the first -- so num_records spans the whole tensor): halo rows and rows past the tensor need no second pointer, and a
 // transfer costs no vector instruction -- the per-lane offsets are loop invariants, tap / chunk offsets are scalar.
 // (Issued from inline asm, like glds16: the compiler neither counts it in vmcnt nor fences LDS reads with vmcnt(0).)
 typedef __attribute__((ext_vector_type(4))) int i32x4;

@@ -58,9 +58,43 @@ def bench(kind, B, H, Cin, Cout, k, s, p, dt=torch.bfloat16, workspace=False):
     fl = 2.0 * B * Ho * Ho * Cout * Cin * k * k
     print(f"{kind:6s} B{B} H{H} {Cin:4d}->{Cout:4d} k{k} s{s}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
 
+def bench_s2(B, H, Cin, Cout, dt=torch.bfloat16, eval_epi=True, stats=False):
+    """the fused stride-2 transition (csrc/conv_s2.hip) against the two generic launches it replaces"""
+    st = L.stream_ptr()
+    Ho = H // 2
+    x = torch.randn(B, H, H, Cin, device=dev).to(dt)
+    wc = (torch.randn(Cout, 9, Cin, device=dev) * 0.05).to(dt); wd = (torch.randn(Cout, Cin, device=dev) * 0.1).to(dt)
+    y = torch.empty(B * Ho * Ho, Cout, device=dev, dtype=dt); yd = torch.empty_like(y)
+    sc = torch.rand(Cout, device=dev) + 0.5; sh = torch.randn(Cout, device=dev) * 0.1
+    d = L.ConvS2Desc(L.qt_dtype(dt), B, H, H, Cin, Cout, 1 if eval_epi else 0, 0)
+    rows = L.lib().qt_conv_s2_pair_stats_rows(ctypes.byref(d))
+    s1 = torch.zeros(rows, 2, Cout, device=dev); s2 = torch.zeros(rows, 2, Cout, device=dev)
+    io = L.ConvS2IO(L.ptr(x), L.ptr(wc), L.ptr(wd), L.ptr(y), L.ptr(yd), L.ptr(sc) if eval_epi else None,
+                    L.ptr(sh) if eval_epi else None, L.ptr(sc) if eval_epi else None, L.ptr(sh) if eval_epi else None,
+                    L.ptr(s1) if stats else None, L.ptr(s2) if stats else None)
+    us = timeit(lambda: L.check(L.lib().qt_conv_s2_pair(ctypes.byref(d), ctypes.byref(io), st)))
+    d3, _ = desc(dt, L.QT_CONV_FWD, B, H, Cin, Cout, 3, 2, 1)
+    d1, _ = desc(dt, L.QT_CONV_FWD, B, H, Cin, Cout, 1, 2, 0)
+    d3.relu = 1 if eval_epi else 0
+    io3 = L.ConvIO(L.ptr(x), L.ptr(wc), L.ptr(y), L.ptr(sc) if eval_epi else None, L.ptr(sh) if eval_epi else None, None, None, None)
+    io1 = L.ConvIO(L.ptr(x), L.ptr(wd), L.ptr(yd), L.ptr(sc) if eval_epi else None, L.ptr(sh) if eval_epi else None, None, None, None)
+    u3 = timeit(lambda: L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d3), ctypes.byref(io3), st)))
+    u1 = timeit(lambda: L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d1), ctypes.byref(io1), st)))
+    fl = 2.0 * B * Ho * Ho * Cout * Cin * 10
+    mb = (x.numel() + 2 * y.numel()) * x.element_size() / 1e6
+    print(f"s2pair B{B} H{H} {Cin:4d}->{Cout:4d} {'eval' if eval_epi else ('stats' if stats else 'raw')}: {us:7.1f} us "
+          f"{fl / us / 1e6:7.1f} TFLOP/s {mb / us * 1e-0:6.2f} TB/s(alg {mb:.0f} MB) | generic 3x3 {u3:6.1f} + 1x1 {u1:6.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     B = 256
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "s2":
+        for ev, stt in ((True, False), (False, True)):
+            bench_s2(B, 56, 64, 128, eval_epi=ev, stats=stt)
+            bench_s2(B, 28, 128, 256, eval_epi=ev, stats=stt)
+            bench_s2(B, 14, 256, 512, eval_epi=ev, stats=stt)
+        sys.exit(0)
     if which in ("all", "ksweep"):
         for cin in (64, 128, 256, 512):
             bench("fwd", B, 28, cin, 128, 3, 1, 1)
