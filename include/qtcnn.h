@@ -125,8 +125,13 @@ void qt_set_patch_conv(int mode);
  * (csrc/conv_pt.hip: 196-pixel tiles of whole image rows, input patch + halo of a 128-byte channel chunk in LDS for all
  * nine taps, weight tiles streamed through an LDS-DMA ring, two wave groups half a period apart).  1 (default) on,
  * 0 generic implicit GEMM.  Same arithmetic (f32 accumulation on MFMA) in a different K order: chunk-major, tap-minor;
- * qt_conv2d_stats_rows follows the choice (one row per 196-pixel tile). */
+ * qt_conv2d_stats_rows follows the choice (two rows per 196-pixel tile: one per wave row). */
 void qt_set_pt_conv(int mode);
+/* The 128-channel-tile instantiations of that kernel are PERSISTENT: one workgroup per CU walks consecutive (channel tile,
+ * pixel tile) items without stopping the K-tile stream (the 28x28 stage of the benchmark: four items per workgroup).
+ * tests: cap the grid at n workgroups (0 = one per CU; a huge n = one item per workgroup, QTCNN_PT_PERSIST=0 does the
+ * same): results are bit-identical for every n. */
+void qt_set_pt_conv_max_workgroups(int n);
 /* The packed bf16 stem convolution (desc of qt_pack_stem_input: kh 7|8, kw 1, stride 2, k_per_tap 32,
  * 64 outputs, no residual / mask / bwd_bn) takes a dedicated kernel (csrc/conv_stem.hip: input
  * rows of a 4 x 112 pixel tile in LDS, filter in registers, one partial-statistics row per

@@ -55,6 +55,7 @@ struct PtArgs {
   int G, R, W, H;               // sub-images per tile, rows per sub-image part, image width / height
   int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
   int tpi, tiles_m, batch;      // pixel tiles per image (GEO_ROWS), pixel tiles in all, images
+  int items, ipw;               // (channel tile, pixel tile) items in all / per workgroup (persistent walk)
   int nchunks;                  // 128-byte channel chunks of the source
   unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
   // GEO_STACK on the 2x2 quadrants of 14x14 maps (the quadrant conv, Quadtree_from scratch/models.py:277-287): "image"
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   constexpr int RW = BN / 64;               // LDS-DMA instructions per wave and weight tile (64 rows per pass)
   constexpr int D = NBW - 1;                // weight tiles in flight
   constexpr int WSLOT = BN * kKB;           // bytes of a weight ring slot
+  constexpr bool AFF_LDS = BN == 128;       // room behind the rings for the per-channel vectors of the epilogue
   static_assert(TN % 2 == 0 && TN >= 2, "a wave owns whole 32-channel groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvArgs& p = q.c;
-
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -152,18 +153,32 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int wm = grp, wn = wave & 3;       // pixel half, channel quarter
   const int frow = lane & 15, fk = lane >> 4;
 
-  // consecutive logical ids share an XCD (its L2): 32 pixel tiles of ONE channel tile -> one weight slice per XCD
-  const int nblk = q.tiles_m * p.gridN;
-  const int bid = qt_xcd_remap(blockIdx.x, nblk);
-  const int nt = bid / q.tiles_m, mt = bid - nt * q.tiles_m;
-  const int n0 = nt * BN;
-  // the tile's images: GEO_ROWS: part (mt % tpi) of image mt / tpi;  GEO_STACK: images 4*mt .. 4*mt + 3, whole
-  const int img0 = GEO == GEO_ROWS ? mt / q.tpi : mt * 4;
-  const int row0 = GEO == GEO_ROWS ? (mt - img0 * q.tpi) * q.R : 0;
+  // PERSISTENT (round 3): a workgroup walks `ipw` consecutive items = (channel tile nt, pixel tile mt), nt-major; the
+  // K-tile stream never stops at an item boundary (the next item's first patch and weight tiles are requested during
+  // the last chunk of the current one) and the epilogue runs from the accumulators between two K-tiles.  Consecutive
+  // logical workgroup ids share an XCD (its L2): a weight slice and neighbouring pixel tiles per XCD.
+  const int wg = qt_xcd_remap(blockIdx.x, gridDim.x);
+  // (the 256-channel tile has no register room for the walk's state next to its epilogue: one item per workgroup there --
+  // which is what 256 images give its 14x14 stage anyway; the loop below then runs once and its state dies in the epilogue)
+  constexpr bool PERSIST = BN == 128;
+  const int item_begin = __builtin_amdgcn_readfirstlane(PERSIST ? wg * q.ipw : wg);
+  const int item_end = PERSIST ? min(item_begin + q.ipw, q.items) : item_begin + 1;
+  if (item_begin >= q.items) return;   // (uniform, before any barrier)
 
   constexpr int patch_bytes = NPASS * 64 * kKB;
   const unsigned smem_base = lds_addr_of(smem);
   const unsigned wring = smem_base + 2 * patch_bytes;
+  // per-channel vectors of the epilogue ([6][N] f32: scale, shift, mean / invstd of two BatchNorm links) in LDS: an
+  // epilogue in the middle of the K-tile stream must not wait for global loads behind the DMA queue
+  float* aff = reinterpret_cast<float*>(smem + 2 * patch_bytes + NBW * WSLOT);
+  if constexpr (AFF_LDS) {
+    for (int i = tid; i < 6 * p.N; i += kNT) {
+      const int v = i / p.N, c = i - v * p.N;
+      const float* src = v == 0 ? p.scale : v == 1 ? p.shift : v == 2 ? p.bn_mean[0] : v == 3 ? p.bn_invstd[0]
+                                                                    : v == 4 ? p.bn_mean[1] : p.bn_invstd[1];
+      aff[i] = src ? src[c] : (v == 0 ? 1.f : 0.f);
+    }
+  }
 
   // ---- per-thread staging rows -------------------------------------------------
   // a DMA wave instruction fills 8 rows x 128 B, lane-linear; LDS slot (lane & 7) of row r receives source chunk
@@ -171,60 +186,84 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int rbase = tid >> 3;                         // row inside a 64-row pass
   const int chunk = (tid & 7) ^ (rbase & 7);          // source 16-byte chunk of this lane (64 | pass stride)
   const int ce = chunk * (16 / (int)sizeof(T));       // ... in elements
-  // patch position i*64 + rbase of pass i: sub-image, patch row / column -> source pixel or the zero page
-  // (32-bit BYTE offsets from `src`; kOob = out of the buffer's range: the DMA writes zeros there)
+  // patch position i*64 + rbase of pass i: sub-image, patch row / column -> source pixel relative to the TILE's origin (the
+  // origin travels in the scalar offset, so these are invariant over the items of a workgroup) or kOob = out of the
+  // buffer's range: the DMA writes zeros there.  GEO_ROWS: the resource's base sits one image row above the tensor, so the
+  // halo row above the tile (real pixels unless the tile starts its image) has a non-negative offset; rows past the end of
+  // the image below the last tile are switched off per item (top / bottom lanes).  32-bit BYTE offsets.
   unsigned pp_off[NPASS];
+  unsigned edge = 0;      // bit i: this lane's row of pass i is the halo row above the tile; bit 8 + i: the one below it
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
     pp_off[i] = kOob;
     const int pos = i * 64 + rbase;
-    int ir, ic, img;
-    bool ok;
     if constexpr (GEO == GEO_ROWS) {
       const unsigned pr = fdiv((unsigned)pos, q.div_pw);
       const unsigned pc = (unsigned)pos - pr * (unsigned)q.PW;
-      ir = row0 + (int)pr - 1; ic = (int)pc - 1; img = img0;
-      ok = pos < q.npos && (unsigned)ir < (unsigned)q.H && (unsigned)ic < (unsigned)q.W;
+      if (pos < q.npos && pc >= 1 && (int)pc <= q.W) {
+        pp_off[i] = (unsigned)((long long)pr * p.src_row_stride + (long long)((int)pc - 1) * p.src_pix_stride + ce) * (unsigned)sizeof(T);
+        if (pr == 0) edge |= 1u << i;
+        if ((int)pr == q.R + 1) edge |= 256u << i;
+      }
     } else {
       const int pr = (pos >> 3) & 7, pc = pos & 7;          // pr = 0 / pc = 0: shared pad row / column
-      ir = pr - 1; ic = pc - 1; img = img0 + (pos >> 6);
-      ok = pos < 256 && pr >= 1 && pc >= 1;                  // (positions 256..: the last image's bottom pad row)
-    }
-    if (ok && img < q.batch) {
-      long long simg = img;
-      if (GEO == GEO_STACK && q.quad == 1) {   // quadrant (img & 3) of map img >> 2
-        simg = img >> 2;
-        ir += ((img >> 1) & 1) * 7;
-        ic += (img & 1) * 7;
+      int ir = pr - 1, ic = pc - 1;
+      const int img = pos >> 6;
+      if (pos < 256 && pr >= 1 && pc >= 1) {                 // (positions 256..: the last image's bottom pad row)
+        long long simg = img;
+        if (q.quad == 1) {   // quadrant img of the tile's map
+          simg = 0;
+          ir += ((img >> 1) & 1) * 7;
+          ic += (img & 1) * 7;
+        }
+        pp_off[i] = (unsigned)((simg * p.src_img_stride + (long long)ir * p.src_row_stride +
+                                (long long)ic * p.src_pix_stride) + ce) * (unsigned)sizeof(T);
       }
-      pp_off[i] = (unsigned)((simg * p.src_img_stride + (long long)ir * p.src_row_stride +
-                              (long long)ic * p.src_pix_stride) + ce) * (unsigned)sizeof(T);
     }
   }
+  // scalar part: the origin of pixel tile mt (bytes), and which halo rows of it are padding
+  auto tile_origin = [&](int mt, unsigned& soff, int& top, int& bot) {
+    if constexpr (GEO == GEO_ROWS) {
+      const int img0 = mt / q.tpi, part = mt - img0 * q.tpi;
+      soff = (unsigned)(((long long)img0 * p.src_img_stride + (long long)(part * q.R) * p.src_row_stride) * (int)sizeof(T));
+      top = part == 0;
+      bot = part == q.tpi - 1;
+    } else {   // images 4*mt .. 4*mt + 3 (images past the batch are past the buffer's range), or map mt (quadrant mode)
+      soff = (unsigned)((long long)mt * (q.quad == 1 ? 1 : 4) * p.src_img_stride * (int)sizeof(T));
+      top = bot = 0;
+    }
+  };
   // LDS weight row rho = 32*g + 16*i + x holds output channel 32*g + 8*(x>>2) + 4*i + (x&3): a lane's two 16x16
   // tiles (i = 0, 1) of a 32-channel group then own eight consecutive channels 8*fk .. 8*fk+7 of a pixel
+  // (lane part: the row inside the channel tile; the tile's first filter travels in the scalar offset)
   unsigned w_off[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
     const int rho = rbase + 64 * i;
     const int x = rho & 15, ii = (rho >> 4) & 1;
-    const int n = n0 + (rho & ~31) + 8 * (x >> 2) + 4 * ii + (x & 3);
+    const int n = (rho & ~31) + 8 * (x >> 2) + 4 * ii + (x & 3);
     w_off[i] = (unsigned)(n * (9 * p.KC) + ce) * (unsigned)sizeof(T);    // N % BN == 0 (checked by the launcher)
   }
-  const i32x4 rs_src = make_rsrc(p.src, q.src_bytes), rs_wgt = make_rsrc(p.wgt, q.wgt_bytes);
+  const i32x4 rs_src = make_rsrc(static_cast<const unsigned char*>(p.src) -
+                                     (GEO == GEO_ROWS ? (long long)p.src_row_stride * (int)sizeof(T) : 0ll), q.src_bytes),
+              rs_wgt = make_rsrc(p.wgt, q.wgt_bytes);
+  const unsigned wtile_bytes = (unsigned)((long long)BN * 9 * p.KC * (int)sizeof(T));   // filters of one channel tile
+  const unsigned tap_bytes = (unsigned)(p.KC * (int)sizeof(T));
 
-  // rows [pass*64, pass*64+64) of chunk cidx into patch buffer cidx & 1 (`off` = this thread's pp_off[pass])
-  auto dma_patch_pass = [&](int pass, unsigned off, int cidx) {
-    int coff = cidx * (int)kKB;       // chunk offset in bytes
-    asm volatile("" : "+s"(coff));    // (opaque: keeps per-chunk address arithmetic out of the loop invariants)
-    blds16(rs_src, off, (unsigned)coff, smem_base + (cidx & 1) * patch_bytes + pass * (64 * kKB) + wave * 1024);
+  // rows [pass*64, pass*64+64) of a chunk into patch buffer `buf` (`off` = this thread's pp_off[pass], `coff` = the
+  // chunk's byte offset inside a pixel)
+  auto dma_patch_pass = [&](const i32x4& rs, int pass, unsigned off, unsigned soff, int buf) {
+    blds16(rs, off, soff, smem_base + buf * patch_bytes + pass * (64 * kKB) + wave * 1024);
   };
-  auto dma_weights = [&](int tap, int cidx, int slot) {
+  // this lane's offset in pass i for a tile whose halo rows above / below are padding (top / bot)
+  auto pass_off = [&](int i, int top, int bot) {
+    const unsigned m = (top ? 1u : 0u) | (bot ? 256u : 0u);
+    return (GEO == GEO_ROWS && ((edge >> i) & m & 0x101u)) ? kOob : pp_off[i];
+  };
+  auto dma_weights = [&](const i32x4& rs, unsigned soff, int slot) {
     const unsigned sw = wring + slot * WSLOT + wave * 1024;
-    int off = (tap * p.KC) * (int)sizeof(T) + cidx * (int)kKB;
-    asm volatile("" : "+s"(off));
-    if constexpr (RW == 2) blds16x2(rs_wgt, w_off[0], w_off[1], (unsigned)off, sw);
-    else blds16x4(rs_wgt, w_off[0], w_off[1], w_off[2], w_off[3], (unsigned)off, sw);
+    if constexpr (RW == 2) blds16x2(rs, w_off[0], w_off[1], soff, sw);
+    else blds16x4(rs, w_off[0], w_off[1], w_off[2], w_off[3], soff, sw);
   };
 
   // ---- per-lane fragment addressing ------------------------------------------------
@@ -236,234 +275,291 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   for (int kk = 0; kk < 2; ++kk) b_off[kk] = (wn * (BN / 4) + frow) * kKB + (((kk * 4 + fk) ^ (frow & 7)) << 4);
 
   f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // item = (nt, mt), nt-major: the items of a workgroup share their channel tile wherever ipw divides tiles_m
+  int cur_nt = item_begin / q.tiles_m, cur_mt = item_begin - cur_nt * q.tiles_m;
+  int pb = 0;                               // patch buffer of the current chunk
+  int rd = 0, wr = D % NBW;                 // weight ring slots
   // ---- prologue: patch of chunk 0, D weight tiles; everything older than weight tile 1 landed ----
+  unsigned cur_soff;
+  int cur_top, cur_bot;
+  tile_origin(cur_mt, cur_soff, cur_top, cur_bot);
 #pragma unroll
-  for (int i = 0; i < NPASS; ++i) dma_patch_pass(i, pp_off[i], 0);
+  for (int i = 0; i < NPASS; ++i) dma_patch_pass(rs_src, i, pass_off(i, cur_top, cur_bot), cur_soff, 0);
 #pragma unroll
-  for (int s = 0; s < D; ++s) dma_weights(s, 0, s);   // (D < 9: all in chunk 0)
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RW * (D - 1)) : "memory");
+  for (int s = 0; s < D; ++s) dma_weights(rs_wgt, (unsigned)cur_nt * wtile_bytes + (unsigned)s * tap_bytes, s);   // (D < 9: all in chunk 0)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RW * (D - 1)) : "memory");   // (lgkmcnt: the vectors above)
   if (grp == 1) asm volatile("s_barrier" ::: "memory");
 
-  int rd = 0, wr = D;                       // weight ring slots
-  // One channel chunk = nine K-tiles (taps), unrolled: the tap's row shift, the patch pass that rides on it and the
-  // counted wait are compile-time.  DMA instructions a wave issues in L_t: one patch pass of the NEXT chunk on taps
-  // 0 .. NPASS-1 (not in the last chunk) + RW for weight tile t+D (not on the last D K-tiles of the last chunk).
-  auto chunk_body = [&](int cidx, auto last_tag) {
-    constexpr bool LAST = decltype(last_tag)::value;
-    const unsigned char* patch = smem + (cidx & 1) * patch_bytes;
-    static_for<9>([&](auto tap_tag) {
-      constexpr int tap = decltype(tap_tag)::value;
-      // ---- L_t ----
-      if (!LAST && tap < NPASS) dma_patch_pass(tap, pp_off[tap < NPASS ? tap : 0], cidx + 1);
-      if (!LAST || tap + D < 9) dma_weights((tap + D) % 9, cidx + (tap + D) / 9, wr);
-      wr = wr + 1 == NBW ? 0 : wr + 1;
-      // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
-      const int kh = tap / 3, kw = tap % 3;
-      const int pitch = GEO == GEO_STACK ? 8 : q.PW;
-      int sh = (DGRAD ? ((2 - kh) * pitch + (2 - kw)) : (kh * pitch + kw)) * kKB;   // bytes
-      // (opaque to the optimiser: otherwise the 7 x 9 fragment addresses, invariant across chunks, are hoisted out
-      // of the chunk loop and 63 live registers spill the accumulators)
-      asm volatile("" : "+s"(sh));
-      const unsigned char* pa = patch + sh;
-      const unsigned char* pw = smem + 2 * patch_bytes + rd * WSLOT;
-      rd = rd + 1 == NBW ? 0 : rd + 1;
-      uint4 fw[2][TN], fa[2][TM];
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
-        fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
-      }
-      {
-        const int rowb = a_lane + sh;
-        const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0 + j * (16 * kKB));
-          fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64) + j * (16 * kKB));
-        }
-      }
-      // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
-      // L_{t+2-D} .. L_t (vmcnt retires in issue order; at a chunk boundary this also covers the next patch, whose
-      // last pass was issued on tap NPASS-1 < 9-D, i.e. before weight tile t+1 of tap 8).
-      constexpr int allowed = issued_in<NPASS, RW, D>(tap, LAST) + (D == 3 ? issued_in<NPASS, RW, D>(tap - 1, LAST) : 0);
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(allowed) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- C_t ----
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[kk][i], fa[kk][j]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_barrier" ::: "memory");
-    });
-  };
-  for (int cidx = 0; cidx + 1 < q.nchunks; ++cidx) chunk_body(cidx, std::false_type{});
-  chunk_body(q.nchunks - 1, std::true_type{});
-  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (group 1's last MFMA segment)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all reads done before the epilogue reuses LDS
-
-  // ---- epilogue: straight from the accumulators ------------------------------------------------
-  // a lane's two 16x16 tiles (i = 2*pi, 2*pi+1) hold EIGHT consecutive channels c0 .. c0+7 of one pixel,
-  // c0 = wave's first channel + pi*32 + fk*8: one 16-byte (bf16) access per lane and operand.
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
-  const bool bwd_stats = p.bn_y[0] != nullptr;
-  const bool want_stats = p.stats_partial != nullptr || bwd_stats;
-  float* red = reinterpret_cast<float*>(smem);   // [2][BN][3] per-wave-row sums (the ring is dead: barrier above)
-  int drow[TM];       // destination row (dense pixel index) of this lane's pixels, -1: none
+  const bool bwd_stats = DGRAD && p.bn_y[0] != nullptr;
+  const bool want_stats = DGRAD ? bwd_stats : p.stats_partial != nullptr;
+
+  for (int it = item_begin; it < item_end; ++it) {
+    const bool nlive = PERSIST && it + 1 < item_end;
+    const int nit = nlive ? it + 1 : item_begin;
+    const int nxt_nt = nit / q.tiles_m, nxt_mt = nit - nxt_nt * q.tiles_m;
+    unsigned nxt_soff;
+    int nxt_top, nxt_bot;
+    tile_origin(nxt_mt, nxt_soff, nxt_top, nxt_bot);
+    // (zeroed here, not where the epilogue consumes them: the accumulators are dead across the epilogue's operand loads)
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = wm * (TM * 16) + j * 16 + frow;
-    drow[j] = -1;
-    if constexpr (GEO == GEO_ROWS) {
-      const unsigned r = fdiv((unsigned)m, q.div_pw);
-      const unsigned c = (unsigned)m - r * (unsigned)q.PW;
-      if ((int)r < q.R && (int)c < q.W && img0 < q.batch) drow[j] = (img0 * q.H + row0 + (int)r) * q.W + (int)c;
-    } else {
-      const int r = (m >> 3) & 7, c = m & 7, img = img0 + (m >> 6);
-      if (r < 7 && c < 7 && img < q.batch) {
-        if (q.quad == 2) drow[j] = ((img >> 2) * 14 + ((img >> 1) & 1) * 7 + r) * 14 + (img & 1) * 7 + c;
-        else drow[j] = (img * 7 + r) * 7 + c;
-      }
-    }
-  }
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-  for (int pi = 0; pi < NP; ++pi) {
-    const int cl = wn * (BN / 4) + pi * 32 + fk * 8;   // channel inside the tile
-    const int c0 = n0 + cl;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sc[e] = p.scale ? p.scale[c0 + e] : 1.f;
-      sh[e] = p.shift ? p.shift[c0 + e] : 0.f;
-    }
-    float mu0[8], is0[8], mu1[8], is1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      mu0[e] = bwd_stats ? p.bn_mean[0][c0 + e] : 0.f;
-      is0[e] = bwd_stats ? p.bn_invstd[0][c0 + e] : 0.f;
-      mu1[e] = p.bn_y[1] ? p.bn_mean[1][c0 + e] : 0.f;
-      is1[e] = p.bn_y[1] ? p.bn_invstd[1][c0 + e] : 0.f;
-    }
-    float s1[8], s2[8], s3[8];  // forward: sum v, sum v^2;  backward: sum g, sum g*xhat0, sum g*xhat1
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
-    // pixel tiles in batches: the batch's memory operands are requested before its first row is finished
-    constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? 2 : 4) : 1;   // (BN == 256: 112 accumulator registers are live)
-#pragma unroll
-    for (int jb = 0; jb < TM; jb += JB) {
-      __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of later batches from being hoisted over this one)
-      Raw8<T> rres[JB], rmsk[JB], ry0[JB], ry1[JB];
-      bool ok[JB];
-#pragma unroll
-      for (int u = 0; u < JB; ++u) {
-        ok[u] = jb + u < TM && drow[jb + u < TM ? jb + u : 0] >= 0;
-        if (ok[u]) {
-          const long long off = (long long)drow[jb + u] * p.N + c0;
-          if (res) rres[u].load(res + off);
-          if (msk) rmsk[u].load(msk + off);
-          if (bwd_stats) ry0[u].load(static_cast<const T*>(p.bn_y[0]) + off);
-          if (p.bn_y[1]) ry1[u].load(static_cast<const T*>(p.bn_y[1]) + off);
+      for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cidx = 0; cidx < q.nchunks; ++cidx) {
+      const bool lastc = cidx + 1 == q.nchunks;
+      // what follows this chunk in the K-tile stream: the next chunk of the item, or chunk 0 of the next item (a slot
+      // with nothing to fetch writes zeros into a dead buffer: out-of-range offsets / a zero-record resource, so that
+      // the counted waits below are compile-time constants)
+      unsigned n_psoff = lastc ? (nlive ? nxt_soff : 0u) : cur_soff + (unsigned)(cidx + 1) * kKB;
+      const int n_top = lastc ? nxt_top : cur_top, n_bot = lastc ? nxt_bot : cur_bot;
+      i32x4 rs_src_n = rs_src;
+      rs_src_n.z = __builtin_amdgcn_readfirstlane((lastc && !nlive) ? 0 : rs_src.z);
+      unsigned n_woff = lastc ? (nlive ? (unsigned)nxt_nt * wtile_bytes : 0u) : (unsigned)cur_nt * wtile_bytes + (unsigned)(cidx + 1) * kKB;
+      unsigned c_woff = (unsigned)cur_nt * wtile_bytes + (unsigned)cidx * kKB;
+      asm volatile("" : "+s"(n_psoff), "+s"(n_woff), "+s"(c_woff));   // (opaque: per-chunk address arithmetic stays out of the loop invariants)
+      i32x4 rs_wgt_n = rs_wgt;
+      rs_wgt_n.z = __builtin_amdgcn_readfirstlane((lastc && !nlive) ? 0 : rs_wgt.z);
+      // the stores of an epilogue sit in the vmcnt queue between the DMA of the item before and after it; everything the
+      // first D-1 K-tiles of an item need was waited for in front of that epilogue (below)
+      const bool after_epilogue = cidx == 0 && it != item_begin;
+      const unsigned char* patch = smem + pb * patch_bytes;
+      static_for<9>([&](auto tap_tag) {
+        constexpr int tap = decltype(tap_tag)::value;
+        // ---- L_t ----
+        if constexpr (tap < NPASS) dma_patch_pass(rs_src_n, tap, pass_off(tap < NPASS ? tap : 0, n_top, n_bot), n_psoff, pb ^ 1);
+        {
+          constexpr int u = (tap + D) % 9;
+          constexpr bool wrap = tap + D >= 9;
+          dma_weights(wrap ? rs_wgt_n : rs_wgt, (wrap ? n_woff : c_woff) + (unsigned)u * tap_bytes, wr);
         }
-      }
+        wr = wr + 1 == NBW ? 0 : wr + 1;
+        // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
+        const int kh = tap / 3, kw = tap % 3;
+        const int pitch = GEO == GEO_STACK ? 8 : q.PW;
+        int sh = (DGRAD ? ((2 - kh) * pitch + (2 - kw)) : (kh * pitch + kw)) * kKB;   // bytes
+        // (opaque to the optimiser: otherwise the 7 x 9 fragment addresses, invariant across chunks, are hoisted out
+        // of the chunk loop and 63 live registers spill the accumulators)
+        asm volatile("" : "+s"(sh));
+        const unsigned char* pa = patch + sh;
+        const unsigned char* pw = smem + 2 * patch_bytes + rd * WSLOT;
+        rd = rd + 1 == NBW ? 0 : rd + 1;
+        uint4 fw[2][TN], fa[2][TM];
 #pragma unroll
-      for (int u = 0; u < JB; ++u) {
-        if (jb + u >= TM) continue;
-        const int j = jb + u;
-        float v[8] = {acc[2 * pi][j][0],     acc[2 * pi][j][1],     acc[2 * pi][j][2],     acc[2 * pi][j][3],
-                      acc[2 * pi + 1][j][0], acc[2 * pi + 1][j][1], acc[2 * pi + 1][j][2], acc[2 * pi + 1][j][3]};
-        if (!ok[u]) continue;
-        const long long off = (long long)drow[j] * p.N + c0;
-        if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
+        for (int i = 0; i < TN; ++i) {
+          fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
+          fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
+        }
+        {
+          const int rowb = a_lane + sh;
+          const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * v[e];
+          for (int j = 0; j < TM; ++j) {
+            fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0 + j * (16 * kKB));
+            fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64) + j * (16 * kKB));
           }
         }
-if (p.scale || p.shift) {  // (uniform)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
+        // L_{t+2-D} .. L_t (vmcnt retires in issue order; at a chunk boundary this also covers the next patch, whose
+        // last pass was issued on tap NPASS-1 < 9-D, i.e. before weight tile t+1 of tap 8).
+        constexpr int in_t = (tap < NPASS ? 1 : 0) + RW;
+        constexpr int in_tm1 = ((tap + 8) % 9 < NPASS ? 1 : 0) + RW;
+        constexpr int allowed = in_t + (D == 3 ? in_tm1 : 0);
+        if (tap < D - 1 && after_epilogue) {   // (uniform)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(allowed) : "memory");
         }
-        if (res) {
-          float rv[8];
-          rres[u].get(rv);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C_t ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (p.relu) {
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (msk) {
-          float mv[8];
-          rmsk[u].get(mv);
+          for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-        }
-        QtVec8<T>::store(dst + off, v);
-        if (bwd_stats) {
-          float yv[8];
-          ry0[u].get(yv);
+            for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[kk][i], fa[kk][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+      });
+      pb ^= 1;
+    }
+
+    // ---- epilogue: straight from the accumulators, no LDS scratch (the next item's DMA is in flight) -----------
+    // Everything the next item's first D-1 K-tiles need (its patch, weight tiles 0 .. D-1: all issued at least a
+    // segment ago) is waited for here, in front of the stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int mt = cur_mt, n0 = cur_nt * BN;
+    const int img0 = GEO == GEO_ROWS ? mt / q.tpi : mt * 4;
+    const int row0 = GEO == GEO_ROWS ? (mt - img0 * q.tpi) * q.R : 0;
+    // a lane's two 16x16 tiles (i = 2*pi, 2*pi+1) hold EIGHT consecutive channels c0 .. c0+7 of one pixel,
+    // c0 = wave's first channel + pi*32 + fk*8: one 16-byte (bf16) access per lane and operand.
+    int drow[TM];       // destination row (dense pixel index) of this lane's pixels, -1: none
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
-          }
-          if (p.bn_y[1]) {
-            ry1[u].get(yv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
-          }
+    for (int j = 0; j < TM; ++j) {
+      int m = wm * (TM * 16) + j * 16 + frow;
+      asm volatile("" : "+v"(m));   // (opaque: the row / column split must not be hoisted out of the item loop into spilled registers)
+      drow[j] = -1;
+      if constexpr (GEO == GEO_ROWS) {
+        const unsigned r = fdiv((unsigned)m, q.div_pw);
+        const unsigned c = (unsigned)m - r * (unsigned)q.PW;
+        if ((int)r < q.R && (int)c < q.W && img0 < q.batch) drow[j] = (img0 * q.H + row0 + (int)r) * q.W + (int)c;
+      } else {
+        const int r = (m >> 3) & 7, c = m & 7, img = img0 + (m >> 6);
+        if (r < 7 && c < 7 && img < q.batch) {
+          if (q.quad == 2) drow[j] = ((img >> 2) * 14 + ((img >> 1) & 1) * 7 + r) * 14 + (img & 1) * 7 + c;
+          else drow[j] = (img * 7 + r) * 7 + c;
         }
       }
     }
-    if (want_stats) {
-      // sum over the 16 pixels (lanes with equal fk) of the wave, fixed butterfly order -> deterministic
+    // A FORWARD launch's epilogue is scale / shift, residual, ReLU and the BatchNorm statistics; a DATA-GRADIENT launch's is
+    // residual, ReLU mask and the BatchNorm-backward links (other combinations take the generic kernel, qt_pt_eligible):
+    // each instantiation carries only its own operands in registers.
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int cl = wn * (BN / 4) + pi * 32 + fk * 8;   // channel inside the tile
+      const int c0 = n0 + cl;
+      float va[DGRAD ? 4 : 2][8];   // forward: scale, shift;  backward: mean / invstd of the two links
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int sft = 1; sft < 16; sft <<= 1) {
-          s1[e] += __shfl_xor(s1[e], sft);
-          s2[e] += __shfl_xor(s2[e], sft);
-          s3[e] += __shfl_xor(s3[e], sft);
+        if constexpr (!DGRAD) {
+          va[0][e] = AFF_LDS ? aff[c0 + e] : (p.scale ? p.scale[c0 + e] : 1.f);
+          va[1][e] = AFF_LDS ? aff[p.N + c0 + e] : (p.shift ? p.shift[c0 + e] : 0.f);
+        } else {
+          va[0][e] = AFF_LDS ? aff[2 * p.N + c0 + e] : (bwd_stats ? p.bn_mean[0][c0 + e] : 0.f);
+          va[1][e] = AFF_LDS ? aff[3 * p.N + c0 + e] : (bwd_stats ? p.bn_invstd[0][c0 + e] : 0.f);
+          va[2][e] = AFF_LDS ? aff[4 * p.N + c0 + e] : (p.bn_y[1] ? p.bn_mean[1][c0 + e] : 0.f);
+          va[3][e] = AFF_LDS ? aff[5 * p.N + c0 + e] : (p.bn_y[1] ? p.bn_invstd[1][c0 + e] : 0.f);
         }
       }
-      if (frow == 0) {
+      float s1[8], s2[8], s3[DGRAD ? 8 : 1];  // forward: sum v, sum v^2;  backward: sum g, sum g*xhat0, sum g*xhat1
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+      for (int e = 0; e < (DGRAD ? 8 : 1); ++e) s3[e] = 0.f;
+      // pixel tiles in batches: the batch's memory operands are requested before its first row is finished
+      constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? (DGRAD ? 1 : 2) : 4) : 1;   // (BN == 256: 112 accumulator registers are live)
+#pragma unroll
+      for (int jb = 0; jb < TM; jb += JB) {
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of later batches from being hoisted over this one)
+        Raw8<T> rres[JB], rmsk[DGRAD ? JB : 1], ry0[DGRAD ? JB : 1], ry1[DGRAD ? JB : 1];
+        bool ok[JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+          ok[u] = jb + u < TM && drow[jb + u < TM ? jb + u : 0] >= 0;
+          if (ok[u]) {
+            const long long off = (long long)drow[jb + u] * p.N + c0;
+            if (res) rres[u].load(res + off);
+            if constexpr (DGRAD) {
+              if (msk) rmsk[u].load(msk + off);
+              if (bwd_stats) ry0[u].load(static_cast<const T*>(p.bn_y[0]) + off);
+              if (p.bn_y[1]) ry1[u].load(static_cast<const T*>(p.bn_y[1]) + off);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+          if (jb + u >= TM) continue;
+          const int j = jb + u;
+          float v[8] = {acc[2 * pi][j][0],     acc[2 * pi][j][1],     acc[2 * pi][j][2],     acc[2 * pi][j][3],
+                        acc[2 * pi + 1][j][0], acc[2 * pi + 1][j][1], acc[2 * pi + 1][j][2], acc[2 * pi + 1][j][3]};
+          if (!ok[u]) continue;
+          const long long off = (long long)drow[j] * p.N + c0;
+          if constexpr (!DGRAD) {
+            if (p.stats_partial != nullptr) {  // (uniform: an eval forward keeps no sums)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                s1[e] += v[e];
+                s2[e] += v[e] * v[e];
+              }
+            }
+            if (p.scale || p.shift) {  // (uniform)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] * va[0][e] + va[1][e];
+            }
+          }
+          if (res) {
+            float rv[8];
+            rres[u].get(rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if constexpr (!DGRAD) {
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+          } else {
+            if (msk) {
+              float mv[8];
+              rmsk[u].get(mv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+            }
+          }
+          QtVec8<T>::store(dst + off, v);
+          if constexpr (DGRAD) {
+            if (bwd_stats) {
+              float yv[8];
+              ry0[u].get(yv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                s1[e] += v[e];
+                s2[e] += v[e] * (yv[e] - va[0][e]) * va[1][e];
+              }
+              if (p.bn_y[1]) {
+                ry1[u].get(yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - va[2][e]) * va[3][e];
+              }
+            }
+          }
+        }
+      }
+      if (want_stats) {
+        // sum over the 16 pixels (lanes with equal fk) of the wave, fixed butterfly order -> deterministic; one partial
+        // row per (pixel tile, wave row): the two wave rows are added by the finalize kernels, not here
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          red[(wm * BN + cl + e) * 3 + 0] = s1[e];
-          red[(wm * BN + cl + e) * 3 + 1] = s2[e];
-          red[(wm * BN + cl + e) * 3 + 2] = s3[e];
+#pragma unroll
+          for (int sft = 1; sft < 16; sft <<= 1) {
+            s1[e] += __shfl_xor(s1[e], sft);
+            s2[e] += __shfl_xor(s2[e], sft);
+            if constexpr (DGRAD) s3[e] += __shfl_xor(s3[e], sft);
+          }
+        }
+        if (frow == 0) {
+          float* o0 = DGRAD ? p.bn_partial[0] : p.stats_partial;
+          const long long row = (long long)mt * 2 + wm;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o0[(row * 2 + 0) * p.N + c0 + e] = s1[e];
+            o0[(row * 2 + 1) * p.N + c0 + e] = s2[e];
+          }
+          if constexpr (DGRAD) {
+            if (p.bn_y[1]) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                p.bn_partial[1][(row * 2 + 0) * p.N + c0 + e] = s1[e];
+                p.bn_partial[1][(row * 2 + 1) * p.N + c0 + e] = s3[e];
+              }
+            }
+          }
         }
       }
     }
+    cur_nt = nxt_nt;
+    cur_mt = nxt_mt;
+    cur_soff = nxt_soff; cur_top = nxt_top; cur_bot = nxt_bot;
   }
-  if (want_stats) {
-    __syncthreads();
-    if (tid < BN) {
-      const float a = red[tid * 3 + 0] + red[(BN + tid) * 3 + 0];   // fixed order over the two wave rows
-      const float b = red[tid * 3 + 1] + red[(BN + tid) * 3 + 1];
-      const float c = red[tid * 3 + 2] + red[(BN + tid) * 3 + 2];
-      float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
-      o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-      o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
-      if (bwd_stats && p.bn_y[1]) {
-        p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-        p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
-      }
-    }
-  }
+  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (group 1's last MFMA segment)
+  // the branch-free slots of the last chunk wrote zeros into dead buffers: landed before the LDS changes hands
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // geometry of the 196-pixel tiles for an H x W image; false: shape not covered
@@ -492,16 +588,35 @@ inline int pt_tiles_m(const PtArgs& q, int batch) { return q.G == 1 ? batch * q.
 // 256-channel tiles where the channel count allows it and 256 pixel tiles still cover the chip (14x14: one per image)
 inline int pt_bn(const ConvArgs& a) { return (a.N % 256 == 0 && a.OH == 14) ? 256 : 128; }
 
+// persistent grid: one workgroup per CU (qt_set_pt_conv_max_workgroups caps it: tests walk several items per workgroup
+// at small batches; QTCNN_PT_PERSIST=0: one item per workgroup as in round 2, same-box A/B)
+int g_pt_max_wgs_fwd = 0;
+inline int pt_workgroups() {
+  static int persist = -1;
+  if (persist < 0) {
+    const char* e = getenv("QTCNN_PT_PERSIST");
+    persist = e ? atoi(e) : 1;
+  }
+  if (g_pt_max_wgs_fwd > 0) return g_pt_max_wgs_fwd;
+  if (!persist) return 1 << 30;
+  int dev = 0, cus = 256, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    cus = v;
+  return cus;
+}
+
 template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD>
 int launch(PtArgs q, hipStream_t stream) {
-  constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB;
+  constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB + (BN == 128 ? 6 * 512 * 4 : 0);   // (+ the epilogue's vectors)
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_pt_kernel<T, BN, NBW, NPASS, GEO, DGRAD>;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
   if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
   q.c.gridN = q.c.N / BN;
   q.c.gridM = q.tiles_m;
-  hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.c.gridN), dim3(kNT), lds, stream, q);
+  q.items = q.tiles_m * q.c.gridN;
+  q.ipw = BN == 128 ? qt_cdiv(q.items, pt_workgroups()) : 1;
+  hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
@@ -533,6 +648,7 @@ inline int pt_enabled() {
 }  // namespace
 
 extern "C" void qt_set_pt_conv(int mode) { g_pt_enabled = mode < 0 ? 1 : mode; }
+extern "C" void qt_set_pt_conv_max_workgroups(int n) { g_pt_max_wgs_fwd = n > 0 ? n : 0; }
 
 // images the kernel walks (quadrant modes: four 7x7 region images per map) and the quadrant mode, -1: not covered
 static int pt_images(const ConvArgs& a, bool dgrad, int* quad) {
@@ -552,6 +668,11 @@ bool qt_pt_eligible(const ConvArgs& a, int dtype, bool dgrad) {
   if (!pt_enabled()) return false;
   const int esz = dtype == QT_F32 ? 4 : 2;
   if (a.ntaps != 9 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.dst_sub) return false;
+  // epilogue operands each instantiation carries (the generic kernel takes every combination): forward = scale / shift,
+  // residual, ReLU, statistics; data gradient = residual, ReLU mask, BatchNorm-backward links
+  if (!dgrad && (a.bn_y[0] || a.relu_mask)) return false;
+  if (dgrad && (a.scale || a.shift || a.stats_partial || a.relu)) return false;
+  if (a.N > 512) return false;   // (per-channel vectors of the epilogue in LDS)
   int quad;
   const int batch = pt_images(a, dgrad, &quad);
   if (batch < 0) return false;
@@ -569,7 +690,7 @@ int qt_pt_stats_rows(const ConvArgs& a, bool dgrad) {
   PtArgs q;
   int quad;
   pt_geometry(a.IH, a.IW, q);
-  return pt_tiles_m(q, pt_images(a, dgrad, &quad));
+  return 2 * pt_tiles_m(q, pt_images(a, dgrad, &quad));   // one partial row per (pixel tile, wave row)
 }
 
 int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
@@ -582,8 +703,9 @@ int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
   q.nchunks = a.KC * esz / kKB;
   const long long simgs = q.quad == 1 ? q.batch / 4 : q.batch;
   const int sh = q.quad == 1 ? 14 : a.IH, sw = q.quad == 1 ? 14 : a.IW;
+  // (the range check covers vector + scalar offset; row geometry: the base sits one image row above the tensor)
   q.src_bytes = (unsigned)(((simgs - 1) * a.src_img_stride + ((long long)sh - 1) * a.src_row_stride +
-                            ((long long)sw - 1) * a.src_pix_stride + a.KC) * esz);
+                            ((long long)sw - 1) * a.src_pix_stride + a.KC + (q.G == 1 ? a.src_row_stride : 0)) * esz);
   q.wgt_bytes = (unsigned)((long long)a.N * 9 * a.KC * esz);
   if (dtype == QT_F32) return dgrad ? dispatch<float, true>(q, stream) : dispatch<float, false>(q, stream);
   return dgrad ? dispatch<bf16_t, true>(q, stream) : dispatch<bf16_t, false>(q, stream);

@@ -214,12 +214,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
   for (int kk = 0; kk < 2; ++kk) b_off[kk] = (wn * (BN / 4) + frow) * kKB + (((kk * 4 + fk) ^ (frow & 7)) << 4);
 
   f32x4 acc[2][TN][TM];   // [0] conv1, [1] downsample
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[s][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const unsigned plane_delta[4] = {
       (unsigned)((kPh[0] * q.src_row_stride + kPw[0] * q.src_pix_stride) * ESZ),
@@ -249,6 +243,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
 
   for (int it = item_begin; it < item_end; ++it) {
     const Item nxt_item = make_item(it + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[s][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int cidx = 0; cidx < q.nchunks; ++cidx) {
       // (item, chunk) that follows this chunk in the K-tile stream
       const bool lastc = cidx + 1 == q.nchunks;
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
       int drow[TM];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        const int m = wm * (TM * 16) + j * 16 + frow;
+        int m = wm * (TM * 16) + j * 16 + frow;
+        asm volatile("" : "+v"(m));   // (opaque: the row / column split must not be hoisted out of the item loop into spilled registers)
         drow[j] = -1;
         if constexpr (GEO == GEO_ROWS) {
           const unsigned r = fdiv((unsigned)m, q.div_pw);
@@ -386,8 +387,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
         for (int j = 0; j < TM; ++j) {
           float v[8] = {acc[s][0][j][0], acc[s][0][j][1], acc[s][0][j][2], acc[s][0][j][3],
                         acc[s][1][j][0], acc[s][1][j][1], acc[s][1][j][2], acc[s][1][j][3]};
-          acc[s][0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          acc[s][1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (drow[j] < 0) continue;
           if (o.stats != nullptr) {   // (uniform)
 #pragma unroll

@@ -87,6 +87,45 @@ __global__ __launch_bounds__(256) void gemm_small_wave_kernel(SmallArgs a) {
   }
 }
 
+// one wave per output element, K contiguous in both operands and a multiple of 8: every lane requests all its 8-element
+// pieces (16 B of bf16 / 32 B of f32) before the first multiply -- classifier.3's forward (K = 2688: 22 us as 42 trips of
+// two scalar loads per lane, one memory latency per group of four) is then ONE latency
+template <bool A16, bool B16>
+__global__ __launch_bounds__(256) void gemm_small_wave_vec_kernel(SmallArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)a.M * a.N;
+  const int nchunk = a.K >> 3;
+  for (long long i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < total; i += (long long)gridDim.x * 4) {
+    const int n = (int)(i % a.N), m = (int)(i / a.N);
+    const long long ab = (long long)m * a.ars, bb = (long long)n * a.brs;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < nchunk; c0 += 64 * 4) {
+      float av[4][8], bv[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 64 + lane;
+        const bool in = c < nchunk;
+        const long long ka = ab + (long long)(in ? c : 0) * 8, kb = bb + (long long)(in ? c : 0) * 8;
+        if constexpr (A16) QtVec8<bf16_t>::load(static_cast<const bf16_t*>(a.A) + ka, av[u]);
+        else QtVec8<float>::load(static_cast<const float*>(a.A) + ka, av[u]);
+        if constexpr (B16) QtVec8<bf16_t>::load(static_cast<const bf16_t*>(a.B) + kb, bv[u]);
+        else QtVec8<float>::load(static_cast<const float*>(a.B) + kb, bv[u]);
+        if (!in) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) av[u][e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += av[u][e] * bv[u][e];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) finish(a, m, n, acc);
+  }
+}
+
 }  // namespace
 
 extern "C" int qt_gemm_small(const qt_gemm_small_desc* d, const void* A, const void* B, const float* bias, void* C,
@@ -108,7 +147,14 @@ extern "C" int qt_gemm_small(const qt_gemm_small_desc* d, const void* A, const v
     hipLaunchKernelGGL(gemm_small_thread_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, a);
   } else {
     long long g = (total + 3) / 4;
-    hipLaunchKernelGGL(gemm_small_wave_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(g > 16384 ? 16384 : g));
+    const int ea = a.a_bf16 ? 2 : 4, eb = a.b_bf16 ? 2 : 4;
+    const bool vec = a.aks == 1 && a.bks == 1 && d->K % 8 == 0 && a.ars % 8 == 0 && a.brs % 8 == 0 &&
+                     ((uintptr_t)A % (8 * ea)) == 0 && ((uintptr_t)B % (8 * eb)) == 0 && !(a.a_bf16 == 0 && a.b_bf16 == 1);
+    if (vec && a.a_bf16 && a.b_bf16) hipLaunchKernelGGL((gemm_small_wave_vec_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else if (vec && a.a_bf16) hipLaunchKernelGGL((gemm_small_wave_vec_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else if (vec) hipLaunchKernelGGL((gemm_small_wave_vec_kernel<false, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_small_wave_kernel, grid, dim3(256), 0, s, a);
   }
   QT_CHECK_LAUNCH();
   return QT_OK;

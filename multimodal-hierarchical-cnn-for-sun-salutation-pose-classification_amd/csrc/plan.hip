@@ -872,6 +872,14 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
     e.run(qt_gemm_small(&g, numerical, e.tf(p->mlp0.w), e.tf(p->mlp0.b), z, e.stream));
     if (tr && p->d.dropout_p > 0.f) e.run(qt_dropout(dt, z, batch, p->mlp0.out, p->fused_ld, seed, p->d.dropout_p, e.stream));
   };
+  // The numerical MLP needs nothing of the image branch: its thin kernels go to the side stream FIRST, next to the
+  // stem's byte-moving kernels.  (Until round 3 they were forked behind layer3 and their workgroups trickled onto CUs
+  // that layer4's whole-CU convolutions released: 58 + 90 us on the side queue, layer4's convs 67 -> 88-100 us.)
+  const bool mlp_early = p->has_image && p->has_numerical && !p->attention && !p->lstm && !p->standard;
+  if (mlp_early) {
+    e.fork();
+    e.on_side(p->stats_ds, [&] { mlp_branch(); });
+  }
   if (p->has_image) {
     if (!tr) e.eval_affines(unf);
     // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
@@ -964,7 +972,7 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
             attn_branch();
           } else {
             quad_branch();
-            if (p->has_numerical) mlp_branch();
+            if (p->has_numerical && !mlp_early) mlp_branch();
           }
         });
       }

@@ -43,6 +43,21 @@ def tiles(B, H):
     return {28: 4 * B, 14: B, 7: (B + 3) // 4}[H]
 
 
+class _maxwg:
+    """with _maxwg(L, n): caps the persistent grid at n workgroups (0 = one per CU): small batches then walk SEVERAL items
+    per workgroup -- the K-tile stream crosses item boundaries, the epilogue runs between two K-tiles, the branch-free
+    DMA slots behind the last item go through out-of-range offsets / a zero-record resource."""
+
+    def __init__(self, L, n):
+        self.lib, self.n = L.lib(), n
+
+    def __enter__(self):
+        self.lib.qt_set_pt_conv_max_workgroups(self.n)
+
+    def __exit__(self, *exc):
+        self.lib.qt_set_pt_conv_max_workgroups(0)
+
+
 FWD_CASES = [
     # B, Cin, Cout, H        pixel tiles            what it covers
     (18, 128, 128, 28),    # 72    layer2 shape: quarter-image tiles, halo rows are real pixels of the same image
@@ -75,8 +90,8 @@ def test_pt_forward_all_epilogues(dt, cfg):
     for on in (True, False):
         with _pt(L, on):
             y0, st = run_conv(L, dt, xd, wd, B, (H, H), (H, H), Cin, Cout, k, k, 1, p, L.QT_CONV_FWD, want_stats=True)
-            if on:   # the statistics rows follow the kernel choice: one row per 196-pixel tile
-                assert st.shape[0] == tiles(B, H)
+            if on:   # the statistics rows follow the kernel choice: one row per 196-pixel tile and wave row
+                assert st.shape[0] == 2 * tiles(B, H)
             y1, _ = run_conv(L, dt, xd, wd, B, (H, H), (H, H), Cin, Cout, k, k, 1, p, L.QT_CONV_FWD, relu=1,
                              scale=scale.to(dev), shift=shift.to(dev), residual=resd)
         out[on] = (y0, st.sum(0), y1)
@@ -194,6 +209,59 @@ def test_pt_quadrant_conv_forward_and_data_gradient(dt):
     assert rel_err(ys[True].float().cpu(), ys[False].float().cpu()) <= TOL[dt]
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(18, 128, 128, 28, 7), (17, 64, 128, 28, 5), (20, 128, 256, 28, 16), (22, 512, 256, 7, 3),
+                                 (16, 128, 128, 14, 4)])
+def test_pt_persistent_walk_over_several_items(dt, cfg):
+    """Several (channel tile, pixel tile) items per workgroup (the benchmark's 28x28 stage walks four): forward with
+    statistics + scale / shift / residual / ReLU and the data gradient with residual, mask and two BatchNorm links
+    against torch and against the same launch with one item per workgroup -- bit for bit (the walk changes no sum)."""
+    dev = _dev()
+    L = pkg("_lib")
+    B, Cin, Cout, H, maxwg = cfg
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dt).float()
+    res = torch.randn(B, Cout, H, H, generator=g).to(dt).float()
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    raw = F.conv2d(x, w, None, 1, 1)
+    ref = F.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    xd, wd = nhwc(x).to(dev, dt), w.permute(0, 2, 3, 1).contiguous().to(dev, dt)
+    resd = nhwc(res).to(dev, dt).view(-1, Cout)
+    outs = {}
+    for n in (maxwg, 1 << 20):
+        with _maxwg(L, n):
+            y0, st = run_conv(L, dt, xd, wd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1, L.QT_CONV_FWD, want_stats=True)
+            y1, _ = run_conv(L, dt, xd, wd, B, (H, H), (H, H), Cin, Cout, 3, 3, 1, 1, L.QT_CONV_FWD, relu=1,
+                             scale=scale.to(dev), shift=shift.to(dev), residual=resd)
+        outs[n] = (y0, st, y1)
+    a, b = outs[maxwg], outs[1 << 20]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    got = a[0].float().cpu().view(B, H, H, Cout).permute(0, 3, 1, 2)
+    assert rel_err(got, raw) <= TOL[dt]
+    got = a[2].float().cpu().view(B, H, H, Cout).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) <= TOL[dt]
+    assert rel_err(a[1].sum(0)[0].cpu(), raw.sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    assert rel_err(a[1].sum(0)[1].cpu(), (raw * raw).sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    # data gradient: y [B,Cout,H,H] -> dx [B,Cin,H,H]
+    dy = torch.randn(B, Cout, H, H, generator=g).to(dt).float()
+    other, act = torch.randn(B, Cin, H, H, generator=g).to(dt).float(), torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    if Cin % 128:
+        return   # (a 64-channel data gradient takes the generic kernel)
+    dxr = (torch.nn.grad.conv2d_input((B, Cin, H, H), w, dy, 1, 1) + other) * (act > 0)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dev, dt)
+    dyd = nhwc(dy).to(dev, dt)
+    od, ad = nhwc(other).to(dev, dt).view(-1, Cin), nhwc(act).to(dev, dt).view(-1, Cin)
+    douts = {}
+    for n in (maxwg, 1 << 20):
+        with _maxwg(L, n):
+            douts[n], _ = run_conv(L, dt, dyd, wt, B, (H, H), (H, H), Cout, Cin, 3, 3, 1, 1, L.QT_CONV_DGRAD, residual=od,
+                                   relu_mask=ad)
+    assert torch.equal(douts[maxwg], douts[1 << 20])
+    assert rel_err(douts[maxwg].float().cpu().view(B, H, H, Cin).permute(0, 3, 1, 2), dxr) <= TOL[dt]
+
+
 def test_pt_full_benchmark_batch_matches_generic_kernel():
     """B = 256, bf16, the three stage shapes of the benchmark: every CU holds a tile (1024 / 512 / 256 workgroups);
     forward with statistics and the data gradient with mask + residual against the generic kernel."""
@@ -222,7 +290,7 @@ def test_pt_full_benchmark_batch_matches_generic_kernel():
 
 
 def test_pt_is_chosen_exactly_where_it_is_eligible():
-    """qt_conv2d_stats_rows mirrors the dispatch: one row per 196-pixel tile exactly where the kernel is eligible."""
+    """qt_conv2d_stats_rows mirrors the dispatch: two rows per 196-pixel tile exactly where the kernel is eligible."""
     _dev()
     L = pkg("_lib")
 
@@ -234,14 +302,15 @@ def test_pt_is_chosen_exactly_where_it_is_eligible():
         d.kh = d.kw = k; d.stride = stride; d.pad = k // 2; d.quad = quad
         return L.lib().qt_conv2d_stats_rows(ctypes.byref(d))
     L.lib().qt_set_pt_conv(-1)
-    assert rows(256, 28, 128, 128) == 1024                           # layer2: quarter images
-    assert rows(256, 14, 256, 256) == 256                            # layer3: images
-    assert rows(256, 7, 512, 512) == 64                              # layer4: four images
-    assert rows(30, 7, 512, 512) == 8                                # ragged: 7 full tiles + 2 images
+    # (two partial rows per tile: one per wave row, no cross-wave reduction in the kernel)
+    assert rows(256, 28, 128, 128) == 2 * 1024                       # layer2: quarter images
+    assert rows(256, 14, 256, 256) == 2 * 256                        # layer3: images
+    assert rows(256, 7, 512, 512) == 2 * 64                          # layer4: four images
+    assert rows(30, 7, 512, 512) == 2 * 8                            # ragged: 7 full tiles + 2 images
     assert rows(4, 28, 128, 128) == (4 * 784 + 127) // 128           # few images: generic 128-pixel tiles
     assert rows(256, 28, 64, 128, k=1, stride=2) == (256 * 196 + 127) // 128   # 1x1 stride 2: generic
     assert rows(256, 28, 128, 64) == (256 * 784 + 127) // 128        # 64 output channels: generic
-    assert rows(64, 7, 256, 128, quad=1) == 64                       # quadrant mode: the four quadrants of a map per tile
+    assert rows(64, 7, 256, 128, quad=1) == 2 * 64                   # quadrant mode: the four quadrants of a map per tile
     assert rows(3, 7, 256, 128, quad=1) == (3 * 4 * 49 + 127) // 128 # 12 region images: generic
     L.lib().qt_set_pt_conv(0)
     assert rows(256, 14, 256, 256) == 392
