@@ -185,6 +185,10 @@ int main() {
   run_k("PIPELINED ping-pong (L = DMA only): 28 MFMA, 18 reads, 3 DMA", kern_pipe<28, 18, 3, true>, src, out, sink);
   run_k("PIPELINED ping-pong (L = DMA only): 28 MFMA, 18 reads, 4 DMA", kern_pipe<28, 18, 4, true>, src, out, sink);
   run_k("PIPELINED lockstep: 28 MFMA, 18 reads, 0 DMA", kern_pipe<28, 18, 0, false>, src, out, sink);
+  run<48, 36, 1, true>("layer1 re-cut: 3 taps per segment: 48 MFMA, 36 reads, 1 DMA", src, out, sink);
+  run<48, 36, 2, true>("layer1 re-cut: 3 taps per segment: 48 MFMA, 36 reads, 2 DMA", src, out, sink);
+  run<32, 24, 1, true>("layer1 re-cut: 2 taps per segment: 32 MFMA, 24 reads, 1 DMA", src, out, sink);
+  run<48, 36, 0, false>("lockstep 48 MFMA, 36 reads (today's ring kernel, 3 taps at a time)", src, out, sink);
   run<0, 18, 0, true>("reads only", src, out, sink);
   run<0, 0, 4, true>("DMA only", src, out, sink);
   return 0;
