@@ -120,11 +120,6 @@ typedef struct qt_conv_io {
  * one-tile-per-workgroup kernel is experimental), 2 (default) only the persistent sliding-ring
  * kernel for the 56x56 64->64 bf16 layers. */
 void qt_set_patch_conv(int mode);
-/* The persistent layer1 kernel (56x56, 64 -> 64 channels, bf16) exists in two cuts with bit-identical results: the
- * round-1 ring kernel (all eight waves in lockstep) and, from round 3, its ping-pong re-cut (two wave groups one barrier
- * apart, three / two taps per segment, epilogue inside a load segment).  1 (default) ping-pong, 0 ring kernel
- * (QTCNN_L1_PP; same-box A/B and the bit-identity test). */
-void qt_set_l1_pingpong(int mode);
 /* 3x3 / stride 1 / pad 1 convolutions on dense 28x28, 14x14 and 7x7 maps with >= 16 images and a multiple of 128 output
  * channels (the twelve such convs of layer2..4, forward and data gradient) take the patch-resident ping-pong kernel
  * (csrc/conv_pt.hip: 196-pixel tiles of whole image rows, input patch + halo of a 128-byte channel chunk in LDS for all

@@ -679,313 +679,19 @@ if (p.scale || p.shift) {  // (uniform)
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Round 3: the same persistent layer1 kernel re-cut on the PING-PONG schedule of conv_pt.hip.
-// In the ring kernel above a tile is one phase after another for all eight waves: per tap and K half a wave reads 6
-// fragments and issues 8 MFMAs, both SIMD partners at the same time (micro-benchmark scripts/ubench/pingpong.hip: 2820
-// cycles per three taps in lockstep against 1617 with the two wave groups one barrier apart, MFMA floor 1536).
-// Here waves 0-3 (channels 0-31) and 4-7 (channels 32-63) alternate: one group reads the fragments of the next
-// SEGMENT (TPS = 3 taps: 36 reads; 2 taps where the epilogue's operands need the registers) and -- in the first segment
-// of a tile -- runs the EPILOGUE of the tile before, issues the window fetch of the tile after and requests this
-// tile's epilogue operands, while the other group issues the 48 (32) MFMAs of its segment.  Same LDS image (filter 72 KB,
-// 640-row sliding ring + 48-row mirror), same tile walk, same arithmetic and summation order per output element as the
-// ring kernel (taps in order, K halves in order): results are bit-identical to it.
-//   RAW  window k+1: every wave waits for its own pieces (vmcnt(0)) at the end of the last L segment of tile k, before
-//        the barrier; nobody reads them before the first L segment of tile k+1, two barriers later;
-//   WAR  the fetch issued in L_0 of tile k replaces the rows of tile k-1, whose last readers (the other group's last L
-//        segment of tile k-1) ended with lgkmcnt(0) before the barrier in front of this L_0.
-// The per-channel vectors of the epilogue live in LDS behind the ring.  Operand combinations instantiated = the ones the
-// train / eval plan produces on layer1: none, residual, mask + one BatchNorm link, residual + mask + one link; anything
-// else keeps the ring kernel.
-// ---------------------------------------------------------------------------------------------
-constexpr int L1_AFF = L1_WBYTES + L1_RBYTES;            // [6][64] f32: scale, shift, mean0, invstd0, (mean1, invstd1)
-constexpr int L1PP_LDS = L1_AFF + 6 * 64 * 4;
-static_assert(L1PP_LDS <= 160 * 1024, "layer1 ping-pong kernel LDS");
-
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void l1_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    l1_static_for<N, I + 1>(f);
-  }
-}
-
-template <bool FLIP, bool RES, bool MSK, bool LINK>
-__global__ __launch_bounds__(NT, 2) void conv_l1_pp_kernel(PatchArgs p) {
-  using T = bf16_t;
-  constexpr int NOPS = (RES ? 1 : 0) + (MSK ? 1 : 0) + (LINK ? 1 : 0);
-  constexpr int TPS = NOPS >= 2 ? 2 : 3;          // taps per segment
-  constexpr int NSEG = (9 + TPS - 1) / TPS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const T* __restrict__ src = static_cast<const T*>(p.src);
-  const T* __restrict__ wgt = static_cast<const T*>(p.wgt);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;        // wn = the wave group (SIMD partners are waves w and w + 4)
-  const int grp = wn;
-  const int frow = lane & 15, fk = lane >> 4;
-  const int rbase = tid >> 3, chunk = (tid & 7) ^ (rbase & 7);
-  const unsigned smem_base = lds_addr_of(smem);
-  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
-
-  const int ntiles = p.gridM, G = gridDim.x, b = blockIdx.x;
-  const int t0 = (int)((long long)b * ntiles / G), t1 = (int)((long long)(b + 1) * ntiles / G);
-  const int nt = t1 - t0;
-  if (nt <= 0) return;
-  const long long qstart = (long long)t0 * BM - (L1_PW + 1);   // padded position of ring index u = 0
-
-  auto dma_ring = [&](int ub) {   // ring pass: 64 consecutive window indices [ub, ub+64), ub a multiple of 64
-    const long long q = qstart + ub + rbase;
-    const T* g = zero_src;
-    if (q >= 0 && q < p.Q) {
-      const unsigned uq = (unsigned)q;
-      const unsigned img = fdiv(uq, p.div_pp);
-      const unsigned rem = uq - img * (unsigned)p.PP;
-      const unsigned hp = fdiv(rem, p.div_pw);
-      const unsigned wp = rem - hp * (unsigned)L1_PW;
-      if (hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u)
-        g = src + (((long long)img * 56 + (hp - 1)) * 56 + (wp - 1)) * 64 + chunk * 8;
-    }
-    const int rrow = __builtin_amdgcn_readfirstlane(ub % L1_RING);
-    glds16(g, smem_base + L1_WBYTES + (rrow + wave * 8) * kRowBytes);
-    if (rrow == 0 && wave < L1_MIRROR / 8)  // rows 0..47 also behind the ring (same source, same pass)
-      glds16(g, smem_base + L1_WBYTES + (L1_RING + wave * 8) * kRowBytes);
-  };
-
-  // ---- prologue: filter (LDS row t*64 + rho, channel permutation of the ring kernel), first window, vectors ----
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int x = rbase & 15, ii = (rbase >> 4) & 1;
-    const int chan = (rbase & 32) + 8 * (x >> 2) + 4 * ii + (x & 3);
-    glds16(wgt + ((long long)chan * 9 + t) * 64 + chunk * 8, smem_base + (t * 64 + wave * 8) * kRowBytes);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) dma_ring(i * 64);
-  float* aff = reinterpret_cast<float*>(smem + L1_AFF);
-  if (tid < 6 * 64) {
-    const int v = tid >> 6, c = tid & 63;
-    const float* q = v == 0 ? p.scale : v == 1 ? p.shift : v == 2 ? p.bn_mean[0] : v == 3 ? p.bn_invstd[0]
-                                                                  : v == 4 ? p.bn_mean[1] : p.bn_invstd[1];
-    aff[tid] = q ? q[c] : (v == 0 ? 1.f : 0.f);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (grp == 1) asm volatile("s_barrier" ::: "memory");
-
-  float s1[2][4], s2[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
-  T* __restrict__ dst = static_cast<T*>(p.dst);
-  const T* __restrict__ res = static_cast<const T*>(p.residual);
-  const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
-  const T* __restrict__ by0 = static_cast<const T*>(p.bn_y[0]);
-  const unsigned char* ring = smem + L1_WBYTES;
-  const int w_lane = (wn * 32 + frow) * kRowBytes + ((fk ^ (frow & 7)) << 4);  // this lane's filter fragment, tap 0 / tile 0 / kk 0
-  const int cbase = wn * 32 + fk * 8;     // this lane's eight channels
-
-  auto out_row = [&](int k, int j) -> int {  // NHWC row of this lane's position in 16x16 tile j of tile k, or -1
-    long long q = (long long)(t0 + k) * BM + wm * 64 + j * 16 + frow;
-    if (q >= p.Q) return -1;
-    const unsigned uq = (unsigned)q;
-    const unsigned img = fdiv(uq, p.div_pp);
-    const unsigned rem = uq - img * (unsigned)p.PP;
-    const unsigned hp = fdiv(rem, p.div_pw);
-    const unsigned wp = rem - hp * (unsigned)L1_PW;
-    return (hp >= 1 && hp <= 56u && wp >= 1 && wp <= 56u) ? (int)((img * 56 + (hp - 1)) * 56 + (wp - 1)) : -1;
-  };
-  auto bf4 = [](unsigned lo, unsigned hi, float (&f)[4]) {
-    f[0] = __uint_as_float(lo << 16); f[1] = __uint_as_float(lo & 0xffff0000u);
-    f[2] = __uint_as_float(hi << 16); f[3] = __uint_as_float(hi & 0xffff0000u);
-  };
-
-  f32x4 acc[2][4];
-  int prow[4] = {-1, -1, -1, -1};
-  uint4 pre_res[RES ? 4 : 1], pre_msk[MSK ? 4 : 1], pre_y0[LINK ? 4 : 1];
-
-  // epilogue of the tile whose accumulators / prow / operands are live: straight from the registers
-  auto epilogue = [&]() {
-    float cst[4][8];   // scale, shift, mean0, invstd0 of this lane's channels
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if ((v < 2 && !FLIP) || (v >= 2 && LINK)) {
-        const float4 lo = *reinterpret_cast<const float4*>(aff + v * 64 + cbase), hi = *reinterpret_cast<const float4*>(aff + v * 64 + cbase + 4);
-        cst[v][0] = lo.x; cst[v][1] = lo.y; cst[v][2] = lo.z; cst[v][3] = lo.w;
-        cst[v][4] = hi.x; cst[v][5] = hi.y; cst[v][6] = hi.z; cst[v][7] = hi.w;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool live = prow[j] >= 0;
-      const float lm = live ? 1.f : 0.f;  // halo positions take no part in the statistics
-      const long long off = (long long)(live ? prow[j] : 0) * 64 + cbase;
-      bf16x8 o;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if constexpr (!FLIP) {
-          if (p.stats_partial != nullptr) {  // (uniform: an eval forward keeps no sums)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s1[i][r] += lm * v[r];
-              s2[i][r] += lm * v[r] * v[r];
-            }
-          }
-          if (p.scale || p.shift) {  // (uniform)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * cst[0][i * 4 + r] + cst[1][i * 4 + r];
-          }
-        }
-        if constexpr (RES) {
-          float rv[4];
-          bf4(i ? pre_res[j].z : pre_res[j].x, i ? pre_res[j].w : pre_res[j].y, rv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += rv[r];
-        }
-        if constexpr (!FLIP) {
-          if (p.relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          }
-        }
-        if constexpr (MSK) {
-          float mv[4];
-          bf4(i ? pre_msk[j].z : pre_msk[j].x, i ? pre_msk[j].w : pre_msk[j].y, mv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[i * 4 + r] = (bf16_t)v[r];
-        if constexpr (LINK) {
-          float yv[4];
-          bf4(i ? pre_y0[j].z : pre_y0[j].x, i ? pre_y0[j].w : pre_y0[j].y, yv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            s1[i][r] += lm * v[r];
-            s2[i][r] += lm * v[r] * (yv[r] - cst[2][i * 4 + r]) * cst[3][i * 4 + r];
-          }
-        }
-      }
-      bf16x8* out = live ? reinterpret_cast<bf16x8*>(dst + off) : reinterpret_cast<bf16x8*>(&l1_store_sink[tid]);
-      // (s_nop: a store of more than 8 bytes needs wait states before its data registers are written again)
-      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(out), "v"(o) : "memory");
-    }
-  };
-
-  int base = 0;  // (256*k) mod 640
-  for (int k = 0; k < nt; ++k) {
-    // ---- L_0 of tile k: epilogue of tile k-1, window fetch of tile k+1, this tile's epilogue operands ----
-    if (k > 0 && !(p.pbufs & 2)) epilogue();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (k + 1 < nt && !(p.pbufs & 4)) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma_ring(256 * k + 384 + i * 64);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      prow[j] = out_row(k, j);
-      if constexpr (NOPS > 0) {
-        const long long off = (long long)(prow[j] >= 0 ? prow[j] : 0) * 64 + cbase;   // (halo lanes: any valid address)
-        if constexpr (RES) pre_res[j] = *reinterpret_cast<const uint4*>(res + off);
-        if constexpr (MSK) pre_msk[j] = *reinterpret_cast<const uint4*>(msk + off);
-        if constexpr (LINK) pre_y0[j] = *reinterpret_cast<const uint4*>(by0 + off);
-      }
-    }
-    const int lane_row = base + wm * 64 + frow;
-    l1_static_for<NSEG>([&](auto seg_tag) {
-      constexpr int sg = decltype(seg_tag)::value;
-      constexpr int tb = sg * TPS, te = (tb + TPS < 9) ? tb + TPS : 9, ntp = te - tb;
-      // ---- L: the fragments of taps tb .. te-1 ----
-      uint4 fw[ntp][2][2], fa[ntp][2][4];
-#pragma unroll
-      for (int u = 0; u < ntp; ++u) {
-        const int t = tb + u;
-        constexpr int kPW = L1_PW;
-        const int kh = t / 3, kw = t % 3;
-        const int shift = FLIP ? (2 - kh) * kPW + (2 - kw) : kh * kPW + kw;
-        int rr0 = lane_row + shift;   // first row of this lane's four tiles for the tap, wrapped once (mirror rows behind the ring)
-        rr0 = rr0 >= L1_RING ? rr0 - L1_RING : rr0;
-        const int a0 = rr0 * kRowBytes + ((fk ^ ((frow + shift) & 7)) << 4);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            fw[u][kk][i] = *reinterpret_cast<const uint4*>(smem + (w_lane ^ (kk << 6)) + (t * 64 + i * 16) * kRowBytes);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            fa[u][kk][j] = *reinterpret_cast<const uint4*>(ring + (a0 ^ (kk << 6)) + j * (16 * kRowBytes));
-        }
-      }
-      if (sg == NSEG - 1 && !(p.pbufs & 1)) {
-        // the next tile's window (and this tile's epilogue operands, requested a tile ago in program terms) have landed
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- C ----
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int u = 0; u < ntp; ++u)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) QtMma<T>::run(acc[i][j], fw[u][kk][i], fa[u][kk][j]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_barrier" ::: "memory");
-    });
-    base += BM;
-    if (base >= L1_RING) base -= L1_RING;
-  }
-  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (group 1's last MFMA segment)
-  epilogue();
-
-  // ---- BatchNorm partial sums: one row per workgroup (as the ring kernel) ----
-  if (p.stats_partial || LINK) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {  // over the 16 positions (lanes with equal fk)
-          s1[i][r] += __shfl_xor(s1[i][r], m, 64);
-          s2[i][r] += __shfl_xor(s2[i][r], m, 64);
-        }
-      }
-    float* red = reinterpret_cast<float*>(smem + L1_RED);  // [wave][i][fk][r][2]
-    __syncthreads();  // the scratch lies over the filter: every wave has issued its last MFMA
-    if (frow == 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* d = red + ((((wave * 2 + i) * 4 + fk) * 4 + r) * 2);
-          d[0] = s1[i][r];
-          d[1] = s2[i][r];
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int n = tid, wn_ = n >> 5, fk_ = (n >> 3) & 3, i = (n >> 2) & 1, r = n & 3;  // n = wn*32 + fk*8 + i*4 + r
-      float a = 0.f, bb = 0.f;
-      for (int w4 = 0; w4 < 4; ++w4) {
-        const float* d = red + (((((wn_ * 4 + w4) * 2 + i) * 4 + fk_) * 4 + r) * 2);
-        a += d[0];
-        bb += d[1];
-      }
-      float* o0 = LINK ? p.bn_partial[0] : p.stats_partial;
-      o0[((long long)b * 2 + 0) * 64 + n] = a;
-      o0[((long long)b * 2 + 1) * 64 + n] = bb;
-    }
-  }
-}
-
+// Round 3, measured and REMOVED (git history: "layer1: ping-pong cut of the persistent kernel"): the same kernel re-cut on
+// conv_pt.hip's ping-pong schedule (waves 0-3 / 4-7 one barrier apart, three taps = 36 fragment reads + 48 MFMAs per
+// segment, the epilogue of tile k-1 / the window fetch of tile k+1 inside the first load segment of tile k).  The micro-
+// benchmark of the bare schedule promised 1617 cycles per three taps against 2820 in lockstep (scripts/ubench/pingpong.hip),
+// the kernel measured 92-97 us against 65-76 us for this one (forward, alone; 117-130 against 85-94 with a residual).
+// Ablation of it (QTCNN_L1_DEBUG at the time): bare fragment-read / MFMA loop 58 us, + window fetch 16 us, + epilogue
+// 25 us, the wait for the window 0 us.  Per tile a wave spends ~460 vector instructions on position arithmetic (two
+// divisions per DMA pass and per output row), accumulator clearing and the epilogue; in a ping-pong they sit in ONE
+// wave group's load segment while the partner's 48 MFMAs (768 cycles) hold half of the SIMD's issue slots, and the other
+// group repeats them one segment later: paid twice per tile, where the lockstep kernel's two waves per SIMD overlap them
+// with each other's MFMAs.  A ping-pong cut of this layer needs tile-invariant addressing (whole-row tiles as conv_pt.hip:
+// per-lane offsets + a scalar origin) and an epilogue spread over the segments behind a second accumulator set -- a
+// different kernel, not this one with barriers moved.
 inline int l1_ring_grid(long long Q) {
   const int ntiles = qt_cdiv(Q, BM);
   return ntiles < 256 ? ntiles : 256;
@@ -1003,31 +709,8 @@ int launch_l1_ring(PatchArgs a, hipStream_t stream) {
   return QT_OK;
 }
 
-template <bool FLIP, bool RES, bool MSK, bool LINK>
-int launch_l1_pp(PatchArgs a, hipStream_t stream) {
-  auto kern = conv_l1_pp_kernel<FLIP, RES, MSK, LINK>;
-  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
-  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), L1PP_LDS, lds_limit_set)) return rc;
-  a.gridM = qt_cdiv(a.Q, BM);
-  a.gridN = 1;
-  hipLaunchKernelGGL(kern, dim3(l1_ring_grid(a.Q)), dim3(NT), L1PP_LDS, stream, a);
-  QT_CHECK_LAUNCH();
-  return QT_OK;
-}
-
-// QTCNN_L1_PP (default 1): the ping-pong cut of the layer1 kernel; 0: the round-1/2 ring kernel (same-box A/B, bit-identical)
-int g_l1_pp = -1;
-inline bool l1_pp_enabled() {
-  if (g_l1_pp < 0) {
-    const char* e = getenv("QTCNN_L1_PP");
-    g_l1_pp = e ? atoi(e) : 0;
-  }
-  return g_l1_pp != 0;
-}
-
 }  // namespace
 
-extern "C" void qt_set_l1_pingpong(int mode) { g_l1_pp = mode < 0 ? 0 : (mode != 0); }
 
 // Shapes this kernel takes over from the generic implicit GEMM (see qt_conv2d_igemm).
 // Mostly off by default (mode 2 = ring kernel only): measured on MI355X (B=256, bf16) it only ties the generic kernel
@@ -1087,21 +770,8 @@ int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   a.div_pp = make_fastdiv((unsigned)a.PP);
   a.div_pw = make_fastdiv((unsigned)a.PW);
   a.gridM = a.gridN = 0;
-  a.pbufs = 0;
-  if (const char* dbg = getenv("QTCNN_L1_DEBUG")) a.pbufs = atoi(dbg);   // (diagnostic builds of the ping-pong kernel: see its loop)
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (l1_ring_shape(d)) {
-    if (l1_pp_enabled() && !a.bn_y[1]) {
-      const bool r = a.residual != nullptr, m = a.relu_mask != nullptr, l = a.bn_y[0] != nullptr;
-      // forward: no mask / links; data gradient: no affine / statistics / ReLU (other combinations: the ring kernel)
-      if (!a.flip && !m && !l) return r ? launch_l1_pp<false, true, false, false>(a, s) : launch_l1_pp<false, false, false, false>(a, s);
-      if (a.flip && !a.scale && !a.shift && !a.stats_partial && !a.relu) {
-        if (r && !m && !l) return launch_l1_pp<true, true, false, false>(a, s);
-        if (!r && m && l) return launch_l1_pp<true, false, true, true>(a, s);
-        if (r && m && l) return launch_l1_pp<true, true, true, true>(a, s);
-        if (!r && !m && !l) return launch_l1_pp<true, false, false, false>(a, s);
-      }
-    }
     const bool ops = a.residual || a.relu_mask || a.bn_y[0];
     if (a.flip) return ops ? launch_l1_ring<true, true>(a, s) : launch_l1_ring<true, false>(a, s);
     return ops ? launch_l1_ring<false, true>(a, s) : launch_l1_ring<false, false>(a, s);

@@ -443,7 +443,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
 #pragma unroll
       for (int e = 0; e < (DGRAD ? 8 : 1); ++e) s3[e] = 0.f;
       // pixel tiles in batches: the batch's memory operands are requested before its first row is finished
-      constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? (DGRAD ? 1 : 2) : 4) : 1;   // (BN == 256: 112 accumulator registers are live)
+      constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? 2 : (DGRAD ? 4 : 8)) : 1;   // (BN == 256: 112 accumulator registers are live; the
+      // 128-channel forward instantiation has the registers for ALL residual loads of a tile in one batch: one exposed latency)
 #pragma unroll
       for (int jb = 0; jb < TM; jb += JB) {
         __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of later batches from being hoisted over this one)

@@ -172,17 +172,6 @@ def bench_ring(label, mode, residual=False, mask=False, link=False, H=56, C=64):
     print(f"ring {label:34s}: {us:8.1f} us", flush=True)
 
 
-if __name__ == "__main__" and which == "l1ab":   # ping-pong cut against the ring kernel, interleaved rounds in one process
-    for rnd in range(2):
-        for pp in (1, 0):
-            L.lib().qt_set_l1_pingpong(pp)
-            print(f"-- round {rnd} qt_set_l1_pingpong({pp})", flush=True)
-            bench_ring("fwd plain", L.QT_CONV_FWD)
-            bench_ring("fwd + scale/shift + residual + relu", L.QT_CONV_FWD, residual=True)
-            bench_ring("dgrad + relu mask + bn link", L.QT_CONV_DGRAD, mask=True, link=True)
-            bench_ring("dgrad + residual + mask + bn link", L.QT_CONV_DGRAD, residual=True, mask=True, link=True)
-    L.lib().qt_set_l1_pingpong(-1)
-
 if __name__ == "__main__" and which == "ring":
     bench_ring("fwd plain", L.QT_CONV_FWD)
     bench_ring("fwd + scale/shift + residual + relu", L.QT_CONV_FWD, residual=True)
