@@ -92,6 +92,13 @@ typedef struct qt_conv_desc {
    * four gathers that each re-read it (weight operand: qt_pack_dgrad_s2_merged). */
   int dst_merge;
   int dst_merge_res0;  /* with dst_merge: the residual is added to class (0,0) only (the other pixels of it are never read) */
+  /* Conv3d as ONE launch (nn.Conv3d 3x3x3 / pad 1 of /root/reference/3dcnn/models.py:108-139, cnn+lstm/models.py:104-121):
+   * kt = 3 frame taps on time-major clips [frames][batch / frames][H][W][C] -- `batch` counts images = frames x clips,
+   * image t * (batch / frames) + b is frame t of clip b; tap (kt, kh, kw) of an output image reads the image one frame
+   * earlier / same / later (zero where that frame does not exist), weight [n_out][kt][kh][kw][k_per_tap]; f32
+   * accumulation over all kt * kh * kw taps, the epilogue (bias, residual, BatchNorm3d statistics) sees the finished value.
+   * DGRAD mirrors it.  Needs stride 1 and no region / strided-destination mode; 0 or 1 = plain 2-D. */
+  int kt, frames;
 } qt_conv_desc;
 
 typedef struct qt_conv_io {
@@ -437,6 +444,16 @@ int qt_gemm_small(const qt_gemm_small_desc* desc, const void* A, const void* B, 
  * channels of pixel (t,b,h,w), element ((kt*3+kh)*3+kw)*3+c, zeros outside the clip and in 81..127: the first Conv3d
  * (3 input channels) becomes a 1x1 convolution with k_per_tap = 128 */
 int qt_pack_clip27(int dtype, const float* clips, void* dst, int batch, int frames, int h, int w, void* stream);
+/* One launch per Conv3d block (nn.Conv3d 3x3x3 + BatchNorm3d, /root/reference/3dcnn/models.py:108-139): the operands of
+ * the 27-tap implicit GEMM (qt_conv_desc.kt = 3) from nn.Conv3d's weight w [O][I][3][3][3] f32 -- w_fwd
+ * [O_pad][27][I_pad], w_dgrad [I_pad][27][O_pad] (optional), zero padded; first != 0: w_fwd [O_pad][128] in the K order of
+ * qt_pack_clip27 (27 * I <= 128) -- and the padded per-channel vectors: vec_in_dev = DEVICE array of 5 device pointers
+ * (conv bias, BatchNorm weight, bias, running_mean, running_var; [O] each, NULL = padding value) -> vec_out [5][O_pad]
+ * padded with 0, 1, 0, 0, 1.  qt_unpack_conv3d_wgrad is the way back for the weight gradient: dw = three [O_pad][9][I_pad]
+ * f32 blocks, one per frame tap, as qt_conv2d_wgrad writes them (first != 0: [O_pad][128]) -> grad [O][I][3][3][3]. */
+int qt_pack_conv3d_block(int dtype, const float* w, void* w_fwd, void* w_dgrad, int O, int I, int O_pad, int I_pad, int first,
+                         const float* const* vec_in_dev, float* vec_out, void* stream);
+int qt_unpack_conv3d_wgrad(const float* dw, float* grad, int O, int I, int O_pad, int I_pad, int first, void* stream);
 /* BatchNorm3d batch statistics of a finished map y [M][C]: partial[qt_bn_stats_rows(M,C)][2][C] sums / sums of squares
  * (fixed summation order), input of qt_bn_finalize (buffer capacity qt_stats_capacity_rows(rows)) */
 int qt_bn_stats_rows(long long M, int C);

@@ -38,6 +38,7 @@ class ConvDesc(ctypes.Structure):
         ("dst_sub", ctypes.c_int), ("dst_h", ctypes.c_int), ("dst_w", ctypes.c_int),
         ("dst_off_h", ctypes.c_int), ("dst_off_w", ctypes.c_int),
         ("dst_merge", ctypes.c_int), ("dst_merge_res0", ctypes.c_int),
+        ("kt", ctypes.c_int), ("frames", ctypes.c_int),
     ]
 
 

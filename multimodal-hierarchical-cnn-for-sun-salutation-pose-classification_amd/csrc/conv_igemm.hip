@@ -140,15 +140,27 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
       a_ow[i] = ow;
       // validity is separable: tap (kh,kw) is valid iff row tap kh and column tap kw are
       unsigned vw = 0, mask = 0;
-      const int KH = p.ntaps / p.KW;
+      const int KH = p.ntaps / (p.KW * (p.KT > 1 ? p.KT : 1));
       for (int kw = 0; kw < p.KW; ++kw)
         if (axis_ok(ow, kw, p.IW)) vw |= 1u << kw;
       for (int kh = 0; kh < KH; ++kh)
         if (axis_ok(oh, kh, p.IH)) mask |= vw << (kh * p.KW);
+      long long f0 = 0;
+      if (p.KT > 1) {   // frame taps: the spatial mask repeats once per frame tap whose source frame exists
+        const int t = img / p.imgs_per_frame, pt = p.KT >> 1;
+        const int taps2d = KH * p.KW;
+        unsigned m3 = 0;
+        for (int kt = 0; kt < p.KT; ++kt) {
+          const int ts = DGRAD ? t + pt - kt : t - pt + kt;
+          if (ts >= 0 && ts < p.frames) m3 |= mask << (kt * taps2d);
+        }
+        mask = m3;
+        f0 = (DGRAD ? pt : -pt) * p.frame_stride;
+      }
       a_mask[i] = mask;
       const long long h0 = DGRAD ? (oh + p.pad) : (oh * p.stride - p.pad);
       const long long w0 = DGRAD ? (ow + p.pad) : (ow * p.stride - p.pad);
-      a_ptr[i] = src + base + h0 * p.src_row_stride + w0 * p.src_pix_stride + chunk * (16 / (int)sizeof(T));
+      a_ptr[i] = src + base + f0 + h0 * p.src_row_stride + w0 * p.src_pix_stride + chunk * (16 / (int)sizeof(T));
     }
   }
   const int ktot = p.ntaps * p.KC;
@@ -178,13 +190,17 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
   const unsigned smem_base = lds_addr_of(smem);
   // uniform (tap, channel offset) of the NEXT stage to issue; stages are issued in order
-  int nx_kh = 0, nx_kw = 0, nx_tap = 0, nx_c0 = 0;
+  int nx_kh = 0, nx_kw = 0, nx_kt = 0, nx_tap = 0, nx_c0 = 0;
+  const int KH2 = p.KT > 1 ? p.ntaps / (p.KT * p.KW) : 1 << 30;   // rows of a 2-D filter slice (frame taps only)
   auto next_tap = [&]() {  // the next tap slot this channel tile uses
     do {
       ++nx_tap;
       if (++nx_kw == p.KW) {
         nx_kw = 0;
-        ++nx_kh;
+        if (++nx_kh == KH2) {
+          nx_kh = 0;
+          ++nx_kt;
+        }
       }
     } while (nx_tap < p.ntaps && !((tmask >> nx_tap) & 1u));
   };
@@ -214,6 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
       } else {
         tap = nx_tap;
         toff = (long long)nx_kh * p.src_row_stride + (long long)nx_kw * p.src_pix_stride;
+        if (p.KT > 1) toff += (long long)nx_kt * p.frame_stride;
         toff = (DGRAD ? -toff : toff) + nx_c0;
       }
 #pragma unroll
@@ -648,8 +665,9 @@ int qt_stem_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream);
 
 extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   if (!d) return QT_ERR_INVALID_ARG;
-  if (qt_patch_eligible(d)) return qt_patch_stats_rows(d);
-  if (qt_stem_eligible(d, nullptr)) return qt_stem_stats_rows(d);
+  const bool kt3 = d->kt > 1;   // (frame taps: always the generic tile)
+  if (!kt3 && qt_patch_eligible(d)) return qt_patch_stats_rows(d);
+  if (!kt3 && qt_stem_eligible(d, nullptr)) return qt_stem_stats_rows(d);
   const long long M = (long long)d->batch * (d->mode == QT_CONV_FWD ? qt_quad_regions(d->quad) : 1) * d->out_h * d->out_w;
   const int esz = d->dtype == QT_F32 ? 4 : 2;
   {
@@ -658,9 +676,9 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
     a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.dst_sub = d->dst_sub;
     a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
     a.src_img_stride = d->src_img_stride; a.src_row_stride = d->src_row_stride; a.src_pix_stride = d->src_pix_stride;
-    if (qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
+    if (!kt3 && qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
   }
-  const int rows = qt_cdiv(M, tile_m(M, d->n_out, d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
+  const int rows = qt_cdiv(M, tile_m(M, d->n_out, (kt3 ? d->kt : 1) * d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
   return d->dst_merge > 0 ? rows * (d->n_out / d->dst_merge) : rows;  // merged parity classes: one row per class
 }
 
@@ -692,8 +710,13 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG((d->src_pix_stride * esz) % 16 == 0 || d->stride * d->src_pix_stride * esz % 16 == 0,
                "qt_conv2d_igemm: pixel stride %d breaks 16-byte alignment", d->src_pix_stride);
 
-  if (qt_stem_eligible(d, io)) return qt_stem_launch(d, io, stream);
-  if (qt_patch_eligible(d)) {
+  const int KT = d->kt > 1 ? d->kt : 1;
+  QT_CHECK_ARG(KT == 1 || (KT == 3 && d->frames > 0 && d->batch % d->frames == 0 && d->stride == 1 && !d->quad && !d->dst_sub &&
+                           !d->dst_merge && d->kh * d->kw * KT <= 32 && d->k_per_tap % bk == 0),
+               "qt_conv2d_igemm: frame taps need kt = 3, frames dividing batch (time-major clips), stride 1, no region / "
+               "strided-destination mode, kt*kh*kw <= 32 and whole K-steps per tap");
+  if (KT == 1 && qt_stem_eligible(d, io)) return qt_stem_launch(d, io, stream);
+  if (KT == 1 && qt_patch_eligible(d)) {
     for (int k = 0; k < 2; ++k)
       QT_CHECK_ARG(!io->bwd_bn[k].y || (io->bwd_bn[k].mean && io->bwd_bn[k].invstd && io->bwd_bn[k].partial &&
                                         !io->stats_partial),
@@ -720,7 +743,9 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG(M < (1ll << 31) && M * d->n_out < (1ll << 40), "qt_conv2d_igemm: problem too large");
   a.M = (int)M; a.N = d->n_out;
   a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
-  a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw;
+  a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw * KT; a.KW = d->kw;
+  a.KT = KT; a.frames = KT > 1 ? d->frames : 1; a.imgs_per_frame = KT > 1 ? d->batch / d->frames : d->batch;
+  a.frame_stride = (long long)a.imgs_per_frame * d->src_img_stride;
   a.stride = d->stride; a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.relu = d->relu;
   a.gridM = a.gridN = 0;
   a.dst_sub = d->dst_sub; a.dst_h = d->dst_h; a.dst_w = d->dst_w; a.dst_oh = d->dst_off_h; a.dst_ow = d->dst_off_w;
@@ -739,6 +764,6 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
                                    (d->out_w - 1) * d->dst_sub + d->dst_off_w < d->dst_w),
                "qt_conv2d_igemm: bad destination mapping");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
+  if (KT == 1 && qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_launch(a, d->dtype, d->mode == QT_CONV_DGRAD, s);
   return d->dtype == QT_F32 ? dispatch<float>(d, a, s) : dispatch<bf16_t>(d, a, s);
 }

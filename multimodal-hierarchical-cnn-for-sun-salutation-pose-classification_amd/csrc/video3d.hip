@@ -205,6 +205,95 @@ inline unsigned grid_for(long long n) {
 
 }  // namespace
 
+namespace {
+
+// ---- one launch per Conv3d block: operands of the 27-tap implicit GEMM + the zero / one padded per-channel vectors ----
+// W [O][I][27] f32 (nn.Conv3d weight, taps (kt, kh, kw) row-major) ->
+//   FIRST == 0: wf [Op][27][Ip] (forward operand), wd [Ip][27][Op] (data-gradient operand, optional), zero padded;
+//   FIRST == 1: wf [Op][128], K index (tap * I + c) < 27 * I as qt_pack_clip27 lays the clip out, zero padded.
+// vec_in[5] = bias, gamma, beta, running_mean, running_var ([O] each) -> vec_out [5][Op], padded with 0, 1, 0, 0, 1.
+template <typename T>
+__global__ void pack_conv3d_block_kernel(const float* __restrict__ W, T* __restrict__ wf, T* __restrict__ wd, int O, int I,
+                                         int Op, int Ip, int first, const float* const* vec_in, float* __restrict__ vec_out) {
+  const long long nf = first ? (long long)Op * 128 : (long long)Op * 27 * Ip;
+  const long long total = nf + 5ll * Op;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (i >= nf) {
+      const int v = (int)((i - nf) / Op), c = (int)((i - nf) % Op);
+      const float* src = vec_in[v];
+      vec_out[v * Op + c] = (c < O && src) ? src[c] : ((v == 1 || v == 4) ? 1.f : 0.f);
+      continue;
+    }
+    if (first) {
+      const int o = (int)(i >> 7), k = (int)(i & 127);
+      float val = 0.f;
+      if (o < O && k < 27 * I) {
+        const int tap = k / I, c = k - tap * I;
+        val = W[((long long)o * I + c) * 27 + tap];
+      }
+      wf[i] = (T)val;
+    } else {
+      const int c = (int)(i % Ip);
+      const long long q = i / Ip;
+      const int tap = (int)(q % 27), o = (int)(q / 27);
+      const float val = (o < O && c < I) ? W[((long long)o * I + c) * 27 + tap] : 0.f;
+      wf[i] = (T)val;
+      if (wd) wd[((long long)c * 27 + tap) * Op + o] = (T)val;
+    }
+  }
+}
+
+// weight gradient back to nn.Conv3d's layout: dw [27][Op][Ip]-like pieces -> dW [O][I][27]
+//   FIRST == 0: dw = three [Op][9][Ip] f32 blocks (one per frame tap, as qt_conv2d_wgrad writes them);
+//   FIRST == 1: dw = [Op][128] (K index tap * I + c).
+__global__ void unpack_conv3d_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ dW, int O, int I, int Op, int Ip,
+                                           int first) {
+  const long long total = (long long)O * I * 27;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 27);
+    const long long q = i / 27;
+    const int c = (int)(q % I), o = (int)(q / I);
+    float v;
+    if (first) v = dw[(long long)o * 128 + tap * I + c];
+    else {
+      const int kt = tap / 9, t2 = tap - kt * 9;
+      v = dw[(((long long)kt * Op + o) * 9 + t2) * Ip + c];
+    }
+    dW[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int qt_pack_conv3d_block(int dtype, const float* w, void* w_fwd, void* w_dgrad, int O, int I, int O_pad, int I_pad,
+                                    int first, const float* const* vec_in_dev, float* vec_out, void* stream) {
+  QT_CHECK_ARG(w && w_fwd && vec_in_dev && vec_out && O > 0 && I > 0 && O_pad >= O && (first || I_pad >= I) &&
+                   (!first || 27 * I <= 128),
+               "qt_pack_conv3d_block: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pack_conv3d_block: bad dtype %d", dtype);
+  const long long total = (first ? (long long)O_pad * 128 : (long long)O_pad * 27 * I_pad) + 5ll * O_pad;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == QT_F32)
+    hipLaunchKernelGGL(pack_conv3d_block_kernel<float>, dim3(grid), dim3(256), 0, s, w, static_cast<float*>(w_fwd),
+                       static_cast<float*>(w_dgrad), O, I, O_pad, I_pad, first, vec_in_dev, vec_out);
+  else
+    hipLaunchKernelGGL(pack_conv3d_block_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, static_cast<bf16_t*>(w_fwd),
+                       static_cast<bf16_t*>(w_dgrad), O, I, O_pad, I_pad, first, vec_in_dev, vec_out);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_unpack_conv3d_wgrad(const float* dw, float* grad, int O, int I, int O_pad, int I_pad, int first, void* stream) {
+  QT_CHECK_ARG(dw && grad && O > 0 && I > 0 && O_pad >= O && (first || I_pad >= I), "qt_unpack_conv3d_wgrad: bad argument");
+  const long long total = (long long)O * I * 27;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(unpack_conv3d_wgrad_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), dw, grad, O, I,
+                     O_pad, I_pad, first);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
 extern "C" int qt_pack_clip27(int dtype, const float* clips, void* dst, int batch, int frames, int h, int w, void* stream) {
   QT_CHECK_ARG(clips && dst && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_pack_clip27: bad argument");
   QT_CHECK_ARG((long long)frames * batch * h * w < (1ll << 31), "qt_pack_clip27: more than 2^31 pixel rows");

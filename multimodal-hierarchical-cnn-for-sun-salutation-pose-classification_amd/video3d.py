@@ -7,15 +7,15 @@ with the reference's constructor arguments, attribute tree, state_dict keys and 
 (image_sequence [B,T,3,H,W], numerical_sequence [B,T,47]) -> logits [B,C].
 
 How a Conv3d runs here.  Clip activations are TIME-MAJOR NHWC, [T][B][H][W][C], in the compute dtype (bf16, or f32
-with QTCNN_DTYPE=f32).  A 3x3x3 convolution with padding 1 is the sum over the frame tap kt of three 3x3 2-D
-convolutions over CONTIGUOUS ranges of frames (out[t] += conv2d(in[t+kt-1], W[:,:,kt]) for the t whose source frame
-exists), so forward, data gradient and weight gradient are three launches each of the implicit-GEMM MFMA kernels
-behind qt_conv2d_igemm / qt_conv2d_wgrad (csrc/conv_igemm.hip, conv_pt.hip, conv_wgrad*.hip), accumulated through the
-kernels' `residual` input.  The first layer (3 input channels) is packed to one 128-wide K row per pixel (27 taps x 3
-channels, qt_pack_clip27) and runs as a 1x1 convolution; its 32 output channels are padded to 64 with zero filters so
-that the next layer's K rows are whole 128-byte chunks.  BatchNorm3d statistics come from qt_bn_stats over the
-finished map, MaxPool3d / AdaptiveAvgPool3d from csrc/video3d.hip, the LSTM recurrences from csrc/lstm.hip, the thin
-dense products from csrc/gemm_small.hip.  The whole forward / backward is ONE autograd node; PyTorch only owns the
+with QTCNN_DTYPE=f32).  A 3x3x3 convolution with padding 1 is ONE implicit GEMM over 27 taps (qt_conv_desc.kt = 3,
+csrc/conv_igemm.hip: tap (kt, kh, kw) of an output pixel of frame t reads frame t + kt - 1, masked per row where that
+frame does not exist), forward and data gradient alike: f32 accumulation over all taps, the epilogue adds the bias and
+emits the BatchNorm3d statistics.  The weight gradient is one launch per frame tap over the contiguous range of frames
+the tap connects (the tile-resident bf16 kernel with fixed-order partial sums where it covers the shape).  The first
+layer (3 input channels) is packed to one 128-wide K row per pixel (27 taps x 3 channels, qt_pack_clip27) and runs as a
+1x1 convolution; its 32 output channels are padded to 64 with zero filters so that the next layer's K rows are whole
+128-byte chunks.  MaxPool3d / AdaptiveAvgPool3d come from csrc/video3d.hip, the LSTM recurrences from csrc/lstm.hip, the
+thin dense products from csrc/gemm_small.hip.  The whole forward / backward is ONE autograd node; PyTorch only owns the
 buffers.  There is no torch / CPU fallback.
 """
 import ctypes
@@ -57,6 +57,8 @@ class _Ops:
         self.L = _lib.lib()
         L = self.L
         L.qt_stats_capacity_rows.restype = _c.c_int
+        L.qt_conv2d_wgrad_workspace_bytes.restype = _c.c_size_t
+        self._wgrad_ws = None
         L.qt_bn_stats_rows.argtypes = [_c.c_longlong, _c.c_int]
         L.qt_bn_bwd_partial_rows.argtypes = [_c.c_longlong, _c.c_int]
 
@@ -77,12 +79,30 @@ class _Ops:
         d.src_img_stride, d.src_row_stride, d.src_pix_stride = h * w * k_per_tap, w * k_per_tap, k_per_tap
         return d
 
-    def igemm(self, d, src, w, dst, shift=None, residual=None):
-        io = _lib.ConvIO(src, w, dst, None, _ptr(shift), residual, None, None)
+    def igemm(self, d, src, w, dst, scale=None, shift=None, residual=None, relu=0, stats=None):
+        d.relu = relu
+        io = _lib.ConvIO(src, w, dst, _ptr(scale), _ptr(shift), residual, None, _ptr(stats))
         self.check(self.L.qt_conv2d_igemm(_c.byref(d), _c.byref(io), _lib.stream_ptr()), "qt_conv2d_igemm")
 
     def wgrad(self, d, dy, x, dw):
-        self.check(self.L.qt_conv2d_wgrad(_c.byref(d), dy, x, _ptr(dw), _lib.stream_ptr()), "qt_conv2d_wgrad")
+        """dw [n_out][taps][k_per_tap] f32 (zeroed by the caller).  Where the tile-resident kernel covers the shape (bf16,
+        3x3 / stride 1) it gets its partial-filter workspace: fixed-order sums instead of float atomics."""
+        nbytes = self.L.qt_conv2d_wgrad_workspace_bytes(_c.byref(d))
+        if nbytes > 0:
+            if self._wgrad_ws is None or self._wgrad_ws.numel() < nbytes or self._wgrad_ws.device != dw.device:
+                self._wgrad_ws = torch.empty(nbytes, dtype=torch.uint8, device=dw.device)
+            self.check(self.L.qt_conv2d_wgrad_ws(_c.byref(d), dy, x, _ptr(dw), _ptr(self._wgrad_ws), _c.c_size_t(nbytes),
+                                                 _lib.stream_ptr()), "qt_conv2d_wgrad_ws")
+        else:
+            self.check(self.L.qt_conv2d_wgrad(_c.byref(d), dy, x, _ptr(dw), _lib.stream_ptr()), "qt_conv2d_wgrad")
+
+    def bn_finalize(self, part, prow, Mrows, C, gamma, beta, rmean, rvar, nbt, dev):
+        out = torch.empty(4, C, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+        self.check(self.L.qt_bn_finalize(_ptr(part), prow, C, _c.c_longlong(Mrows), _ptr(gamma), _ptr(beta), _ptr(rmean),
+                                         _ptr(rvar), _ptr(nbt), _c.c_float(BN_MOMENTUM), _c.c_float(BN_EPS),
+                                         _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _lib.stream_ptr()),
+                   "qt_bn_finalize")
+        return out
 
     def pack_weight(self, dt, w_oihw, w_fwd, w_dgrad, O, I, k):
         self.check(self.L.qt_pack_conv_weight(_lib.qt_dtype(dt), _ptr(w_oihw), _ptr(w_fwd), _ptr(w_dgrad), O, I, k, k,
@@ -178,76 +198,78 @@ def _cpad(c):
 
 
 class _ConvBlock:
-    """Conv3d(3x3x3, pad 1, bias) + BatchNorm3d + ReLU (+ MaxPool3d (pt,2,2)) on [T][B][H][W][C]."""
+    """Conv3d(3x3x3, pad 1, bias) + BatchNorm3d + ReLU (+ MaxPool3d (pt,2,2)) on [T][B][H][W][C].
+    ONE forward and ONE data-gradient launch per Conv3d: the implicit GEMM walks all 27 taps (qt_conv_desc.kt = 3, f32
+    accumulation, frames past the clip's ends masked per output row), its epilogue adds the bias and emits the BatchNorm3d
+    statistics of the finished value.  (Rounds 1-2 ran three launches per convolution that accumulated through the bf16
+    output map: two extra read + write passes per layer and two intermediate roundings.)"""
 
     def __init__(self, conv, bn, pool_t, first):
         self.conv, self.bn, self.pool_t, self.first = conv, bn, pool_t, first
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.cin_p = 128 if first else _cpad(self.cin)
         self.cout_p = _cpad(self.cout)
+        self._buf_key = None
 
-    # -- operand packing (per forward: parameters may have changed) --
+    # -- operand packing: ONE launch per forward (weights may have changed: fused optimizers do not bump _version) --
     def pack(self, dt, need_dgrad):
         o, dev = ops(), self.conv.weight.device
-        W = self.conv.weight.detach()
-        self.wf, self.wd = [], []
-        if self.first:   # [O][3][kt][kh][kw] -> [O][(kt,kh,kw,c)] padded to [cout_p][128], a 1x1 filter
-            w1 = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
-            w1[:self.cout, :81] = W.permute(0, 2, 3, 4, 1).reshape(self.cout, 81)
-            wf = torch.empty(self.cout_p, 1, 1, 128, dtype=dt, device=dev)
-            o.pack_weight(dt, w1, wf, None, self.cout_p, 128, 1)
-            self.wf.append(wf)
-        else:
-            for kt in range(3):
-                wk = torch.zeros(self.cout_p, self.cin_p, 3, 3, dtype=torch.float32, device=dev)
-                wk[:self.cout, :self.cin] = W[:, :, kt]
-                wf = torch.empty(self.cout_p, 3, 3, self.cin_p, dtype=dt, device=dev)
-                wd = torch.empty(self.cin_p, 3, 3, self.cout_p, dtype=dt, device=dev) if need_dgrad else None
-                o.pack_weight(dt, wk, wf, wd, self.cout_p, self.cin_p, 3)
-                self.wf.append(wf)
-                self.wd.append(wd)
-        pad = self.cout_p - self.cout
-        z, one = torch.zeros(pad, device=dev), torch.ones(pad, device=dev)
-        self.bias_p = torch.cat([self.conv.bias.detach(), z])
-        self.gamma_p = torch.cat([self.bn.weight.detach(), one])
-        self.beta_p = torch.cat([self.bn.bias.detach(), z])
-        self.rmean_p = torch.cat([self.bn.running_mean, z])
-        self.rvar_p = torch.cat([self.bn.running_var, one])
+        key = (dt, dev, bool(need_dgrad))
+        if self._buf_key != key:
+            nf = self.cout_p * 128 if self.first else self.cout_p * 27 * self.cin_p
+            self.wf = torch.empty(nf, dtype=dt, device=dev)
+            self.wd = torch.empty(nf, dtype=dt, device=dev) if (need_dgrad and not self.first) else None
+            self.vec = torch.empty(5, self.cout_p, dtype=torch.float32, device=dev)
+            self._buf_key = key
+        vals = (self.conv.bias.data_ptr(), self.bn.weight.data_ptr(), self.bn.bias.data_ptr(),
+                self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr())
+        if getattr(self, "_ptr_vals", None) != vals:   # (device array of the five vector pointers: rebuilt only when a tensor moved)
+            self._ptrs = torch.tensor(vals, dtype=torch.int64).to(dev)
+            self._ptr_vals = vals
+        ptrs = self._ptrs
+        o.check(o.L.qt_pack_conv3d_block(_lib.qt_dtype(dt), _ptr(self.conv.weight.detach()), _ptr(self.wf), _ptr(self.wd),
+                                         self.cout, self.cin, self.cout_p, self.cin_p, 1 if self.first else 0, _ptr(ptrs),
+                                         _ptr(self.vec), _lib.stream_ptr()), "qt_pack_conv3d_block")
+        self.bias_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p = (self.vec[i] for i in range(5))
 
-    @staticmethod
-    def _ranges(T, kt):
-        """(dst frame begin, src frame begin, frames) of out[t] += conv(in[t + kt - 1])"""
-        lo = max(0, 1 - kt)
-        hi = min(T, T + 1 - kt)
-        return lo, lo + kt - 1, max(0, hi - lo)
+    def _desc(self, dt, mode, T, B, H, W):
+        if self.first:
+            return o_desc(dt, mode, T * B, H, W, 128, self.cout_p, 1, 0)
+        kin, kout = (self.cin_p, self.cout_p) if mode == _lib.QT_CONV_FWD else (self.cout_p, self.cin_p)
+        d = o_desc(dt, mode, T * B, H, W, kin, kout, 3, 1)
+        d.kt, d.frames = 3, T
+        return d
 
     def forward(self, dt, x, T, B, H, W, training, keep):
         o, dev = ops(), x.device
-        esz = 2 if dt == torch.bfloat16 else 4
         rows = T * B * H * W
+        d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
         y = torch.empty(rows, self.cout_p, dtype=dt, device=dev)
-        if self.first:
-            d = o.conv_desc(dt, _lib.QT_CONV_FWD, T * B, H, W, 128, self.cout_p, 1, 0)
-            o.igemm(d, _ptr(x), _ptr(self.wf[0]), _ptr(y), shift=self.bias_p)
-        else:
-            frame_in, frame_out = B * H * W * self.cin_p * esz, B * H * W * self.cout_p * esz
-            for n, kt in enumerate((1, 0, 2)):     # the centre tap covers every frame: it goes first and carries the bias
-                dlo, slo, cnt = self._ranges(T, kt)
-                if cnt == 0:
-                    continue
-                d = o.conv_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
-                dst = _ptr(y, dlo * frame_out)
-                o.igemm(d, _ptr(x, slo * frame_in), _ptr(self.wf[kt]), dst, shift=self.bias_p if n == 0 else None,
-                        residual=None if n == 0 else dst)
+        fused_eval = not training and not keep   # eval without backward: BatchNorm3d + ReLU in the conv epilogue, no second pass
         if training:
-            nbt = self.bn.num_batches_tracked
-            stats = o.bn_train(dt, y, rows, self.cout_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, nbt, dev)
+            prow = o.L.qt_conv2d_stats_rows(_c.byref(d))
+            part = torch.empty(o.L.qt_stats_capacity_rows(prow), 2, self.cout_p, dtype=torch.float32, device=dev)
+            # Under batch statistics BatchNorm3d(conv + bias) = BatchNorm3d(conv): a per-channel constant moves the mean with it.
+            # y holds the bias-free accumulator and the epilogue's statistics are of exactly that value; the bias only enters
+            # the running mean the reference tracks (mean of conv + bias), added below.
+            o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), stats=part)
+            stats = o.bn_finalize(part, prow, rows, self.cout_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p,
+                                  self.bn.num_batches_tracked, dev)
+            self.rmean_p.add_(self.bias_p, alpha=BN_MOMENTUM)
             self.bn.running_mean.copy_(self.rmean_p[:self.cout])
             self.bn.running_var.copy_(self.rvar_p[:self.cout])
         else:
             stats = o.bn_eval(self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, self.cout_p, dev)
-        a = torch.empty_like(y)
-        o.bn_act(dt, y, stats, a, rows, self.cout_p)
+            if fused_eval:   # relu(scale * (conv + bias) + shift)
+                shift = torch.addcmul(stats[3], stats[2], self.bias_p)
+                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), scale=stats[2], shift=shift, relu=1)
+            else:
+                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), shift=self.bias_p)
+        if fused_eval:
+            a = y
+        else:
+            a = torch.empty_like(y)
+            o.bn_act(dt, y, stats, a, rows, self.cout_p)
         arg, out, To, Ho, Wo = None, a, T, H, W
         if self.pool_t:
             To, Ho, Wo = T // self.pool_t, H // 2, W // 2
@@ -256,6 +278,13 @@ class _ConvBlock:
             o.pool(dt, a, out, arg, T, B, H, W, self.cout_p, self.pool_t)
         saved = (x, y, a, arg, stats, (T, B, H, W), training) if keep else None
         return out, (To, Ho, Wo), saved
+
+    @staticmethod
+    def _ranges(T, kt):
+        """(dst frame begin, src frame begin, frames) of out[t] += conv(in[t + kt - 1])"""
+        lo = max(0, 1 - kt)
+        hi = min(T, T + 1 - kt)
+        return lo, lo + kt - 1, max(0, hi - lo)
 
     def backward(self, dt, dout, saved):
         """dout: d/d(block output) -> (dx or None, dW, db, dgamma, dbeta)"""
@@ -282,29 +311,32 @@ class _ConvBlock:
         dW = torch.empty_like(self.conv.weight)
         dx = None
         if self.first:
-            d = o.conv_desc(dt, _lib.QT_CONV_FWD, T * B, H, W, 128, self.cout_p, 1, 0)
-            dw = torch.zeros(self.cout_p, 1, 128, dtype=torch.float32, device=dev)
+            d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
+            dw = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
             o.wgrad(d, _ptr(dy), _ptr(x), dw)
-            dW.copy_(dw[:self.cout, 0, :81].view(self.cout, 3, 3, 3, 3).permute(0, 4, 1, 2, 3))
         else:
+            # weight gradient: one launch per frame tap over the contiguous range of frames the tap connects (the contraction
+            # runs over pixels: f32 sums, nothing accumulates through an activation map); with a workspace the bf16 build takes
+            # the tile-resident kernel and its fixed-order partial sums: deterministic, no float atomics
             frame_in, frame_out = B * H * W * self.cin_p * esz, B * H * W * self.cout_p * esz
-            dx = torch.empty(T * B * H * W, self.cin_p, dtype=dt, device=dev)
-            g4 = torch.empty(self.cout_p, self.cin_p, 3, 3, dtype=torch.float32, device=dev)
-            for n, kt in enumerate((1, 0, 2)):
+            dw = torch.zeros(3, self.cout_p, 9, self.cin_p, dtype=torch.float32, device=dev)
+            for kt in range(3):
                 dlo, slo, cnt = self._ranges(T, kt)   # forward: out[dlo + i] read in[slo + i]
                 if cnt == 0:
-                    dW[:, :, kt].zero_()
                     continue
-                d = o.conv_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
-                dw = torch.zeros(self.cout_p, 9, self.cin_p, dtype=torch.float32, device=dev)
-                o.wgrad(d, _ptr(dy, dlo * frame_out), _ptr(x, slo * frame_in), dw)
-                o.unpack_wgrad(dw, g4, self.cout_p, self.cin_p, 3)
-                dW[:, :, kt].copy_(g4[:self.cout, :self.cin])
-                # data gradient: dx[slo + i] += conv_transpose(dy[dlo + i]); the centre tap writes every frame first
-                dd = o.conv_desc(dt, _lib.QT_CONV_DGRAD, cnt * B, H, W, self.cout_p, self.cin_p, 3, 1)
-                dst = _ptr(dx, slo * frame_in)
-                o.igemm(dd, _ptr(dy, dlo * frame_out), _ptr(self.wd[kt]), dst, residual=None if n == 0 else dst)
+                d2 = o_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
+                o.wgrad(d2, _ptr(dy, dlo * frame_out), _ptr(x, slo * frame_in), dw[kt])
+            # data gradient: one 27-tap launch
+            dd = self._desc(dt, _lib.QT_CONV_DGRAD, T, B, H, W)
+            dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
+            o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx))
+        o.check(o.L.qt_unpack_conv3d_wgrad(_ptr(dw), _ptr(dW), self.cout, self.cin, self.cout_p, self.cin_p,
+                                           1 if self.first else 0, _lib.stream_ptr()), "qt_unpack_conv3d_wgrad")
         return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
+
+
+def o_desc(dt, mode, images, h, w, k_per_tap, n_out, k, pad):
+    return _Ops.conv_desc(dt, mode, images, h, w, k_per_tap, n_out, k, pad)
 
 
 class _Lstm:

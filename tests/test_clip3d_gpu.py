@@ -22,7 +22,9 @@ import torch.nn.functional as F
 from _util import PKG, ROOT, check_summary, pkg, rel_err
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = {torch.float32: 1e-3, torch.bfloat16: 6e-2}
+# bf16: one rounding per Conv3d output now (27 taps accumulate in f32 inside ONE launch): measured 1.1e-3 .. 2.6e-3 on the
+# fixtures (rounds 1-2 summed three launches through the bf16 map and needed 6e-2)
+LOGIT_TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
 
 
 def _dev():
@@ -123,6 +125,64 @@ CASES = [("q3_t8", 2, 8, 112, "quadtree_3d_fusion", 31), ("q3_t5", 2, 5, 64, "qu
          ("q3_img_t8", 2, 8, 64, "quadtree_3d_image_only", 31), ("ji_t4", 2, 4, 64, None, 32)]
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 8, 64, 64, 28), (3, 5, 64, 128, 14), (1, 1, 128, 64, 16), (2, 4, 128, 256, 28)])
+def test_conv3d_as_one_27_tap_launch(dt, cfg):
+    """nn.Conv3d(3x3x3, padding 1) as ONE implicit GEMM over 27 taps (qt_conv_desc.kt = 3) on time-major clips: forward with
+    bias and BatchNorm3d statistics, and the data gradient, against torch CPU fp32 conv3d on the same (pre-rounded)
+    operands.  T = 1 (every neighbour frame masked), odd T, several clips per frame."""
+    dev = _dev()
+    L = pkg("_lib")
+    B, T, Cin, Cout, H = cfg
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(B, Cin, T, H, H, generator=g).to(dt).float()
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5).to(dt).float()
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv3d(x, w, bias, 1, 1)                                           # [B][Cout][T][H][H]
+    xd = x.permute(2, 0, 3, 4, 1).contiguous().to(dev, dt)                     # [T][B][H][W][C]
+    wf = w.permute(0, 2, 3, 4, 1).contiguous().to(dev, dt)                     # [O][kt][kh][kw][I]
+    wd = w.permute(1, 2, 3, 4, 0).contiguous().to(dev, dt)                     # [I][kt][kh][kw][O]
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+
+    def desc(mode, kin, kout):
+        d = L.ConvDesc()
+        d.dtype = L.qt_dtype(dt); d.mode = mode; d.batch = T * B
+        d.in_h = d.in_w = d.out_h = d.out_w = H
+        d.k_per_tap, d.n_out = kin, kout
+        d.kh = d.kw = 3; d.stride = 1; d.pad = 1
+        d.src_img_stride, d.src_row_stride, d.src_pix_stride = H * H * kin, H * kin, kin
+        d.kt, d.frames = 3, T
+        return d
+    d = desc(L.QT_CONV_FWD, Cin, Cout)
+    rows = L.lib().qt_conv2d_stats_rows(ctypes.byref(d))
+    y = torch.full((T * B * H * H, Cout), float("nan"), dtype=dt, device=dev)
+    st = torch.zeros(rows, 2, Cout, device=dev)
+    io = L.ConvIO(L.ptr(xd), L.ptr(wf), L.ptr(y), None, L.ptr(bias.to(dev)), None, None, L.ptr(st))
+    L.check(L.lib().qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()), "qt_conv2d_igemm kt=3")
+    torch.cuda.synchronize()
+    got = y.float().cpu().view(T, B, H, H, Cout).permute(1, 4, 0, 2, 3)
+    assert rel_err(got, ref) <= tol
+    # statistics of the raw accumulator (before the bias): sums of conv3d(x, w)
+    raw = ref - bias.view(1, -1, 1, 1, 1)
+    s = st.sum(0).cpu()
+    assert rel_err(s[0], raw.sum((0, 2, 3, 4))) <= 1e-3 + tol
+    assert rel_err(s[1], (raw * raw).sum((0, 2, 3, 4))) <= 1e-3 + tol
+    # data gradient
+    dy = torch.randn(B, Cout, T, H, H, generator=g).to(dt).float()
+    dxr = torch.nn.grad.conv3d_input((B, Cin, T, H, H), w, dy, 1, 1)
+    dyd = dy.permute(2, 0, 3, 4, 1).contiguous().to(dev, dt)
+    dd = desc(L.QT_CONV_DGRAD, Cout, Cin)
+    dx = torch.full((T * B * H * H, Cin), float("nan"), dtype=dt, device=dev)
+    io = L.ConvIO(L.ptr(dyd), L.ptr(wd), L.ptr(dx), None, None, None, None, None)
+    L.check(L.lib().qt_conv2d_igemm(ctypes.byref(dd), ctypes.byref(io), L.stream_ptr()), "qt_conv2d_igemm kt=3 dgrad")
+    torch.cuda.synchronize()
+    assert rel_err(dx.float().cpu().view(T, B, H, H, Cin).permute(1, 4, 0, 2, 3), dxr) <= tol
+    # frame taps are refused where they are not implemented
+    bad = desc(L.QT_CONV_FWD, Cin, Cout)
+    bad.frames = T + 1 if (T * B) % (T + 1) else 0
+    assert L.lib().qt_conv2d_igemm(ctypes.byref(bad), ctypes.byref(io), L.stream_ptr()) != 0
+
+
 def _build(mode, T, dt, dropout=0.0):
     P, synth = pkg(), pkg("synth")
     m = P.Ji3DCNN(12, sequence_length=T, dropout_rate=dropout, compute_dtype=dt) if mode is None else \
@@ -144,14 +204,16 @@ def test_clip_models_match_reference_golden(dt, tag, B, T, HW, mode, salt, golde
     m = _build(mode, T, dt).to(dev).eval()
     with torch.no_grad():
         logits = m(x.to(dev), f.to(dev))
+    print(f"{tag} {dt}: eval logits rel err {rel_err(logits.cpu(), g[f'{tag}/eval/logits']):.2e}")
     assert rel_err(logits.cpu(), g[f"{tag}/eval/logits"]) <= LOGIT_TOL[dt]
     m.train()
     out = m(x.to(dev), f.to(dev))
     loss = F.cross_entropy(out, y.to(dev))
     loss.backward()
     assert rel_err(out.detach().cpu(), g[f"{tag}/train/logits"]) <= LOGIT_TOL[dt]
-    assert abs(loss.item() - float(g[f"{tag}/train/loss"])) <= (1e-3 if dt == torch.float32 else 6e-2) * max(1.0, abs(float(g[f"{tag}/train/loss"])))
+    assert abs(loss.item() - float(g[f"{tag}/train/loss"])) <= (1e-3 if dt == torch.float32 else 2e-2) * max(1.0, abs(float(g[f"{tag}/train/loss"])))
     params = dict(m.named_parameters())
+    worst_cos = 1.0
     for name in [str(n) for n in g[f"{tag}/train/grad_names"]]:
         grad = params[name].grad
         assert grad is not None and torch.isfinite(grad).all(), name
@@ -173,7 +235,11 @@ def test_clip_models_match_reference_golden(dt, tag, B, T, HW, mode, salt, golde
             assert _cos(smp, gold_s) >= (0.9999 if head else 0.999), (name, _cos(smp, gold_s))
             assert float(np.abs(smp - gold_s).max()) <= (2e-3 if head else 6e-2) * max(float(np.abs(gold_s).max()), 1e-30), name
         else:
-            assert _cos(smp, gold_s) >= (0.98 if head else 0.8), (name, _cos(smp, gold_s))
+            cosv = _cos(smp, gold_s)
+            worst_cos = min(worst_cos, cosv) if not head else worst_cos
+            assert cosv >= (0.98 if head else 0.9), (name, cosv)
+    if dt == torch.bfloat16:
+        print(f"{tag} bf16: smallest cosine of a conv gradient against the reference {worst_cos:.4f}")
     bufs = dict(m.named_buffers())
     for k in g.files:
         if k.startswith(f"{tag}/train/buf/") and k.endswith("/shape"):
@@ -203,7 +269,7 @@ def test_quadtree3d_config4_size_matches_oracle():
         mm.train()
         loss = F.cross_entropy(mm(x.to(dev), f.to(dev)), y.to(dev))
         loss.backward()
-        assert abs(loss.item() - ref_loss.item()) <= (1e-3 if dt == torch.float32 else 6e-2) * max(1.0, abs(ref_loss.item()))
+        assert abs(loss.item() - ref_loss.item()) <= (1e-3 if dt == torch.float32 else 2e-2) * max(1.0, abs(ref_loss.item()))
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mm.parameters())
         del mm
         torch.cuda.empty_cache()
