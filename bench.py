@@ -45,7 +45,8 @@ FWD_BWD_GFLOP_PER_IMAGE = 11.0792   # BASELINE.md section 3 (all parameters trai
 FWD_GFLOP_PER_IMAGE = 3.7718
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
 # kernel families (scripts/summarize_profiles.py) behind roofline.achieved: forward + data-gradient conv launches
-ROOFLINE_FAMILIES = ("conv_igemm_kernel", "conv_pt_kernel", "conv_l1_ring_kernel", "conv_stem_kernel")
+ROOFLINE_FAMILIES = ("conv_igemm_kernel", "conv_pt_kernel", "conv_s2_kernel", "conv_l1_ring_kernel", "conv_stem_kernel",
+                     "conv_stem_pool_kernel", "linear_splitk_kernel")
 
 
 def kernel_sources_sha1():
@@ -338,6 +339,12 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # (single-rank rehearsal without a launcher: any free port)
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         # nccl == RCCL over xGMI.  QTCNN_DIST_BACKEND=gloo only exists to rehearse the
         # multi-process path with several ranks on ONE GPU (RCCL refuses duplicate devices).
         backend = os.environ.get("QTCNN_DIST_BACKEND", "nccl")
@@ -441,6 +448,9 @@ def main():
         torch.cuda.synchronize()
         fl, ms, ln = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int * 3)()
         L.qt_plan_profile_end(eng.handle, fl, ms, ln)
+        by = (ctypes.c_double * 3)()
+        L.qt_plan_profile_bytes.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        L.qt_plan_profile_bytes(eng.handle, by)
         # what the plan's three timing kinds aggregate (csrc/plan.hip begin_timed): every forward conv / linear launch,
         # every data-gradient launch, every weight-gradient launch -- whichever kernel family serves the layer
         kinds = ["forward conv launches (conv_stem / conv_l1_ring / conv_s2 / conv_pt / conv_igemm / linear_splitk)",
@@ -452,7 +462,8 @@ def main():
                 per[kinds[k]] = {"launches_per_step": ln[k] // args.profile_steps,
                                  "avg_us": round(1e3 * ms[k] / ln[k], 2),
                                  "gflop_per_launch": round(fl[k] / ln[k] / 1e9, 3),
-                                 "tflops": round(fl[k] / (ms[k] * 1e-3) / 1e12, 1)}
+                                 "tflops": round(fl[k] / (ms[k] * 1e-3) / 1e12, 1),
+                                 "algorithmic_mb_per_launch": round(by[k] / ln[k] / 1e6, 1)}
         nig = ln[0] + ln[1]
         if nig:
             ach = (fl[0] + fl[1]) / ((ms[0] + ms[1]) * 1e-3) / 1e12
@@ -469,16 +480,49 @@ def main():
             else:
                 traffic_src = src
             roofline = {"kernel": "forward + data-gradient conv launches (conv_pt_kernel for the 3x3 stride-1 layers of "
-                                  "layer2-4; conv_l1_ring_kernel for the 56x56 64->64 layers; conv_igemm_kernel for the "
-                                  "stride-2 transitions; conv_stem_kernel for conv1)",
+                                  "layer2-4; conv_l1_ring_kernel for the 56x56 64->64 layers; conv_s2_kernel for the stride-2 "
+                                  "transitions forward, conv_igemm_kernel for their data gradients; conv_stem_kernel for conv1)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": round((by[0] + by[1]) / nig),
+                        "algorithmic_bytes_note": "every operand of a launch once (source map, weights, destination, per-pixel "
+                                                  "epilogue operands), launch-weighted mean over the same launches as `traffic`",
                         "avg_launch_us": round(1e3 * (ms[0] + ms[1]) / nig, 2),
                         "gflop_per_launch": round((fl[0] + fl[1]) / nig / 1e9, 3),
                         "sum_of_launch_ms_per_step": round(sum(ms) / args.profile_steps, 3),
                         "sum_of_launch_ms_note": "sum of per-launch event times over TWO concurrent streams (weight "
                                                  "gradients run beside the main chain): not a serial time, may exceed ms_per_step",
                         "steps_profiled": args.profile_steps, "by_kernel": per}
+
+    if eng is None and args.model == "quadtree3d" and args.profile_steps > 0:
+        # no plan behind the clip models: the Conv3d launches (qt_conv2d_igemm with 27 taps, forward + data gradient) are
+        # timed per launch with HIP events on their stream in extra steps (video3d.py::_Ops.igemm)
+        v3d = importlib.import_module(PKG + ".video3d")
+        v3d.ops().timed = []
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        recs, v3d.ops().timed = v3d.ops().timed, None
+        if recs:
+            tot_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in recs)
+            tot_fl, tot_by = sum(r[2] for r in recs), sum(r[3] for r in recs)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            per = {}
+            for mode, nm in ((0, "forward Conv3d launches (conv_igemm_kernel, 27 taps; block 1: 1x1 over packed K rows)"),
+                             (1, "data-gradient Conv3d launches (conv_igemm_kernel, 27 taps)")):
+                sel = [r for r in recs if r[4] == mode]
+                if sel:
+                    msk = sum(a.elapsed_time(b) for a, b, _, _, _ in sel)
+                    per[nm] = {"launches_per_step": len(sel) // args.profile_steps, "avg_us": round(1e3 * msk / len(sel), 1),
+                               "tflops": round(sum(r[2] for r in sel) / (msk * 1e-3) / 1e12, 1),
+                               "algorithmic_mb_per_launch": round(sum(r[3] for r in sel) / len(sel) / 1e6, 1)}
+            roofline = {"kernel": "Conv3d launches of the step (one 27-tap implicit GEMM per convolution and direction)",
+                        "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": None, "traffic_source": "no PMC pass collected for this model",
+                        "algorithmic_bytes_per_launch": round(tot_by / len(recs)), "avg_launch_us": round(1e3 * tot_ms / len(recs), 1),
+                        "gflop_per_launch": round(tot_fl / len(recs) / 1e9, 3), "steps_profiled": args.profile_steps,
+                        "by_kernel": per}
 
     # whole-step HBM traffic / matrix-pipe busy cycles from the committed PMC summaries of the same command
     # (scripts/collect_profiles.sh, scripts/collect_mfma_busy.sh) against THIS run's step time -- only from summaries
@@ -533,8 +577,20 @@ def main():
                    "value": round(fps, 1), "unit": "images/s", "ms_per_batch": round(1e3 * ft / nf, 3), "passes": nf,
                    "gflop_per_image": fwd_gflop,
                    "model_mfma_util": round(fwd_gflop * fps / world / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
-                   "target": "north star: >= 0.60 at bs 256 (<= 0.643 ms)"}
+                   "target": "north star: >= 0.60 at bs 256 (<= 0.643 ms)" if args.model == "quadtree" else
+                             "secondary line (SURVEY.md 8f): no target of its own"}
         model.train()
+    # what the process group really is (a later SCALE line checks itself): backend, ranks, bytes / buckets reduced per step
+    dp_info = None
+    if dist is not None:
+        red = getattr(model, "_grad_sync", None)
+        steps_done = args.warmup + args.steps + (args.profile_steps if roofline is not None else 0)
+        dp_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                   "rccl": dist.get_backend() == "nccl",
+                   "gradient_bytes_per_step": int(red.bytes_reduced // max(1, steps_done)) if red is not None else None,
+                   "buckets_per_step": getattr(red, "buckets_per_step", None),
+                   "bucket_order": getattr(red, "bucket_log", None),
+                   "average": "ncclAvg on the communication stream, joined once at the end of backward"}
     if dist is not None:
         dist.barrier()
     if rank != 0:
@@ -586,6 +642,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "model_mfma_util": round(gflop_img * value / world / 1e3 / MFMA_PEAK_TFLOPS[args.dtype], 4),
         "forward": forward,
+        "data_parallel": dp_info,
         "roofline": roofline,
         "mfma_pmc": mfma_pmc,
         "hbm": hbm,

@@ -544,6 +544,9 @@ int qt_plan_find_buffer(const qt_plan* plan, const char* name, size_t* offset);
  * and launch counts per kind {0 igemm forward, 1 igemm dgrad, 2 wgrad}. */
 int qt_plan_profile_begin(qt_plan* plan);
 int qt_plan_profile_end(qt_plan* plan, double* flops3, double* ms3, int* launches3);
+/* algorithmic HBM bytes of the launches of the last profile, per kind: every operand of a launch once (source map,
+ * weights, destination, per-pixel epilogue operands) -- the figure bench.py puts beside the PMC-measured traffic */
+int qt_plan_profile_bytes(const qt_plan* plan, double* bytes3);
 /* Weight gradients run on a plan-owned side stream; a partial qt_plan_backward phase returns
  * without joining it.  Before consuming that phase's gradients on another stream (the
  * all-reduce stream), make it wait for the side stream with qt_plan_side_fence (and for the

@@ -117,7 +117,8 @@ struct qt_plan {
   int bwd_rows_bn2 = 0;  // carried from the layer4 phase to the rest-of-backbone phase  // BatchNorm-backward partials emitted by dgrad epilogues
   // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events on
   // the launch stream around every igemm / wgrad launch while enabled
-  struct Timed { hipEvent_t a, b; double flops; int kind; };
+  struct Timed { hipEvent_t a, b; double flops; double bytes; int kind; };
+  double last_profile_bytes[3] = {0, 0, 0};   // algorithmic HBM bytes per kind of the last profile (each operand once)
   bool profiling = false;
   std::vector<Timed> timed;
   // weight gradients run on a plan-owned side stream, concurrently with the BatchNorm /
@@ -588,7 +589,7 @@ struct Exec {
       io.bwd_bn[k].y = links[k].y; io.bwd_bn[k].mean = links[k].mean;
       io.bwd_bn[k].invstd = links[k].invstd; io.bwd_bn[k].partial = links[k].partial;
     }
-    const int slot = begin_timed(conv_flops(d), kind >= 0 ? kind : (d.mode == QT_CONV_FWD ? 0 : 1));
+    const int slot = begin_timed(conv_flops(d), kind >= 0 ? kind : (d.mode == QT_CONV_FWD ? 0 : 1), nullptr, conv_bytes(dd, io));
     run(qt_conv2d_igemm(&dd, &io, stream));
     end_timed(slot);
   }
@@ -599,7 +600,8 @@ struct Exec {
   void linear(const qt_conv_desc& d, const void* x, const void* w, void* y, const float* bias, int relu) {
     if (!ok()) return;
     if (dt == QT_BF16 && B <= 256) {
-      const int slot = begin_timed(conv_flops(d), d.mode == QT_CONV_FWD ? 0 : 1);
+      const int slot = begin_timed(conv_flops(d), d.mode == QT_CONV_FWD ? 0 : 1, nullptr,
+                                   2.0 * ((double)B * d.k_per_tap + (double)d.k_per_tap * d.n_out + (double)B * d.n_out));
       const int st = qt_linear_bf16(x, w, bias, relu, y, B, d.n_out, d.k_per_tap, at(p->lin_ws), p->lin_ws_bytes, stream);
       end_timed(slot);
       if (st == QT_OK) return;
@@ -621,11 +623,30 @@ struct Exec {
     const double k = stem ? 147.0 : (d.dst_merge ? 9.0 / 4.0 : (double)d.kh * d.kw) * d.k_per_tap;
     return 2.0 * imgs * fwd_pixels * k * d.n_out;
   }
-  int begin_timed(double flops, int kind, void* on = nullptr) {
+  // algorithmic HBM bytes of a conv launch: source map, weights, destination and every per-pixel epilogue operand, each once
+  double conv_bytes(const qt_conv_desc& d, const qt_conv_io& io) const {
+    const double es = d.dtype == QT_F32 ? 4.0 : 2.0;
+    const double imgs = (double)d.batch * (d.mode == QT_CONV_FWD ? 1.0 : 1.0);
+    const bool stem = d.k_per_tap == 32 && d.kw == 1 && d.stride == 2 && d.n_out == 64;
+    const double regions = qt_quad_regions(d.quad);
+    const double src = stem ? imgs * d.in_h * d.in_w * 4.0 * es
+                            : imgs * regions * (double)d.in_h * d.in_w * d.k_per_tap * es;
+    const double rows = d.dst_merge ? imgs * (double)d.dst_h * d.dst_w : imgs * (d.mode == QT_CONV_FWD ? regions : 1.0) * d.out_h * d.out_w;
+    const double ncol = d.dst_merge ? d.dst_merge : d.n_out;
+    double per_pixel = 1.0;   // dst
+    if (io.residual) per_pixel += d.dst_merge_res0 ? 0.25 : 1.0;
+    if (io.relu_mask) per_pixel += 1.0;
+    if (io.bwd_bn[0].y) per_pixel += 1.0;
+    if (io.bwd_bn[1].y) per_pixel += 1.0;
+    const double wgt = (double)d.kh * d.kw * d.k_per_tap * d.n_out * es;
+    return src + wgt + rows * ncol * es * per_pixel;
+  }
+  int begin_timed(double flops, int kind, void* on = nullptr, double bytes = 0.0) {
     if (!p->profiling) return -1;
     qt_plan::Timed t;
     if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
     t.flops = flops;
+    t.bytes = bytes;
     t.kind = kind;
     (void)hipEventRecord(t.a, static_cast<hipStream_t>(on ? on : stream));
     p->timed.push_back(t);
@@ -684,7 +705,10 @@ struct Exec {
       io.stats_conv = at<float>(p->stats);
       io.stats_down = at<float>(p->stats_ds);
     }
-    const int slot = begin_timed(conv_flops(conv_desc(c1, QT_CONV_FWD)) + conv_flops(conv_desc(cd, QT_CONV_FWD)), 0);
+    const double es = dt == QT_F32 ? 4.0 : 2.0;
+    const int slot = begin_timed(conv_flops(conv_desc(c1, QT_CONV_FWD)) + conv_flops(conv_desc(cd, QT_CONV_FWD)), 0, nullptr,
+                                 es * ((double)B * c1.hin * c1.hin * c1.cin + 2.0 * B * c1.hout * c1.hout * c1.cout +
+                                       10.0 * c1.cin * c1.cout));
     run(qt_conv_s2_pair(&d, &io, stream));
     end_timed(slot);
     if (training == 1 && ok()) {
@@ -893,7 +917,8 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
                          e.at<unsigned char>(p->argmax), e.at(p->ymax), batch, stream));
     } else {
       // eval: conv1 + folded bn1 + ReLU + max pool in one kernel (bf16); the conv1 map is not materialised
-      const int slot = e.begin_timed(e.conv_flops(sd), 0);
+      const int slot = e.begin_timed(e.conv_flops(sd), 0, nullptr,
+                                     (double)batch * p->esz * ((double)QT_STEM_PAD_H * QT_STEM_PAD_W * 4 + 56.0 * 56 * 64));
       const int fused = qt_stem_conv_pool(dt, e.at(p->xpad), e.at(c0.w_fwd), e.stem_taps(), e.at<float>(bn0.scale),
                                           e.at<float>(bn0.shift), e.at(p->p0), batch, stream);
       e.end_timed(slot);
@@ -1132,6 +1157,11 @@ struct Bwd : Exec {
     }
     return rows;
   }
+  double wgrad_bytes(const ConvL& c, const qt_conv_desc& f) const {
+    const double es = dt == QT_F32 ? 4.0 : 2.0, imgs = (double)f.batch * qt_quad_regions(f.quad);
+    return es * imgs * ((double)f.in_h * f.in_w * f.k_per_tap + (double)f.out_h * f.out_w * f.n_out) +
+           4.0 * f.kh * f.kw * f.k_per_tap * f.n_out;
+  }
   // weight gradient of conv c: dy = c.gy, x = src
   void wgrad(const ConvL& c, const qt_conv_desc& fwd_desc, const void* src, bool stem) {
     if (!ok() || !gf(c.w)) return;
@@ -1140,12 +1170,12 @@ struct Bwd : Exec {
     const size_t n = stem ? (size_t)64 * 7 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
     if (!stem && c.k == 1) {  // [O][1][I] is already OIHW
       run(zero(gf(c.w), n * 4, ws_));
-      const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);
+      const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_, wgrad_bytes(c, fwd_desc));
       run(qt_conv2d_wgrad(&fwd_desc, at(c.gy), src, gf(c.w), ws_));
       end_timed(slot, ws_);
       return;
     }
-    const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_);  // c.dw was zeroed at the start of this backward
+    const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_, wgrad_bytes(c, fwd_desc));  // c.dw was zeroed at the start of this backward
     if (!stem && qt_conv2d_wgrad_workspace_bytes(&fwd_desc) > 0) {
       // streaming kernel: the partial-filter sum writes .grad in OIHW directly
       run(qt_conv2d_wgrad_oihw(&fwd_desc, at(c.gy), src, gf(c.w), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
@@ -1606,7 +1636,7 @@ extern "C" int qt_plan_profile_begin(qt_plan* p) {
 extern "C" int qt_plan_profile_end(qt_plan* p, double* flops, double* ms, int* launches) {
   QT_CHECK_ARG(p && flops && ms && launches, "qt_plan_profile_end: null argument");
   p->profiling = false;
-  for (int k = 0; k < 3; ++k) { flops[k] = 0; ms[k] = 0; launches[k] = 0; }
+  for (int k = 0; k < 3; ++k) { flops[k] = 0; ms[k] = 0; launches[k] = 0; p->last_profile_bytes[k] = 0; }
   int st = QT_OK;
   for (auto& t : p->timed) {
     float dt = 0.f;
@@ -1615,11 +1645,19 @@ extern "C" int qt_plan_profile_end(qt_plan* p, double* flops, double* ms, int* l
       st = QT_ERR_LAUNCH;
     } else if (t.kind >= 0 && t.kind < 3) {
       flops[t.kind] += t.flops; ms[t.kind] += dt; launches[t.kind] += 1;
+      p->last_profile_bytes[t.kind] += t.bytes;
     }
     (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
   }
   p->timed.clear();
   return st;
+}
+
+// algorithmic HBM bytes (each operand of a launch once) summed per kind over the launches of the last qt_plan_profile_end
+extern "C" int qt_plan_profile_bytes(const qt_plan* p, double* bytes3) {
+  QT_CHECK_ARG(p && bytes3, "qt_plan_profile_bytes: null argument");
+  for (int k = 0; k < 3; ++k) bytes3[k] = p->last_profile_bytes[k];
+  return QT_OK;
 }
 
 // Make `waiting_stream` wait for everything enqueued so far on the plan's side stream (the

@@ -38,14 +38,22 @@ class GradBucketReducer:
         self.comm_stream = None
         self.bytes_reduced = 0
         self.force = False  # exercise the collective even with one rank (rehearsal)
+        self.bucket_log = []        # (phase, bytes) of the first step's buckets, in hand-over order
+        self.buckets_per_step = 0
+        self._first_step_open = True
         self._avg_ok = dist.get_backend(process_group) == "nccl"
 
     def __call__(self, bucket, phase, side_fence=None):
         if bucket is None:
+            if self._first_step_open and self.bucket_log:
+                self._first_step_open = False
+                self.buckets_per_step = len(self.bucket_log)
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
             return
         self.bytes_reduced += bucket.numel() * bucket.element_size()
+        if self._first_step_open:
+            self.bucket_log.append([int(phase), int(bucket.numel() * bucket.element_size())])
         if self.world == 1 and not self.force:
             return
         if bucket.is_cuda:

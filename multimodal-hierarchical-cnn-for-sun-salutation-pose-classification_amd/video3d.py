@@ -59,6 +59,7 @@ class _Ops:
         L.qt_stats_capacity_rows.restype = _c.c_int
         L.qt_conv2d_wgrad_workspace_bytes.restype = _c.c_size_t
         self._wgrad_ws = None
+        self.timed = None   # list while bench.py profiles: (start event, end event, algorithmic flops, bytes, mode) per conv launch
         L.qt_bn_stats_rows.argtypes = [_c.c_longlong, _c.c_int]
         L.qt_bn_bwd_partial_rows.argtypes = [_c.c_longlong, _c.c_int]
 
@@ -79,10 +80,17 @@ class _Ops:
         d.src_img_stride, d.src_row_stride, d.src_pix_stride = h * w * k_per_tap, w * k_per_tap, k_per_tap
         return d
 
-    def igemm(self, d, src, w, dst, scale=None, shift=None, residual=None, relu=0, stats=None):
+    def igemm(self, d, src, w, dst, scale=None, shift=None, residual=None, relu=0, stats=None, flops=0.0, nbytes=0.0):
         d.relu = relu
         io = _lib.ConvIO(src, w, dst, _ptr(scale), _ptr(shift), residual, None, _ptr(stats))
+        ev = None
+        if self.timed is not None:   # bench.py's roofline: HIP events on the launch stream (= torch's current stream here)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self.check(self.L.qt_conv2d_igemm(_c.byref(d), _c.byref(io), _lib.stream_ptr()), "qt_conv2d_igemm")
+        if ev is not None:
+            ev[1].record()
+            self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(d.mode)))
 
     def wgrad(self, d, dy, x, dw):
         """dw [n_out][taps][k_per_tap] f32 (zeroed by the caller).  Where the tile-resident kernel covers the shape (bf16,
@@ -246,13 +254,17 @@ class _ConvBlock:
         d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
         y = torch.empty(rows, self.cout_p, dtype=dt, device=dev)
         fused_eval = not training and not keep   # eval without backward: BatchNorm3d + ReLU in the conv epilogue, no second pass
+        esz = 2 if dt == torch.bfloat16 else 4
+        fl = 2.0 * rows * 27 * self.cin * self.cout            # algorithmic: the Conv3d as the reference computes it
+        nb = esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p)
+        tk = dict(flops=fl, nbytes=nb)
         if training:
             prow = o.L.qt_conv2d_stats_rows(_c.byref(d))
             part = torch.empty(o.L.qt_stats_capacity_rows(prow), 2, self.cout_p, dtype=torch.float32, device=dev)
             # Under batch statistics BatchNorm3d(conv + bias) = BatchNorm3d(conv): a per-channel constant moves the mean with it.
             # y holds the bias-free accumulator and the epilogue's statistics are of exactly that value; the bias only enters
             # the running mean the reference tracks (mean of conv + bias), added below.
-            o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), stats=part)
+            o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), stats=part, **tk)
             stats = o.bn_finalize(part, prow, rows, self.cout_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p,
                                   self.bn.num_batches_tracked, dev)
             self.rmean_p.add_(self.bias_p, alpha=BN_MOMENTUM)
@@ -262,9 +274,9 @@ class _ConvBlock:
             stats = o.bn_eval(self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, self.cout_p, dev)
             if fused_eval:   # relu(scale * (conv + bias) + shift)
                 shift = torch.addcmul(stats[3], stats[2], self.bias_p)
-                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), scale=stats[2], shift=shift, relu=1)
+                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), scale=stats[2], shift=shift, relu=1, **tk)
             else:
-                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), shift=self.bias_p)
+                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), shift=self.bias_p, **tk)
         if fused_eval:
             a = y
         else:
@@ -329,7 +341,8 @@ class _ConvBlock:
             # data gradient: one 27-tap launch
             dd = self._desc(dt, _lib.QT_CONV_DGRAD, T, B, H, W)
             dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
-            o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx))
+            o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx), flops=2.0 * rows * 27 * self.cin * self.cout,
+                    nbytes=esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p))
         o.check(o.L.qt_unpack_conv3d_wgrad(_ptr(dw), _ptr(dW), self.cout, self.cin, self.cout_p, self.cin_p,
                                            1 if self.first else 0, _lib.stream_ptr()), "qt_unpack_conv3d_wgrad")
         return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
