@@ -22,6 +22,8 @@
 // with the padded position decoded back to the dense row.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "qt_common.h"
 
 namespace {
@@ -692,6 +694,19 @@ if (p.scale || p.shift) {  // (uniform)
 // with each other's MFMAs.  A ping-pong cut of this layer needs tile-invariant addressing (whole-row tiles as conv_pt.hip:
 // per-lane offsets + a scalar origin) and an epilogue spread over the segments behind a second accumulator set -- a
 // different kernel, not this one with barriers moved.
+// A SECOND ping-pong cut, built on those lessons, was measured and removed as well (never committed; its numbers are in
+// gpurun_out/r03r_*.json, r03s_l1ab.log and DESIGN.md): whole-row
+// tiles (4 rows of a 56-wide image per tile: tile-invariant addressing, one image per workgroup), filter resident (taps 0-7
+// in LDS, tap 8 in registers), two accumulator sets with the epilogue of tile k-1 spread over the load segments of tile k,
+// residual slices requested by inline-asm loads behind counted waits; bit-identical outputs.  Alone (forward, 256 images):
+// 97-100 us against 69-76 us for this kernel (113-120 against 85-94 with a residual).  Ablation: fragment reads +
+// barriers + prologue 42 us; + MFMAs 54 us; + patch DMA 74-80 us; + epilogue 97-100 us.  Two conclusions: (i) even with
+// DMA and epilogue hidden completely the read / MFMA skeleton of a 64-channel tile (24 fragment reads per 32 MFMAs, one
+// barrier pair per two taps) is 54 us -- the gain over this kernel would be 15-20 us; (ii) they do not hide: a wave's
+// ~320 vector instructions per tile (epilogue, accumulator clearing, addresses) issue at half rate beside the partner's
+// MFMAs and exceed the partner's 2,300 MFMA cycles.  The 64 -> 64 layer has too few MFMAs per staged byte and per output
+// element for the two-group schedule; this lockstep kernel (two waves per SIMD overlapping each other's vector work)
+// stays the layer1 kernel.
 inline int l1_ring_grid(long long Q) {
   const int ntiles = qt_cdiv(Q, BM);
   return ntiles < 256 ? ntiles : 256;
@@ -713,6 +728,7 @@ int launch_l1_ring(PatchArgs a, hipStream_t stream) {
 
 
 // Shapes this kernel takes over from the generic implicit GEMM (see qt_conv2d_igemm).
+
 // Mostly off by default (mode 2 = ring kernel only): measured on MI355X (B=256, bf16) it only ties the generic kernel
 // (layer1 127 vs 119 us, layer2 109 vs 100 us): with one 8-wave workgroup per CU the load,
 // MFMA and epilogue phases of a tile do not overlap, while the generic kernel runs two
