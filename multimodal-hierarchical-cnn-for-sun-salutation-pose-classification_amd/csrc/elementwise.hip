@@ -683,37 +683,50 @@ __global__ void quad_pool_kernel(const T* __restrict__ q, T* __restrict__ dst, i
   }
 }
 
+// One thread per (region image, 2x2 pooling window, 8 channels): the four window pixels are read and written as 16-byte
+// vectors (the round-1 kernel was one thread per ELEMENT with four scalar loads each: 65 us in the train step for 40 MB);
+// the 13 pixels of row / column 6, which MaxPool2d(2,2) drops on a 7x7 map, get their zeros from 13 more items per image.
 template <typename T>
 __global__ void quad_pool_bwd_kernel(const T* __restrict__ d, const T* __restrict__ q, T* __restrict__ dq, int batch,
                                      int ld, int col0) {
-  constexpr int C = 128;
-  const int total = batch * 4 * 49 * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int c = i % C;
-    const int pix = (i / C) % 49;
-    const int img = i / (C * 49);
-    const int h = pix / 7, w = pix % 7;
-    float out = 0.f;
-    if (h < 6 && w < 6) {
-      const int ph = h >> 1, pw = w >> 1;
-      const T* s = q + (((long long)img * 7 + ph * 2) * 7 + pw * 2) * C + c;
-      const float v0 = qt_to_f32<T>(s[0]), v1 = qt_to_f32<T>(s[C]), v2 = qt_to_f32<T>(s[7 * C]),
-                  v3 = qt_to_f32<T>(s[8 * C]);
-      int am = 0;
-      float best = v0;
-      if (v1 > best) { best = v1; am = 1; }
-      if (v2 > best) { best = v2; am = 2; }
-      if (v3 > best) { best = v3; am = 3; }
-      const int me = (h & 1) * 2 + (w & 1);
-      if (am == me && best > 0.f) {  // best > 0: ReLU passes gradient
-        const int b = img >> 2, quad = img & 3;
-        out = qt_to_f32<T>(d[(long long)b * ld + col0 + quad * 1152 + c * 9 + ph * 3 + pw]);
-      }
+  constexpr int C = 128, G = C / 8, ITEMS = (9 + 13) * G;   // per region image
+  const long long total = (long long)batch * 4 * ITEMS;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int img = (int)(i / ITEMS), r = (int)(i - (long long)img * ITEMS);
+    const int g = r % G, k = r / G;
+    const int c0 = g * 8;
+    float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k >= 9) {   // the dropped row / column: pixels (6, 0..6) and (0..5, 6)
+      const int e = k - 9;
+      const int h = e < 7 ? 6 : e - 7, w = e < 7 ? e : 6;
+      QtVec8<T>::store(dq + (((long long)img * 7 + h) * 7 + w) * C + c0, z);
+      continue;
     }
-    if constexpr (sizeof(T) == 4)
-      dq[i] = out;
-    else
-      dq[i] = (bf16_t)out;
+    const int ph = k / 3, pw = k - ph * 3;
+    const long long base = (((long long)img * 7 + ph * 2) * 7 + pw * 2) * C + c0;
+    float v[4][8];
+    QtVec8<T>::load(q + base, v[0]);
+    QtVec8<T>::load(q + base + C, v[1]);
+    QtVec8<T>::load(q + base + 7 * C, v[2]);
+    QtVec8<T>::load(q + base + 8 * C, v[3]);
+    const int b = img >> 2, quad = img & 3;
+    const T* dp = d + (long long)b * ld + col0 + quad * 1152 + ph * 3 + pw;
+    float o[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int am = 0;
+      float best = v[0][e];
+      if (v[1][e] > best) { best = v[1][e]; am = 1; }
+      if (v[2][e] > best) { best = v[2][e]; am = 2; }
+      if (v[3][e] > best) { best = v[3][e]; am = 3; }
+      const float gd = best > 0.f ? qt_to_f32<T>(dp[(c0 + e) * 9]) : 0.f;   // best > 0: ReLU passes gradient
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m][e] = m == am ? gd : 0.f;
+    }
+    QtVec8<T>::store(dq + base, o[0]);
+    QtVec8<T>::store(dq + base + C, o[1]);
+    QtVec8<T>::store(dq + base + 7 * C, o[2]);
+    QtVec8<T>::store(dq + base + 8 * C, o[3]);
   }
 }
 
@@ -1087,7 +1100,7 @@ extern "C" int qt_quad_pool_bwd(int dtype, const void* d, const void* q, void* d
   hipStream_t s = static_cast<hipStream_t>(stream);
   by_dtype(dtype, [&](auto tag) {
     using T = QT_T(tag);
-    hipLaunchKernelGGL(quad_pool_bwd_kernel<T>, dim3(grid_for((long long)batch * 4 * 49 * 128)), dim3(256), 0, s,
+    hipLaunchKernelGGL(quad_pool_bwd_kernel<T>, dim3(grid_for((long long)batch * 4 * 22 * 16)), dim3(256), 0, s,
                        (const T*)d, (const T*)q, (T*)dq, batch, ld, col0);
   });
   QT_CHECK_LAUNCH();
