@@ -676,6 +676,7 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
     a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.dst_sub = d->dst_sub;
     a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
     a.src_img_stride = d->src_img_stride; a.src_row_stride = d->src_row_stride; a.src_pix_stride = d->src_pix_stride;
+    a.dst_merge = d->dst_merge; a.dst_h = d->dst_h; a.dst_w = d->dst_w;
     if (!kt3 && qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
   }
   const int rows = qt_cdiv(M, tile_m(M, d->n_out, (kt3 ? d->kt : 1) * d->kh * d->kw * d->k_per_tap * esz / kRowBytes));

@@ -62,7 +62,7 @@ struct PtArgs {
   // n*4 + q is quadrant q of map n.  1: forward, the SOURCE is the un-split map (zero halo at the seam comes for free:
   // the patch's pad positions); 2: data gradient, the DESTINATION is the un-split map.
   int quad;
-  FastDiv div_pw;
+  FastDiv div_pw, div_hw, div_w;   // (div_hw / div_w: merged destination mapping)
 };
 
 // eight consecutive elements as loaded (decoded to f32 only where they are consumed)
@@ -129,10 +129,38 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD>
+// patch passes of the NEXT chunk issued in the L segment of tap `tap`: all of them no later than (and, inside their segment,
+// before) weight tile 0 of the next chunk, which is issued in L_{NTAPS-D}.  Nine taps: one pass on each of the first NPASS
+// taps; four taps (the merged stride-2 data gradient): two on the first one or two taps, one on the next.
+template <int NTAPS, int NPASS, int D>
+constexpr int passes_in(int tap) {
+  if (NTAPS == 9) return tap < NPASS ? 1 : 0;
+  const int slots = NTAPS - D + 1;                       // segments 0 .. NTAPS-D
+  if (tap >= slots) return 0;
+  const int base = NPASS / slots, extra = NPASS - base * slots;
+  return base + (tap < extra ? 1 : 0);
+}
+template <int NTAPS, int NPASS, int D>
+constexpr int passes_before(int tap) {
+  int n = 0;
+  for (int t = 0; t < tap; ++t) n += passes_in<NTAPS, NPASS, D>(t);
+  return n;
+}
+
+// NTAPS = 9: the 3x3 / stride-1 convolution (forward, or with DGRAD its data gradient: taps mirrored).
+// NTAPS = 4 ("merged"): the data gradient of a 3x3 / STRIDE-2 convolution as one 2x2-tap gather over the gradient map
+// (qt_conv_desc.dst_merge, operand qt_pack_dgrad_s2_merged): the window (r..r+1, c..c+1) = taps (1,1) (1,2) (2,1) (2,2) of
+// this kernel's pad-1 numbering, the 4 C output channels are the four parity classes of destination pixel
+// (2r + class/2, 2c + class%2) of the C-channel map, where residual / mask / BatchNorm links are read.  All four slots are
+// multiplied for every class (the slots a class does not use hold zero weights: 16/9 of the products) -- still 2-3 x
+// faster than the generic tile on these short-K launches.
+template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9>
 __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
-  static_assert(NPASS >= 1 && NPASS <= kMaxPass && NPASS - 1 <= 9 - (NBW - 1),
+  static_assert(NTAPS == 9 || (NTAPS == 4 && !DGRAD && BN == 128 && NBW == 3), "tap sets");
+  static_assert(NPASS >= 1 && NPASS <= kMaxPass && (NTAPS != 9 || NPASS - 1 <= 9 - (NBW - 1)),
                 "the last patch pass is issued no later than (and, in its L segment, before) weight tile 0 of the next chunk");
+  constexpr bool MERGE = NTAPS == 4;
+  constexpr bool BWD = DGRAD || MERGE;      // which epilogue the instantiation carries
   static_assert(BN == 128 || BN == 256, "channel tile");
   static_assert(NBW == 3 || NBW == 4, "weight ring slots");
   constexpr int TM = GEO == GEO_STACK ? 8 : 7;   // 16-row tiles per wave (two wave rows)
@@ -171,9 +199,10 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   // per-channel vectors of the epilogue ([6][N] f32: scale, shift, mean / invstd of two BatchNorm links) in LDS: an
   // epilogue in the middle of the K-tile stream must not wait for global loads behind the DMA queue
   float* aff = reinterpret_cast<float*>(smem + 2 * patch_bytes + NBW * WSLOT);
+  const int NC = MERGE ? p.dst_merge : p.N;     // channels of the per-channel vectors (merged: of the destination map)
   if constexpr (AFF_LDS) {
-    for (int i = tid; i < 6 * p.N; i += kNT) {
-      const int v = i / p.N, c = i - v * p.N;
+    for (int i = tid; i < 6 * NC; i += kNT) {
+      const int v = i / NC, c = i - v * NC;
       const float* src = v == 0 ? p.scale : v == 1 ? p.shift : v == 2 ? p.bn_mean[0] : v == 3 ? p.bn_invstd[0]
                                                                     : v == 4 ? p.bn_mean[1] : p.bn_invstd[1];
       aff[i] = src ? src[c] : (v == 0 ? 1.f : 0.f);
@@ -242,12 +271,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
     const int rho = rbase + 64 * i;
     const int x = rho & 15, ii = (rho >> 4) & 1;
     const int n = (rho & ~31) + 8 * (x >> 2) + 4 * ii + (x & 3);
-    w_off[i] = (unsigned)(n * (9 * p.KC) + ce) * (unsigned)sizeof(T);    // N % BN == 0 (checked by the launcher)
+    w_off[i] = (unsigned)(n * (NTAPS * p.KC) + ce) * (unsigned)sizeof(T);    // N % BN == 0 (checked by the launcher)
   }
   const i32x4 rs_src = make_rsrc(static_cast<const unsigned char*>(p.src) -
                                      (GEO == GEO_ROWS ? (long long)p.src_row_stride * (int)sizeof(T) : 0ll), q.src_bytes),
               rs_wgt = make_rsrc(p.wgt, q.wgt_bytes);
-  const unsigned wtile_bytes = (unsigned)((long long)BN * 9 * p.KC * (int)sizeof(T));   // filters of one channel tile
+  const unsigned wtile_bytes = (unsigned)((long long)BN * NTAPS * p.KC * (int)sizeof(T));   // filters of one channel tile
   const unsigned tap_bytes = (unsigned)(p.KC * (int)sizeof(T));
 
   // rows [pass*64, pass*64+64) of a chunk into patch buffer `buf` (`off` = this thread's pp_off[pass], `coff` = the
@@ -294,8 +323,15 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
-  const bool bwd_stats = DGRAD && p.bn_y[0] != nullptr;
-  const bool want_stats = DGRAD ? bwd_stats : p.stats_partial != nullptr;
+  const bool bwd_stats = BWD && p.bn_y[0] != nullptr;
+  const bool want_stats = BWD ? bwd_stats : p.stats_partial != nullptr;
+  // merged classes: dense pixel index of the gradient map -> pixel (2r + class/2, 2c + class%2) of the destination map
+  auto merged_row = [&](int dr, int cls) -> long long {
+    const unsigned img = fdiv((unsigned)dr, q.div_hw);
+    const unsigned rem = (unsigned)dr - img * (unsigned)(q.H * q.W);
+    const unsigned r = fdiv(rem, q.div_w), c = rem - r * (unsigned)q.W;
+    return ((long long)img * p.dst_h + 2 * r + (cls >> 1)) * p.dst_w + 2 * c + (cls & 1);
+  };
 
   for (int it = item_begin; it < item_end; ++it) {
     const bool nlive = PERSIST && it + 1 < item_end;
@@ -327,18 +363,24 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
       // first D-1 K-tiles of an item need was waited for in front of that epilogue (below)
       const bool after_epilogue = cidx == 0 && it != item_begin;
       const unsigned char* patch = smem + pb * patch_bytes;
-      static_for<9>([&](auto tap_tag) {
+      static_for<NTAPS>([&](auto tap_tag) {
         constexpr int tap = decltype(tap_tag)::value;
         // ---- L_t ----
-        if constexpr (tap < NPASS) dma_patch_pass(rs_src_n, tap, pass_off(tap < NPASS ? tap : 0, n_top, n_bot), n_psoff, pb ^ 1);
         {
-          constexpr int u = (tap + D) % 9;
-          constexpr bool wrap = tap + D >= 9;
+          constexpr int np = passes_in<NTAPS, NPASS, D>(tap), p0 = passes_before<NTAPS, NPASS, D>(tap);
+          static_for<np>([&](auto pass_tag) {
+            constexpr int ps = p0 + decltype(pass_tag)::value;
+            dma_patch_pass(rs_src_n, ps, pass_off(ps, n_top, n_bot), n_psoff, pb ^ 1);
+          });
+        }
+        {
+          constexpr int u = (tap + D) % NTAPS;
+          constexpr bool wrap = tap + D >= NTAPS;
           dma_weights(wrap ? rs_wgt_n : rs_wgt, (wrap ? n_woff : c_woff) + (unsigned)u * tap_bytes, wr);
         }
         wr = wr + 1 == NBW ? 0 : wr + 1;
         // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
-        const int kh = tap / 3, kw = tap % 3;
+        const int kh = MERGE ? (tap >> 1) + 1 : tap / 3, kw = MERGE ? (tap & 1) + 1 : tap % 3;
         const int pitch = GEO == GEO_STACK ? 8 : q.PW;
         int sh = (DGRAD ? ((2 - kh) * pitch + (2 - kw)) : (kh * pitch + kw)) * kKB;   // bytes
         // (opaque to the optimiser: otherwise the 7 x 9 fragment addresses, invariant across chunks, are hoisted out
@@ -365,8 +407,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
         // L_{t+2-D} .. L_t (vmcnt retires in issue order; at a chunk boundary this also covers the next patch, whose
         // last pass was issued on tap NPASS-1 < 9-D, i.e. before weight tile t+1 of tap 8).
-        constexpr int in_t = (tap < NPASS ? 1 : 0) + RW;
-        constexpr int in_tm1 = ((tap + 8) % 9 < NPASS ? 1 : 0) + RW;
+        constexpr int in_t = passes_in<NTAPS, NPASS, D>(tap) + RW;
+        constexpr int in_tm1 = passes_in<NTAPS, NPASS, D>((tap + NTAPS - 1) % NTAPS) + RW;
         constexpr int allowed = in_t + (D == 3 ? in_tm1 : 0);
         if (tap < D - 1 && after_epilogue) {   // (uniform)
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -423,40 +465,43 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
     for (int pi = 0; pi < NP; ++pi) {
       __builtin_amdgcn_sched_barrier(0);
       const int cl = wn * (BN / 4) + pi * 32 + fk * 8;   // channel inside the tile
-      const int c0 = n0 + cl;
-      float va[DGRAD ? 4 : 2][8];   // forward: scale, shift;  backward: mean / invstd of the two links
+      // merged parity classes: channel n0 + cl of the 4 C outputs is channel c0 of class mcls (uniform per wave: 32 | C)
+      const int mcls = MERGE ? (n0 + cl) / NC : 0;
+      const int c0 = MERGE ? (n0 + cl) - mcls * NC : n0 + cl;
+      const T* __restrict__ res_c = (MERGE && p.dst_merge_res0 && mcls != 0) ? nullptr : res;
+      float va[BWD ? 4 : 2][8];   // forward: scale, shift;  backward: mean / invstd of the two links
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if constexpr (!DGRAD) {
+        if constexpr (!BWD) {
           va[0][e] = AFF_LDS ? aff[c0 + e] : (p.scale ? p.scale[c0 + e] : 1.f);
-          va[1][e] = AFF_LDS ? aff[p.N + c0 + e] : (p.shift ? p.shift[c0 + e] : 0.f);
+          va[1][e] = AFF_LDS ? aff[NC + c0 + e] : (p.shift ? p.shift[c0 + e] : 0.f);
         } else {
-          va[0][e] = AFF_LDS ? aff[2 * p.N + c0 + e] : (bwd_stats ? p.bn_mean[0][c0 + e] : 0.f);
-          va[1][e] = AFF_LDS ? aff[3 * p.N + c0 + e] : (bwd_stats ? p.bn_invstd[0][c0 + e] : 0.f);
-          va[2][e] = AFF_LDS ? aff[4 * p.N + c0 + e] : (p.bn_y[1] ? p.bn_mean[1][c0 + e] : 0.f);
-          va[3][e] = AFF_LDS ? aff[5 * p.N + c0 + e] : (p.bn_y[1] ? p.bn_invstd[1][c0 + e] : 0.f);
+          va[0][e] = AFF_LDS ? aff[2 * NC + c0 + e] : (bwd_stats ? p.bn_mean[0][c0 + e] : 0.f);
+          va[1][e] = AFF_LDS ? aff[3 * NC + c0 + e] : (bwd_stats ? p.bn_invstd[0][c0 + e] : 0.f);
+          va[2][e] = AFF_LDS ? aff[4 * NC + c0 + e] : (p.bn_y[1] ? p.bn_mean[1][c0 + e] : 0.f);
+          va[3][e] = AFF_LDS ? aff[5 * NC + c0 + e] : (p.bn_y[1] ? p.bn_invstd[1][c0 + e] : 0.f);
         }
       }
-      float s1[8], s2[8], s3[DGRAD ? 8 : 1];  // forward: sum v, sum v^2;  backward: sum g, sum g*xhat0, sum g*xhat1
+      float s1[8], s2[8], s3[BWD ? 8 : 1];  // forward: sum v, sum v^2;  backward: sum g, sum g*xhat0, sum g*xhat1
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
-      for (int e = 0; e < (DGRAD ? 8 : 1); ++e) s3[e] = 0.f;
+      for (int e = 0; e < (BWD ? 8 : 1); ++e) s3[e] = 0.f;
       // pixel tiles in batches: the batch's memory operands are requested before its first row is finished
-      constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? 2 : (DGRAD ? 4 : 8)) : 1;   // (BN == 256: 112 accumulator registers are live; the
+      constexpr int JB = sizeof(T) == 2 ? (BN == 256 ? 2 : (BWD ? 4 : 8)) : 1;   // (BN == 256: 112 accumulator registers are live; the
       // 128-channel forward instantiation has the registers for ALL residual loads of a tile in one batch: one exposed latency)
 #pragma unroll
       for (int jb = 0; jb < TM; jb += JB) {
         __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of later batches from being hoisted over this one)
-        Raw8<T> rres[JB], rmsk[DGRAD ? JB : 1], ry0[DGRAD ? JB : 1], ry1[DGRAD ? JB : 1];
+        Raw8<T> rres[JB], rmsk[BWD ? JB : 1], ry0[BWD ? JB : 1], ry1[BWD ? JB : 1];
         bool ok[JB];
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
           ok[u] = jb + u < TM && drow[jb + u < TM ? jb + u : 0] >= 0;
           if (ok[u]) {
-            const long long off = (long long)drow[jb + u] * p.N + c0;
-            if (res) rres[u].load(res + off);
-            if constexpr (DGRAD) {
+            const long long off = (MERGE ? merged_row(drow[jb + u], mcls) : (long long)drow[jb + u]) * NC + c0;
+            if (res_c) rres[u].load(res_c + off);
+            if constexpr (BWD) {
               if (msk) rmsk[u].load(msk + off);
               if (bwd_stats) ry0[u].load(static_cast<const T*>(p.bn_y[0]) + off);
               if (p.bn_y[1]) ry1[u].load(static_cast<const T*>(p.bn_y[1]) + off);
@@ -470,8 +515,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
           float v[8] = {acc[2 * pi][j][0],     acc[2 * pi][j][1],     acc[2 * pi][j][2],     acc[2 * pi][j][3],
                         acc[2 * pi + 1][j][0], acc[2 * pi + 1][j][1], acc[2 * pi + 1][j][2], acc[2 * pi + 1][j][3]};
           if (!ok[u]) continue;
-          const long long off = (long long)drow[j] * p.N + c0;
-          if constexpr (!DGRAD) {
+          const long long off = (MERGE ? merged_row(drow[j], mcls) : (long long)drow[j]) * NC + c0;
+          if constexpr (!BWD) {
             if (p.stats_partial != nullptr) {  // (uniform: an eval forward keeps no sums)
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -484,13 +529,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
               for (int e = 0; e < 8; ++e) v[e] = v[e] * va[0][e] + va[1][e];
             }
           }
-          if (res) {
+          if (res_c) {
             float rv[8];
             rres[u].get(rv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
           }
-          if constexpr (!DGRAD) {
+          if constexpr (!BWD) {
             if (p.relu) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -504,7 +549,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
             }
           }
           QtVec8<T>::store(dst + off, v);
-          if constexpr (DGRAD) {
+          if constexpr (BWD) {
             if (bwd_stats) {
               float yv[8];
               ry0[u].get(yv);
@@ -531,23 +576,23 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
           for (int sft = 1; sft < 16; sft <<= 1) {
             s1[e] += __shfl_xor(s1[e], sft);
             s2[e] += __shfl_xor(s2[e], sft);
-            if constexpr (DGRAD) s3[e] += __shfl_xor(s3[e], sft);
+            if constexpr (BWD) s3[e] += __shfl_xor(s3[e], sft);
           }
         }
         if (frow == 0) {
-          float* o0 = DGRAD ? p.bn_partial[0] : p.stats_partial;
-          const long long row = (long long)mt * 2 + wm;
+          float* o0 = BWD ? p.bn_partial[0] : p.stats_partial;
+          const long long row = MERGE ? ((long long)mt * 2 + wm) * 4 + mcls : (long long)mt * 2 + wm;   // (merged: one row per class too)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            o0[(row * 2 + 0) * p.N + c0 + e] = s1[e];
-            o0[(row * 2 + 1) * p.N + c0 + e] = s2[e];
+            o0[(row * 2 + 0) * NC + c0 + e] = s1[e];
+            o0[(row * 2 + 1) * NC + c0 + e] = s2[e];
           }
-          if constexpr (DGRAD) {
+          if constexpr (BWD) {
             if (p.bn_y[1]) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                p.bn_partial[1][(row * 2 + 0) * p.N + c0 + e] = s1[e];
-                p.bn_partial[1][(row * 2 + 1) * p.N + c0 + e] = s3[e];
+                p.bn_partial[1][(row * 2 + 0) * NC + c0 + e] = s1[e];
+                p.bn_partial[1][(row * 2 + 1) * NC + c0 + e] = s3[e];
               }
             }
           }
@@ -606,11 +651,11 @@ inline int pt_workgroups() {
   return cus;
 }
 
-template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD>
+template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9>
 int launch(PtArgs q, hipStream_t stream) {
   constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB + (BN == 128 ? 6 * 512 * 4 : 0);   // (+ the epilogue's vectors)
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, GEO, DGRAD>;
+  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, GEO, DGRAD, NTAPS>;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
   if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
   q.c.gridN = q.c.N / BN;
@@ -620,6 +665,17 @@ int launch(PtArgs q, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
   QT_CHECK_LAUNCH();
   return QT_OK;
+}
+
+// merged stride-2 data gradient (four tap slots, 128-channel tiles of the 4 C class channels)
+template <typename T>
+int dispatch_merged(const PtArgs& q, hipStream_t stream) {
+  if (q.G == 4) return launch<T, 128, 3, 5, GEO_STACK, false, 4>(q, stream);
+  // (the GEO_ROWS forms - 28x28 and 14x14 gradient maps - were measured and are not instantiated: 8 / 16 K-tiles per item do not
+  // cover an epilogue that scatters 64-byte runs, 276 / 229 us in the train step against 156 / 118 us of the generic tile whose
+  // three workgroups per CU overlap their epilogues; on the 7x7 map, 32 K-tiles per item, this kernel wins 121 against 136 us)
+  qt_set_error("conv_pt (merged): only the 7x7 gradient map is instantiated");
+  return QT_ERR_UNSUPPORTED;
 }
 
 template <typename T, bool DGRAD>
@@ -634,6 +690,17 @@ int dispatch(const PtArgs& q, hipStream_t stream) {
   }
   qt_set_error("conv_pt: %d patch passes not instantiated", q.npass);
   return QT_ERR_UNSUPPORTED;
+}
+
+// QTCNN_PT_MERGED (default 1): the merged stride-2 data gradients take this kernel's four-tap instantiation; 0: the generic
+// tile (same-box A/B)
+inline bool merged_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("QTCNN_PT_MERGED");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
 }
 
 // 0: off, 1: on (default).  QTCNN_PT_CONV / qt_set_pt_conv: same-box A/B against the generic kernel.
@@ -664,10 +731,28 @@ static int pt_images(const ConvArgs& a, bool dgrad, int* quad) {
   return a.M / (a.OH * a.OW);
 }
 
+// the merged stride-2 data gradient (qt_conv_desc.dst_merge): a 2x2 / stride 1 / pad 0 gather over a 7x7
+// gradient map whose 4 C outputs scatter to the (2H x 2W) C-channel map
+static bool pt_merged_shape(const ConvArgs& a, int esz) {
+  return a.dst_merge > 0 && a.ntaps == 4 && a.KW == 2 && a.stride == 1 && a.pad == 0 && a.dst_sub == 2 && !a.quad &&
+         a.IH == a.OH && a.IW == a.OW && a.dst_h == 2 * a.OH && a.dst_w == 2 * a.OW && a.dst_merge % 32 == 0 &&
+         a.N == 4 * a.dst_merge && a.N % 128 == 0 && (a.KC * esz) % kKB == 0 && a.dst_merge <= 512;
+}
+
 // the descriptor must be a 3x3 / stride 1 / pad 1 convolution on 28x28, 14x14 or 7x7 images (or 7x7 quadrants of 14x14 maps)
 bool qt_pt_eligible(const ConvArgs& a, int dtype, bool dgrad) {
   if (!pt_enabled()) return false;
   const int esz = dtype == QT_F32 ? 4 : 2;
+  if (a.dst_merge) {
+    if (dgrad || !pt_merged_shape(a, esz) || !merged_enabled()) return false;
+    if (a.scale || a.shift || a.stats_partial || a.relu) return false;
+    PtArgs q;
+    if (!pt_geometry(a.OH, a.OW, q)) return false;
+    const int batch = a.M / (a.OH * a.OW);
+    if (batch < 16 || q.G != 4 || batch % 4 != 0) return false;   // (7x7 gradient maps only, see dispatch_merged)
+    if ((long long)batch * a.src_img_stride * esz >= (1ll << 31) || (long long)a.N * 4 * a.KC * esz >= (1ll << 31)) return false;
+    return true;
+  }
   if (a.ntaps != 9 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.dst_sub) return false;
   // epilogue operands each instantiation carries (the generic kernel takes every combination): forward = scale / shift,
   // residual, ReLU, statistics; data gradient = residual, ReLU mask, BatchNorm-backward links
@@ -690,6 +775,10 @@ bool qt_pt_eligible(const ConvArgs& a, int dtype, bool dgrad) {
 int qt_pt_stats_rows(const ConvArgs& a, bool dgrad) {
   PtArgs q;
   int quad;
+  if (a.dst_merge) {   // (pixel tile, wave row, class)
+    pt_geometry(a.OH, a.OW, q);
+    return 2 * 4 * pt_tiles_m(q, a.M / (a.OH * a.OW));
+  }
   pt_geometry(a.IH, a.IW, q);
   return 2 * pt_tiles_m(q, pt_images(a, dgrad, &quad));   // one partial row per (pixel tile, wave row)
 }
@@ -697,6 +786,20 @@ int qt_pt_stats_rows(const ConvArgs& a, bool dgrad) {
 int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
   PtArgs q;
   q.c = a;
+  if (a.dst_merge) {
+    const int esz = dtype == QT_F32 ? 4 : 2;
+    pt_geometry(a.OH, a.OW, q);
+    q.quad = 0;
+    q.batch = a.M / (a.OH * a.OW);
+    q.tiles_m = pt_tiles_m(q, q.batch);
+    q.nchunks = a.KC * esz / kKB;
+    q.src_bytes = (unsigned)((((long long)q.batch - 1) * a.src_img_stride + ((long long)a.OH - 1) * a.src_row_stride +
+                              ((long long)a.OW - 1) * a.src_pix_stride + a.KC + (q.G == 1 ? a.src_row_stride : 0)) * esz);
+    q.wgt_bytes = (unsigned)((long long)a.N * 4 * a.KC * esz);
+    q.div_hw = make_fastdiv((unsigned)(a.OH * a.OW));
+    q.div_w = make_fastdiv((unsigned)a.OW);
+    return dtype == QT_F32 ? dispatch_merged<float>(q, stream) : dispatch_merged<bf16_t>(q, stream);
+  }
   pt_geometry(a.IH, a.IW, q);
   q.batch = pt_images(a, dgrad, &q.quad);
   q.tiles_m = pt_tiles_m(q, q.batch);

@@ -308,7 +308,11 @@ void layout_workspace(qt_plan* p) {
     const size_t bwd = (size_t)qt_stats_capacity_rows(2048) * 2 * 512 * 4;
     p->stats = ws.take(bytes > bwd ? bytes : bwd);
     // dgrad-epilogue partials: one row per 128-pixel tile (+ the fold rows); layer1 is the largest
-    const size_t ep = (size_t)qt_stats_capacity_rows(qt_cdiv((long long)B * 56 * 56, 128) + 8) * 2 * 64 * 4;
+    // (... or, larger, the merged stride-2 data gradient of layer2.0 on the patch-resident kernel: one row per 196-pixel
+    // tile of the 28x28 gradient map, wave row and parity class = 32 rows per image)
+    const size_t ep0 = (size_t)qt_stats_capacity_rows(qt_cdiv((long long)B * 56 * 56, 128) + 8) * 2 * 64 * 4;
+    const size_t ep1 = (size_t)qt_stats_capacity_rows((int)(32 * B + 8)) * 2 * 64 * 4;
+    const size_t ep = ep0 > ep1 ? ep0 : ep1;
     p->stats_bn2 = ws.take(ep);
     p->stats_ds = ws.take(ep);
     p->stats_bn1 = ws.take(ep);

@@ -383,7 +383,9 @@ def test_quadrant_wgrad(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(2, 64, 128, 56), (3, 128, 256, 28), (5, 256, 512, 14), (1, 64, 64, 10)])
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 56), (3, 128, 256, 28), (5, 256, 512, 14), (1, 64, 64, 10),
+                                 # >= 16 images: the four-tap instantiation of the patch-resident kernel (csrc/conv_pt.hip)
+                                 (16, 64, 128, 56), (18, 128, 256, 28), (20, 256, 512, 14)])
 def test_stride2_dgrad_merged_classes(dt, cfg):
     """Data gradient of a 3x3 stride-2 conv as ONE 2x2-tap launch over the gradient map (qt_conv_desc.dst_merge,
     qt_pack_dgrad_s2_merged): values (+ residual, ReLU mask) against torch.nn.grad.conv2d_input, and the
@@ -433,6 +435,28 @@ def test_stride2_dgrad_merged_classes(dt, cfg):
     xhat = (ybn - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
     assert rel_err(sums[0], got.sum((0, 2, 3))) <= 1e-3 + TOL[dt]
     assert rel_err(sums[1], (got * xhat).sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    # the generic tile behind the same descriptor (qt_set_pt_conv(0)): same products in another order, residual only on class
+    # (0,0) (dst_merge_res0: the sparse downsample-gradient map of the plan)
+    if B >= 16:
+        for res0 in (0, 1):
+            d.dst_merge_res0 = res0
+            outs = []
+            for on in (1, 0):
+                lib.qt_set_pt_conv(on)
+                try:
+                    o2 = torch.full((B * H * H, Cin), float("nan"), dtype=dt, device=dev)
+                    rows2 = lib.qt_conv2d_stats_rows(ctypes.byref(d))
+                    p2 = torch.zeros(rows2, 2, Cin, dtype=torch.float32, device=dev)
+                    io2 = L.ConvIO(L.ptr(dyd), L.ptr(wd), L.ptr(o2), None, None, L.ptr(res), L.ptr(msk), None,
+                                   L.ptr(yb), L.ptr(md), L.ptr(isd), L.ptr(p2), None, None, None, None)
+                    L.check(lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io2), L.stream_ptr()), "qt_conv2d_igemm")
+                    torch.cuda.synchronize()
+                    outs.append((o2.float().cpu(), p2.sum(0).cpu()))
+                finally:
+                    lib.qt_set_pt_conv(-1)
+            assert rel_err(outs[0][0], outs[1][0]) <= TOL[dt], res0
+            assert rel_err(outs[0][1], outs[1][1]) <= 1e-3 + TOL[dt], res0
+        d.dst_merge_res0 = 0
     # bad shapes are refused
     d.n_out = 2 * Cin
     assert lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()) != 0
