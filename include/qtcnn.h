@@ -120,6 +120,11 @@ typedef struct qt_conv_io {
     const float* invstd; /* [n_out] */
     float* partial;
   } bwd_bn[2];
+  /* The ReLU mask as ONE BIT per element instead of a tensor of the data type: [M][n_out / 8] bytes, bit (n & 7) of byte
+   * n / 8 of row m set = the gradient passes (what qt_bn_act_mask writes next to the activation).  NULL or exclusive with
+   * relu_mask; read at the destination row like relu_mask (strided / merged destinations included).  n_out % 8 == 0.
+   * 1/16 of the bytes of a bf16 mask: the mask is the second-largest epilogue operand of a data-gradient launch. */
+  const unsigned char* relu_mask_bits;
 } qt_conv_io;
 
 /* 3x3 stride-1 convs with the input patch resident in LDS (csrc/conv_patch.hip) instead of the
@@ -312,6 +317,12 @@ int qt_bn_eval_affine_batched(const qt_bn_eval_item* items, int n, float eps, vo
 /* out = relu?( y*scale+shift + (residual ? residual*res_scale+res_shift : 0) ), [M][C] */
 int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
               const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C, void* stream);
+/* the same, and mask_bits (nullable) receives out > 0 as one bit per element: [M][C/8] bytes, bit (c & 7) of byte c / 8 --
+ * the ReLU mask in the form qt_conv_io.relu_mask_bits takes (the training forward of the plan writes it for every
+ * activation whose mask a data-gradient epilogue applies) */
+int qt_bn_act_mask(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
+                   const float* res_scale, const float* res_shift, int relu, void* out, unsigned char* mask_bits,
+                   long long M, int C, void* stream);
 /* backward: g = d(loss)/d(BN output) (masked by `mask` > 0 if given).  qt_bn_bwd_finalize with count == 0 is the backward of
  * an eval-mode BatchNorm (running statistics in mean / invstd): dx = g*gamma*invstd without the batch-mean terms. */
 int qt_bn_bwd_partial_rows(long long M, int C);

@@ -53,6 +53,7 @@ class ConvIO(ctypes.Structure):
         ("bn0_partial", ctypes.c_void_p),
         ("bn1_y", ctypes.c_void_p), ("bn1_mean", ctypes.c_void_p), ("bn1_invstd", ctypes.c_void_p),
         ("bn1_partial", ctypes.c_void_p),
+        ("relu_mask_bits", ctypes.c_void_p),   # [M][n_out/8] bytes: the ReLU mask as one bit per element (or NULL)
     ]
 
 

@@ -13,6 +13,7 @@ struct ConvArgs {
   const float* shift;      // per destination channel, nullable
   const void* residual;    // [M][N] same dtype, nullable
   const void* relu_mask;   // [M][N] same dtype: result *= (mask > 0), nullable
+  const unsigned char* relu_mask_bits;   // [M][N/8]: the same mask, one bit per element (qt_conv_io.relu_mask_bits), nullable
   float* stats_partial;    // [gridM][2][N] per-tile sum / sum of squares, nullable
   // BatchNorm-backward partial sums of the value written to dst (g): sum g and sum g*xhat with
   // xhat = (bn_y - mean) * invstd, for up to two BatchNorms that consume g

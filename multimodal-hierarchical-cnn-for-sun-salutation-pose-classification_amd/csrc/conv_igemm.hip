@@ -382,6 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = (p.dst_merge && p.dst_merge_res0 && mcls != 0) ? nullptr : static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  const unsigned char* __restrict__ mbits = p.relu_mask_bits;
   // Passes run in batches of PB rows: the batch's memory operands (residual, ReLU mask, saved BatchNorm
   // inputs; 16 bytes per thread and row each) are all requested before the first row is finished, so a tile
   // exposes one memory latency per batch instead of one per row (alone, layer2 data gradient with mask +
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
     long long offs[PB];
     bool oks[PB];
     uint4 raw_res[PB], raw_msk[PB], raw_y0[PB], raw_y1[PB];
+    unsigned raw_bits[PB];
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
       const int m = m0 + r0 + (pb + u) * RPP;
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         if (oks[u]) {
           if (res) raw_res[u] = *reinterpret_cast<const uint4*>(res + offs[u]);
           if (msk) raw_msk[u] = *reinterpret_cast<const uint4*>(msk + offs[u]);
+          if (mbits) raw_bits[u] = mbits[offs[u] >> 3];
           if (bwd_stats) raw_y0[u] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[0]) + offs[u]);
           if (p.bn_y[1]) raw_y1[u] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[1]) + offs[u]);
         }
@@ -468,6 +471,7 @@ if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
       }
+      if (mbits) qt_apply_mask_bits(PB > 1 ? raw_bits[u] : (unsigned)mbits[off >> 3], v);
       QtVec8<T>::store(dst + off, v);
       if (bwd_stats) {
         float yv[8];
@@ -536,6 +540,7 @@ if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
       }
+      if (mbits) qt_apply_mask_bits(mbits[off >> 3], v);
       QtVec8<T>::store(dst + off, v);
       if (bwd_stats) {
         float yv[8];
@@ -711,6 +716,8 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   QT_CHECK_ARG((d->src_pix_stride * esz) % 16 == 0 || d->stride * d->src_pix_stride * esz % 16 == 0,
                "qt_conv2d_igemm: pixel stride %d breaks 16-byte alignment", d->src_pix_stride);
 
+  QT_CHECK_ARG(!(io->relu_mask && io->relu_mask_bits), "qt_conv2d_igemm: relu_mask and relu_mask_bits are exclusive");
+  QT_CHECK_ARG(!io->relu_mask_bits || d->n_out % 8 == 0, "qt_conv2d_igemm: relu_mask_bits needs n_out %% 8 == 0");
   const int KT = d->kt > 1 ? d->kt : 1;
   QT_CHECK_ARG(KT == 1 || (KT == 3 && d->frames > 0 && d->batch % d->frames == 0 && d->stride == 1 && !d->quad && !d->dst_sub &&
                            !d->dst_merge && d->kh * d->kw * KT <= 32 && d->k_per_tap % bk == 0),
@@ -727,7 +734,7 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   ConvArgs a;
   a.src = io->src; a.wgt = io->weight; a.dst = io->dst;
   a.scale = io->scale; a.shift = io->shift;
-  a.residual = io->residual; a.relu_mask = io->relu_mask;
+  a.residual = io->residual; a.relu_mask = io->relu_mask; a.relu_mask_bits = io->relu_mask_bits;
   a.stats_partial = io->stats_partial;
   for (int k = 0; k < 2; ++k) {
     a.bn_y[k] = io->bwd_bn[k].y; a.bn_mean[k] = io->bwd_bn[k].mean; a.bn_invstd[k] = io->bwd_bn[k].invstd;

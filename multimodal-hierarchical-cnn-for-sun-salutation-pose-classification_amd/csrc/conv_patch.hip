@@ -36,6 +36,7 @@ struct PatchArgs {
   const float* shift;
   const void* residual;
   const void* relu_mask;
+  const unsigned char* relu_mask_bits;   // one bit per element (qt_conv_io.relu_mask_bits)
   float* stats_partial;
   const void* bn_y[2];
   const float* bn_mean[2];
@@ -85,6 +86,7 @@ __device__ __forceinline__ void patch_epilogue(const PatchArgs& p, unsigned char
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  const unsigned char* __restrict__ mbits = p.relu_mask_bits;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int r = r0 + ps * RPP;
@@ -127,6 +129,7 @@ if (p.scale || p.shift) {  // (uniform)
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
         }
+        if (mbits) qt_apply_mask_bits(mbits[off >> 3], v);
         QtVec8<T>::store(dst + off, v);
         if (bwd_stats) {
           float yv[8];
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  const unsigned char* __restrict__ mbits = p.relu_mask_bits;
   const unsigned char* ring = smem + L1_WBYTES;
   const int w_lane = (wn * 32 + frow) * kRowBytes + ((fk ^ (frow & 7)) << 4);  // this lane's filter fragment, tap 0 / tile 0 / kk 0
 
@@ -519,6 +523,7 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
           const long long off = (long long)prow[j] * 64 + wn * 32 + fk * 8;
           if (res) pre_res[j] = *reinterpret_cast<const uint4*>(res + off);
           if (msk) pre_msk[j] = *reinterpret_cast<const uint4*>(msk + off);
+          if (mbits) pre_msk[j].x = mbits[off >> 3];   // (the mask as one byte, a bit per channel, in the same registers)
           if (bwd_stats) pre_y0[j] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[0]) + off);
           if (p.bn_y[1]) pre_y1[j] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.bn_y[1]) + off);
         }
@@ -606,6 +611,10 @@ if (p.scale || p.shift) {  // (uniform)
           bf4(i ? pre_msk[j].z : pre_msk[j].x, i ? pre_msk[j].w : pre_msk[j].y, mv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
+        }
+        if (OPS && mbits) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (pre_msk[j].x >> (i * 4 + r)) & 1u ? v[r] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[i * 4 + r] = (bf16_t)v[r];
@@ -773,6 +782,7 @@ int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   PatchArgs a;
   a.src = io->src; a.wgt = io->weight; a.dst = io->dst;
   a.scale = io->scale; a.shift = io->shift; a.residual = io->residual; a.relu_mask = io->relu_mask;
+  a.relu_mask_bits = io->relu_mask_bits;
   a.stats_partial = io->stats_partial;
   for (int k = 0; k < 2; ++k) {
     a.bn_y[k] = io->bwd_bn[k].y; a.bn_mean[k] = io->bwd_bn[k].mean; a.bn_invstd[k] = io->bwd_bn[k].invstd;
@@ -788,7 +798,7 @@ int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   a.gridM = a.gridN = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (l1_ring_shape(d)) {
-    const bool ops = a.residual || a.relu_mask || a.bn_y[0];
+    const bool ops = a.residual || a.relu_mask || a.relu_mask_bits || a.bn_y[0];
     if (a.flip) return ops ? launch_l1_ring<true, true>(a, s) : launch_l1_ring<true, false>(a, s);
     return ops ? launch_l1_ring<false, true>(a, s) : launch_l1_ring<false, false>(a, s);
   }

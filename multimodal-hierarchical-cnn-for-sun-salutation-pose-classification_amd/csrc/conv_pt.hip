@@ -56,6 +56,7 @@ struct PtArgs {
   int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
   int tpi, tiles_m, batch;      // pixel tiles per image (GEO_ROWS), pixel tiles in all, images
   int items, ipw;               // (channel tile, pixel tile) items in all / per workgroup (persistent walk)
+  int stagger;                  // start delay of workgroup class k = (blockIdx / 8) % 4: k * stagger * 1024 cycles (0: none)
   int nchunks;                  // 128-byte channel chunks of the source
   unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
   // GEO_STACK on the 2x2 quadrants of 14x14 maps (the quadrant conv, Quadtree_from scratch/models.py:277-287): "image"
@@ -192,6 +193,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int item_begin = __builtin_amdgcn_readfirstlane(PERSIST ? wg * q.ipw : wg);
   const int item_end = PERSIST ? min(item_begin + q.ipw, q.items) : item_begin + 1;
   if (item_begin >= q.items) return;   // (uniform, before any barrier)
+  if constexpr (PERSIST) {
+    // de-phase the workgroups: all items cost the same, so without this every CU reaches its epilogue at the same moment
+    // and the launch alternates between a phase that only issues MFMAs and a phase that only moves epilogue operands
+    const int cls = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < cls * q.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
 
   constexpr int patch_bytes = NPASS * 64 * kKB;
   const unsigned smem_base = lds_addr_of(smem);
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
   const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
+  const unsigned char* __restrict__ mbits = p.relu_mask_bits;
   const bool bwd_stats = BWD && p.bn_y[0] != nullptr;
   const bool want_stats = BWD ? bwd_stats : p.stats_partial != nullptr;
   // merged classes: dense pixel index of the gradient map -> pixel (2r + class/2, 2c + class%2) of the destination map
@@ -495,6 +503,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of later batches from being hoisted over this one)
         Raw8<T> rres[JB], rmsk[BWD ? JB : 1], ry0[BWD ? JB : 1], ry1[BWD ? JB : 1];
         bool ok[JB];
+        unsigned rbits[BWD ? JB : 1];   // (the mask as one byte: a bit per channel of the lane's 8)
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
           ok[u] = jb + u < TM && drow[jb + u < TM ? jb + u : 0] >= 0;
@@ -503,6 +512,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
             if (res_c) rres[u].load(res_c + off);
             if constexpr (BWD) {
               if (msk) rmsk[u].load(msk + off);
+              if (mbits) rbits[u] = mbits[off >> 3];
               if (bwd_stats) ry0[u].load(static_cast<const T*>(p.bn_y[0]) + off);
               if (p.bn_y[1]) ry1[u].load(static_cast<const T*>(p.bn_y[1]) + off);
             }
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
             }
+            if (mbits) qt_apply_mask_bits(rbits[u], v);
           }
           QtVec8<T>::store(dst + off, v);
           if constexpr (BWD) {
@@ -637,6 +648,16 @@ inline int pt_bn(const ConvArgs& a) { return (a.N % 256 == 0 && a.OH == 14) ? 25
 // persistent grid: one workgroup per CU (qt_set_pt_conv_max_workgroups caps it: tests walk several items per workgroup
 // at small batches; QTCNN_PT_PERSIST=0: one item per workgroup as in round 2, same-box A/B)
 int g_pt_max_wgs_fwd = 0;
+int g_pt_stagger[2] = {-1, -1};   // forward, backward
+inline int pt_stagger(bool bwd) {
+  if (g_pt_stagger[0] < 0) {
+    const char* e = getenv("QTCNN_PT_STAGGER_FWD");
+    g_pt_stagger[0] = e ? atoi(e) : 0;
+    e = getenv("QTCNN_PT_STAGGER_BWD");
+    g_pt_stagger[1] = e ? atoi(e) : 0;
+  }
+  return g_pt_stagger[bwd ? 1 : 0];
+}
 inline int pt_workgroups() {
   static int persist = -1;
   if (persist < 0) {
@@ -662,6 +683,7 @@ int launch(PtArgs q, hipStream_t stream) {
   q.c.gridM = q.tiles_m;
   q.items = q.tiles_m * q.c.gridN;
   q.ipw = BN == 128 ? qt_cdiv(q.items, pt_workgroups()) : 1;
+  q.stagger = q.ipw >= 2 ? pt_stagger(DGRAD || NTAPS == 4) : 0;
   hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -756,7 +778,7 @@ bool qt_pt_eligible(const ConvArgs& a, int dtype, bool dgrad) {
   if (a.ntaps != 9 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.dst_sub) return false;
   // epilogue operands each instantiation carries (the generic kernel takes every combination): forward = scale / shift,
   // residual, ReLU, statistics; data gradient = residual, ReLU mask, BatchNorm-backward links
-  if (!dgrad && (a.bn_y[0] || a.relu_mask)) return false;
+  if (!dgrad && (a.bn_y[0] || a.relu_mask || a.relu_mask_bits)) return false;
   if (dgrad && (a.scale || a.shift || a.stats_partial || a.relu)) return false;
   if (a.N > 512) return false;   // (per-channel vectors of the epilogue in LDS)
   int quad;

@@ -333,7 +333,7 @@ bool qt_stem_eligible(const qt_conv_desc* d, const qt_conv_io* io) {
       d->src_img_stride != (long long)QT_STEM_PAD_H * QT_STEM_PAD_W * 4)
     return false;
   if (d->quad || d->dst_sub) return false;
-  if (io && (io->residual || io->relu_mask || io->bwd_bn[0].y || io->bwd_bn[1].y)) return false;
+  if (io && (io->residual || io->relu_mask || io->relu_mask_bits || io->bwd_bn[0].y || io->bwd_bn[1].y)) return false;
   return true;
 }
 

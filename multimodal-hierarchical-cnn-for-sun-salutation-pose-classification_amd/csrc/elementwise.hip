@@ -162,7 +162,8 @@ __global__ void bn_eval_affine_batched_kernel(BnEvalBatchArgs a) {
 template <typename T>
 __global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                               const T* __restrict__ res, const float* __restrict__ rscale,
-                              const float* __restrict__ rshift, int relu, T* __restrict__ out, long long M, int C) {
+                              const float* __restrict__ rshift, int relu, T* __restrict__ out,
+                              unsigned char* __restrict__ bits, long long M, int C) {
   const int cgs = C >> 3;
   const long long total = M * cgs;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -194,6 +195,12 @@ __global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     QtVec8<T>::store(out + off, v);
+    if (bits) {  // the ReLU mask of the data-gradient epilogues, one bit per element (qt_conv_io.relu_mask_bits)
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+      bits[i] = (unsigned char)b;
+    }
   }
 }
 
@@ -852,9 +859,9 @@ extern "C" int qt_bn_eval_affine_batched(const qt_bn_eval_item* items, int n, fl
   return QT_OK;
 }
 
-extern "C" int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
-                         const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C,
-                         void* stream) {
+extern "C" int qt_bn_act_mask(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
+                              const float* res_scale, const float* res_shift, int relu, void* out, unsigned char* mask_bits,
+                              long long M, int C, void* stream) {
   QT_DT_OK(dtype, "qt_bn_act");
   QT_CHECK_ARG(y && scale && shift && out && M > 0 && C > 0 && C % 8 == 0, "qt_bn_act: bad argument");
   QT_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "qt_bn_act: res_scale/res_shift must come in pairs");
@@ -862,12 +869,18 @@ extern "C" int qt_bn_act(int dtype, const void* y, const float* scale, const flo
   const int grid = grid_for(M * (C / 8));
   if (dtype == QT_F32)
     hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift,
-                       (const float*)residual, res_scale, res_shift, relu, (float*)out, M, C);
+                       (const float*)residual, res_scale, res_shift, relu, (float*)out, mask_bits, M, C);
   else
     hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
-                       (const bf16_t*)residual, res_scale, res_shift, relu, (bf16_t*)out, M, C);
+                       (const bf16_t*)residual, res_scale, res_shift, relu, (bf16_t*)out, mask_bits, M, C);
   QT_CHECK_LAUNCH();
   return QT_OK;
+}
+
+extern "C" int qt_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* residual,
+                         const float* res_scale, const float* res_shift, int relu, void* out, long long M, int C,
+                         void* stream) {
+  return qt_bn_act_mask(dtype, y, scale, shift, residual, res_scale, res_shift, relu, out, nullptr, M, C, stream);
 }
 
 static int bn_bwd_rows_per_block(long long M, int C) {

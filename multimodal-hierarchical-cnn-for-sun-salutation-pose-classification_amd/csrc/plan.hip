@@ -66,6 +66,7 @@ struct ConvL {
 struct Block {
   int conv1, conv2, ds;
   size_t a1, out, gout, gtmp;
+  size_t a1_bits, out_bits;   // ReLU masks of a1 / out, one bit per element (written by the training forward)
 };
 
 struct LinL {
@@ -377,6 +378,8 @@ void layout_workspace(qt_plan* p) {
       blk.a1 = ws.take(n * es);
       blk.out = ws.take(n * es);
       blk.gout = ws.take(n * es);
+      blk.a1_bits = ws.take(n / 8);
+      blk.out_bits = ws.take(n / 8);
       const ConvL& c1 = p->convs[blk.conv1];
       blk.gtmp = blk.ds >= 0 ? ws.take(B * c1.hin * c1.hin * c1.cin * es) : 0;
     }
@@ -584,11 +587,12 @@ struct Exec {
   };
   void igemm(const qt_conv_desc& d, const void* src, const void* w, void* dst, const float* scale, const float* shift,
              const void* res, const void* mask, float* stats, int relu, int kind = -1, const BnLink* links = nullptr,
-             int nlinks = 0) {
+             int nlinks = 0, const unsigned char* mask_bits = nullptr) {
     if (!ok()) return;
     qt_conv_desc dd = d;
     dd.relu = relu;
     qt_conv_io io = {src, w, dst, scale, shift, res, mask, stats};
+    io.relu_mask_bits = mask_bits;
     for (int k = 0; k < nlinks && k < 2; ++k) {
       io.bwd_bn[k].y = links[k].y; io.bwd_bn[k].mean = links[k].mean;
       io.bwd_bn[k].invstd = links[k].invstd; io.bwd_bn[k].partial = links[k].partial;
@@ -640,6 +644,7 @@ struct Exec {
     double per_pixel = 1.0;   // dst
     if (io.residual) per_pixel += d.dst_merge_res0 ? 0.25 : 1.0;
     if (io.relu_mask) per_pixel += 1.0;
+    if (io.relu_mask_bits) per_pixel += 1.0 / (8.0 * es);
     if (io.bwd_bn[0].y) per_pixel += 1.0;
     if (io.bwd_bn[1].y) per_pixel += 1.0;
     const double wgt = (double)d.kh * d.kw * d.k_per_tap * d.n_out * es;
@@ -960,8 +965,8 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
       }
       if (!pair) e.conv_bn_stats(c1, d1, e.at(x), training);
       if (unf) {
-        e.run(qt_bn_act(dt, e.at(c1.y), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr, nullptr, nullptr, 1,
-                        e.at(blk.a1), M, c1.cout, stream));
+        e.run(qt_bn_act_mask(dt, e.at(c1.y), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr, nullptr, nullptr, 1,
+                             e.at(blk.a1), e.at<unsigned char>(blk.a1_bits), M, c1.cout, stream));
       } else if (!pair) {
         e.igemm(d1, e.at(x), e.at(c1.w_fwd), e.at(blk.a1), e.at<float>(b1.scale), e.at<float>(b1.shift), nullptr,
                 nullptr, nullptr, 1);
@@ -976,8 +981,9 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
         e.conv_bn_stats(c2, d2, e.at(blk.a1), training);
         if (!pair) e.join();   // (the fused pair ran on this stream: a head branch forked earlier keeps running beside layer4)
         if (unf) {
-          e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(cd.y),
-                          e.at<float>(bd.scale), e.at<float>(bd.shift), 1, e.at(blk.out), M, c2.cout, stream));
+          e.run(qt_bn_act_mask(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(cd.y),
+                               e.at<float>(bd.scale), e.at<float>(bd.shift), 1, e.at(blk.out),
+                               e.at<unsigned char>(blk.out_bits), M, c2.cout, stream));
         } else {
           e.igemm(d2, e.at(blk.a1), e.at(c2.w_fwd), e.at(blk.out), e.at<float>(b2.scale), e.at<float>(b2.shift),
                   e.at(cd.y), nullptr, nullptr, 1);
@@ -986,8 +992,8 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
       } else {
         e.conv_bn_stats(c2, d2, e.at(blk.a1), training);
         if (unf) {
-          e.run(qt_bn_act(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(x), nullptr, nullptr, 1,
-                          e.at(blk.out), M, c2.cout, stream));
+          e.run(qt_bn_act_mask(dt, e.at(c2.y), e.at<float>(b2.scale), e.at<float>(b2.shift), e.at(x), nullptr, nullptr, 1,
+                               e.at(blk.out), e.at<unsigned char>(blk.out_bits), M, c2.cout, stream));
         } else {
           e.igemm(d2, e.at(blk.a1), e.at(c2.w_fwd), e.at(blk.out), e.at<float>(b2.scale), e.at<float>(b2.shift),
                   e.at(x), nullptr, nullptr, 1);
@@ -1110,11 +1116,12 @@ struct Bwd : Exec {
   // sparse: (1x1 stride 2 as `c`) leave the three parity classes the conv does not reach unwritten instead of zeroing
   // the map; (3x3 stride 2 as `c`) `resid` is such a map: only class (0,0) adds it.  Saves a fill of the block input's
   // size and three quarters of the residual reads per transition.
+  // mask / mask_bits: the ReLU mask as a tensor or as one bit per element (qt_conv_io.relu_mask_bits), at most one of them
   int dgrad(const ConvL& c, void* dst, const void* resid, const void* mask, const BnLink* links = nullptr,
-            int nlinks = 0, bool sparse = false) {
+            int nlinks = 0, bool sparse = false, const unsigned char* mask_bits = nullptr) {
     if (c.stride == 1) {
       const qt_conv_desc d = conv_desc(c, QT_CONV_DGRAD);
-      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, -1, links, nlinks);
+      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, -1, links, nlinks, mask_bits);
       return qt_conv2d_stats_rows(&d);
     }
     if (c.merged_dgrad) {  // all four parity classes in one 2x2-tap launch over the gradient map
@@ -1126,13 +1133,13 @@ struct Bwd : Exec {
       d.kh = d.kw = 2; d.stride = 1; d.pad = 0;
       d.src_pix_stride = c.cout; d.src_row_stride = c.hout * c.cout; d.src_img_stride = (long long)c.hout * c.hout * c.cout;
       d.dst_sub = 2; d.dst_h = d.dst_w = c.hin; d.dst_merge = c.cin; d.dst_merge_res0 = sparse ? 1 : 0;
-      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, 1, links, nlinks);
+      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, 1, links, nlinks, mask_bits);
       return qt_conv2d_stats_rows(&d);
     }
     bool empty_class = false;
     for (int cls = 0; cls < 4; ++cls) empty_class |= c.cls_kh[cls] * c.cls_kw[cls] == 0;
     if (empty_class) {  // 1x1 stride 2: three of four pixels receive nothing from the conv
-      if (resid || mask || nlinks) {
+      if (resid || mask || mask_bits || nlinks) {
         status = QT_ERR_UNSUPPORTED;
         qt_set_error("dgrad: 1x1 stride-2 with residual/mask/links is not wired");
         return 0;
@@ -1156,7 +1163,7 @@ struct Bwd : Exec {
         l2[k].partial = links[k].partial + (size_t)rows * 2 * c.cin;  // each class appends its tile rows
       }
       igemm(d, at(c.gy), at<unsigned char>(c.w_dgrad) + (size_t)c.cls_off[cls] * p->esz, dst, nullptr, nullptr,
-            sparse && !empty_class && cls != 0 ? nullptr : resid, mask, nullptr, 0, 1, l2, nlinks);
+            sparse && !empty_class && cls != 0 ? nullptr : resid, mask, nullptr, 0, 1, l2, nlinks, mask_bits);
       rows += qt_conv2d_stats_rows(&d);
     }
     return rows;
@@ -1441,6 +1448,9 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       rows_bn2 = p->bwd_rows_bn2;
     }
     const int bi_hi = do_l4 ? 7 : (do_l32 ? 5 : 1), bi_lo = do_rest ? 0 : (do_l32 ? 2 : 6);
+    // ReLU masks of the data-gradient epilogues as one bit per element (written by the training forward's qt_bn_act_mask
+    // launches): 1/16 of the bytes of the bf16 activation they replace as an operand.  QTCNN_MASK_BITS=0: the activations.
+    static const bool mask_bits = !(getenv("QTCNN_MASK_BITS") && atoi(getenv("QTCNN_MASK_BITS")) == 0);
     for (int bi = bi_hi; bi >= bi_lo; --bi) {
       const Block& blk = p->blocks[bi];
       const ConvL& c1 = p->convs[blk.conv1];
@@ -1453,7 +1463,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       {
         const BnL& b1 = p->bns[c1.bn];
         Exec::BnLink l = {e.at(c1.y), e.at<float>(b1.mean), e.at<float>(b1.invstd), e.at<float>(p->stats_bn1)};
-        const int r1 = e.dgrad(c2, e.at(c1.gy), nullptr, e.at(blk.a1), &l, 1);
+        const int r1 = mask_bits ? e.dgrad(c2, e.at(c1.gy), nullptr, nullptr, &l, 1, false, e.at<unsigned char>(blk.a1_bits))
+                                 : e.dgrad(c2, e.at(c1.gy), nullptr, e.at(blk.a1), &l, 1);
         // bn1 / conv1
         e.bn_backward(c1, e.at(c1.gy), nullptr, e.at<float>(p->stats_bn1), r1);
       }
@@ -1487,7 +1498,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         resid = e.at(p->gbase_tmp);
       }
       void* gprev = bi == 0 ? e.at(p->g_p0) : e.at(p->blocks[bi - 1].gout);
-      const void* mask = bi == 0 ? nullptr : e.at(x);
+      const void* mask = (bi == 0 || mask_bits) ? nullptr : e.at(x);
+      const unsigned char* mbits = (bi > 0 && mask_bits) ? e.at<unsigned char>(p->blocks[bi - 1].out_bits) : nullptr;
       Exec::BnLink links[2];
       int nlinks = 0;
       if (bi > 0) {  // gprev feeds bn2 (and the downsample BN) of the previous block
@@ -1501,7 +1513,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
           links[nlinks++] = {e.at(pcd.y), e.at<float>(pbd.mean), e.at<float>(pbd.invstd), e.at<float>(p->stats_ds)};
         }
       }
-      rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks, sparse_ds);
+      rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks, sparse_ds, mbits);
       if (bi == 0) rows_bn2 = 0;
     }
     p->bwd_rows_bn2 = rows_bn2;

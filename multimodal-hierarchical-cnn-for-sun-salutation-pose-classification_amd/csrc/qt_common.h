@@ -74,6 +74,13 @@ template <> struct QtVec8<bf16_t> {
   }
 };
 
+// ReLU mask, one bit per element ([M][N/8] bytes): zero the channels of the 8-channel group at element offset `off`
+// (a multiple of 8) whose bit is clear.  `byte` was loaded from bits[off >> 3].
+__device__ __forceinline__ void qt_apply_mask_bits(unsigned byte, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (byte >> e) & 1u ? v[e] : 0.f;
+}
+
 template <typename T> __device__ __forceinline__ float qt_to_f32(T v);
 template <> __device__ __forceinline__ float qt_to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float qt_to_f32<bf16_t>(bf16_t v) { return (float)v; }
