@@ -579,16 +579,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         }
       }
       if (want_stats) {
-        // sum over the 16 pixels (lanes with equal fk) of the wave, fixed butterfly order -> deterministic; one partial
+        // sum over the 16 pixels (lanes with equal fk) of the wave, four DPP adds in a fixed order -> deterministic; one partial
         // row per (pixel tile, wave row): the two wave rows are added by the finalize kernels, not here
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-#pragma unroll
-          for (int sft = 1; sft < 16; sft <<= 1) {
-            s1[e] += __shfl_xor(s1[e], sft);
-            s2[e] += __shfl_xor(s2[e], sft);
-            if constexpr (BWD) s3[e] += __shfl_xor(s3[e], sft);
-          }
+          s1[e] = qt_row16_sum(s1[e]);
+          s2[e] = qt_row16_sum(s2[e]);
+          if constexpr (BWD) s3[e] = qt_row16_sum(s3[e]);
         }
         if (frow == 0) {
           float* o0 = BWD ? p.bn_partial[0] : p.stats_partial;

@@ -406,15 +406,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
           QtVec8<T>::store(dst + (long long)drow[j] * q.N + c0, v);
         }
         if (o.stats != nullptr) {
-          // sum over the 16 pixels (lanes with equal fk) of the wave, fixed butterfly order; one partial row per
+          // sum over the 16 pixels (lanes with equal fk) of the wave, four DPP adds in a fixed order; one partial row per
           // (pixel tile, wave row): no cross-wave reduction, no LDS
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int sft = 1; sft < 16; sft <<= 1) {
-              s1[e] += __shfl_xor(s1[e], sft);
-              s2[e] += __shfl_xor(s2[e], sft);
-            }
+            s1[e] = qt_row16_sum(s1[e]);
+            s2[e] = qt_row16_sum(s2[e]);
           }
           if (frow == 0) {
             float* o0 = o.stats + ((long long)(cur.mt * 2 + wm) * 2) * q.N + c0;

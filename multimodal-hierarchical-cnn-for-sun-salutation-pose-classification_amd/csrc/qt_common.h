@@ -81,6 +81,17 @@ __device__ __forceinline__ void qt_apply_mask_bits(unsigned byte, float (&v)[8])
   for (int e = 0; e < 8; ++e) v[e] = (byte >> e) & 1u ? v[e] : 0.f;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), every lane receives the total; four DPP adds in a fixed
+// order (row mirror, half-row mirror, quad reversal, neighbour swap) -> deterministic, no LDS crossbar traffic
+// (__shfl_xor compiles to ds_bpermute_b32).
+__device__ __forceinline__ float qt_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x1b, 0xf, 0xf, false));   // quad_perm [3,2,1,0]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  return v;
+}
+
 template <typename T> __device__ __forceinline__ float qt_to_f32(T v);
 template <> __device__ __forceinline__ float qt_to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float qt_to_f32<bf16_t>(bf16_t v) { return (float)v; }
