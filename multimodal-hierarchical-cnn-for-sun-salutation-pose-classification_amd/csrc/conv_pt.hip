@@ -56,6 +56,7 @@ struct PtArgs {
   int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
   int tpi, tiles_m, batch;      // pixel tiles per image (GEO_ROWS), pixel tiles in all, images
   int items, ipw;               // (channel tile, pixel tile) items in all / per workgroup (persistent walk)
+  unsigned long long* prof;     // PROFILING AID (QTCNN_PT_PROF): [workgroup][32] s_memrealtime stamps (10 ns), NULL normally
   int stagger;                  // start delay of workgroup class k = (blockIdx / 8) % 4: k * stagger * 1024 cycles (0: none)
   int nchunks;                  // 128-byte channel chunks of the source
   unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   constexpr int NP = TN / 2;                // pairs of them = 32-channel groups
   constexpr int RW = BN / 64;               // LDS-DMA instructions per wave and weight tile (64 rows per pass)
   constexpr int D = NBW - 1;                // weight tiles in flight
+  constexpr bool WFIRST = NTAPS == 9;       // L segments issue the weight tile before the patch pass (see the K loop)
   constexpr int WSLOT = BN * kKB;           // bytes of a weight ring slot
   constexpr bool AFF_LDS = BN == 128;       // room behind the rings for the per-channel vectors of the epilogue
   static_assert(TN % 2 == 0 && TN >= 2, "a wave owns whole 32-channel groups");
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   // K-tile stream never stops at an item boundary (the next item's first patch and weight tiles are requested during
   // the last chunk of the current one) and the epilogue runs from the accumulators between two K-tiles.  Consecutive
   // logical workgroup ids share an XCD (its L2): a weight slice and neighbouring pixel tiles per XCD.
+  if (q.prof && threadIdx.x == 0) q.prof[(long long)blockIdx.x * 32 + 31] = wall_clock64();   // kernel entry
   const int wg = qt_xcd_remap(blockIdx.x, gridDim.x);
   // (the 256-channel tile has no register room for the walk's state next to its epilogue: one item per workgroup there --
   // which is what 256 images give its 14x14 stage anyway; the loop below then runs once and its state dies in the epilogue)
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
     // de-phase the workgroups: all items cost the same, so without this every CU reaches its epilogue at the same moment
     // and the launch alternates between a phase that only issues MFMAs and a phase that only moves epilogue operands
     const int cls = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < cls * q.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    for (int i = 0; i < cls * q.stagger; ++i) __builtin_amdgcn_s_sleep(16);   // (negative: no delay)
   }
 
   constexpr int patch_bytes = NPASS * 64 * kKB;
@@ -326,6 +329,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   for (int s = 0; s < D; ++s) dma_weights(rs_wgt, (unsigned)cur_nt * wtile_bytes + (unsigned)s * tap_bytes, s);   // (D < 9: all in chunk 0)
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RW * (D - 1)) : "memory");   // (lgkmcnt: the vectors above)
   if (grp == 1) asm volatile("s_barrier" ::: "memory");
+  int prof_i = 0;
+  auto stamp = [&]() {
+    if (q.prof && tid == 0 && prof_i < 32) q.prof[(long long)blockIdx.x * 32 + prof_i] = wall_clock64();
+    ++prof_i;
+  };
+  stamp();   // 0: prologue done
 
   T* __restrict__ dst = static_cast<T*>(p.dst);
   const T* __restrict__ res = static_cast<const T*>(p.residual);
@@ -374,18 +383,24 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
       static_for<NTAPS>([&](auto tap_tag) {
         constexpr int tap = decltype(tap_tag)::value;
         // ---- L_t ----
-        {
+        // Nine taps: the weight tile FIRST, then the patch pass.  vmcnt retires in issue order, so the wait for a weight tile
+        // also waits for everything issued before it: a patch pass comes from HBM / the memory-side cache (2.5-3 us measured
+        // in the prologue) while a weight tile comes from the XCD's L2; behind the weight tile of its segment the pass has
+        // D K-tiles instead of D - 1 before a wait covers it (pt_phases.py: the K loop stalled ~0.9 us per chunk on it).
+        auto issue_patch = [&]() {
           constexpr int np = passes_in<NTAPS, NPASS, D>(tap), p0 = passes_before<NTAPS, NPASS, D>(tap);
           static_for<np>([&](auto pass_tag) {
             constexpr int ps = p0 + decltype(pass_tag)::value;
             dma_patch_pass(rs_src_n, ps, pass_off(ps, n_top, n_bot), n_psoff, pb ^ 1);
           });
-        }
+        };
+        if constexpr (!WFIRST) issue_patch();
         {
           constexpr int u = (tap + D) % NTAPS;
           constexpr bool wrap = tap + D >= NTAPS;
           dma_weights(wrap ? rs_wgt_n : rs_wgt, (wrap ? n_woff : c_woff) + (unsigned)u * tap_bytes, wr);
         }
+        if constexpr (WFIRST) issue_patch();
         wr = wr + 1 == NBW ? 0 : wr + 1;
         // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
         const int kh = MERGE ? (tap >> 1) + 1 : tap / 3, kw = MERGE ? (tap & 1) + 1 : tap % 3;
@@ -417,7 +432,9 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         // last pass was issued on tap NPASS-1 < 9-D, i.e. before weight tile t+1 of tap 8).
         constexpr int in_t = passes_in<NTAPS, NPASS, D>(tap) + RW;
         constexpr int in_tm1 = passes_in<NTAPS, NPASS, D>((tap + NTAPS - 1) % NTAPS) + RW;
-        constexpr int allowed = in_t + (D == 3 ? in_tm1 : 0);
+        // (weights first: the patch passes of segment t + 1 - D sit behind the weight tile waited for and may stay in flight)
+        constexpr int behind = WFIRST ? passes_in<NTAPS, NPASS, D>((tap + 1 - D + 2 * NTAPS) % NTAPS) : 0;
+        constexpr int allowed = in_t + (D == 3 ? in_tm1 : 0) + behind;
         if (tap < D - 1 && after_epilogue) {   // (uniform)
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
@@ -442,7 +459,16 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
     // ---- epilogue: straight from the accumulators, no LDS scratch (the next item's DMA is in flight) -----------
     // Everything the next item's first D-1 K-tiles need (its patch, weight tiles 0 .. D-1: all issued at least a
     // segment ago) is waited for here, in front of the stores.
+    // Item boundary of the ping-pong.  Group 1 runs one barrier behind group 0: without the next two lines its last barrier of
+    // the item pairs with group 0's FIRST barrier of the next item (or the one behind the loop), i.e. group 1 sits out group 0's
+    // whole epilogue and group 0 then waits for group 1's -- the two epilogues ran one after the other (pt_phases.py: a
+    // data gradient's epilogue cost 5.7 us for group 0 and the following K loop was 4.8 us longer).  Group 0 takes one extra
+    // barrier BEFORE its epilogue (pairs with group 1's last), so both epilogues run side by side; group 1 takes one extra
+    // barrier AFTER its epilogue when another item follows, which restores the one-barrier offset exactly as at the start.
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+    stamp();   // 1 + 3k: K loop of item k done
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();   // 2 + 3k: the next item's first tiles have landed
     const int mt = cur_mt, n0 = cur_nt * BN;
     const int img0 = GEO == GEO_ROWS ? mt / q.tpi : mt * 4;
     const int row0 = GEO == GEO_ROWS ? (mt - img0 * q.tpi) * q.R : 0;
@@ -610,8 +636,9 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
     cur_nt = nxt_nt;
     cur_mt = nxt_mt;
     cur_soff = nxt_soff; cur_top = nxt_top; cur_bot = nxt_bot;
+    if (grp == 1 && it + 1 < item_end) asm volatile("s_barrier" ::: "memory");   // (see the item boundary above)
+    stamp();   // 3 + 3k: epilogue of item k done
   }
-  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (group 1's last MFMA segment)
   // the branch-free slots of the last chunk wrote zeros into dead buffers: landed before the LDS changes hands
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -645,6 +672,7 @@ inline int pt_bn(const ConvArgs& a) { return (a.N % 256 == 0 && a.OH == 14) ? 25
 // persistent grid: one workgroup per CU (qt_set_pt_conv_max_workgroups caps it: tests walk several items per workgroup
 // at small batches; QTCNN_PT_PERSIST=0: one item per workgroup as in round 2, same-box A/B)
 int g_pt_max_wgs_fwd = 0;
+unsigned long long* g_pt_prof = nullptr;
 int g_pt_stagger[2] = {-1, -1};   // forward, backward
 inline int pt_stagger(bool bwd) {
   if (g_pt_stagger[0] < 0) {
@@ -681,6 +709,7 @@ int launch(PtArgs q, hipStream_t stream) {
   q.items = q.tiles_m * q.c.gridN;
   q.ipw = BN == 128 ? qt_cdiv(q.items, pt_workgroups()) : 1;
   q.stagger = q.ipw >= 2 ? pt_stagger(DGRAD || NTAPS == 4) : 0;
+  q.prof = g_pt_prof;
   hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -736,6 +765,7 @@ inline int pt_enabled() {
 
 extern "C" void qt_set_pt_conv(int mode) { g_pt_enabled = mode < 0 ? 1 : mode; }
 extern "C" void qt_set_pt_conv_max_workgroups(int n) { g_pt_max_wgs_fwd = n > 0 ? n : 0; }
+extern "C" void qt_set_pt_prof(unsigned long long* buf) { g_pt_prof = buf; }   // profiling aid, not in the header
 
 // images the kernel walks (quadrant modes: four 7x7 region images per map) and the quadrant mode, -1: not covered
 static int pt_images(const ConvArgs& a, bool dgrad, int* quad) {

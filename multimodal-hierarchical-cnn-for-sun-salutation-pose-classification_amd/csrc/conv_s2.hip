@@ -349,6 +349,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
     // the next item's first K-tile needs (its plane A, weight tiles 0 and 1: all issued at least a segment ago) is waited for
     // HERE, so that the first L segment behind the stores needs no vmcnt wait at all and nobody waits for a store to retire
     // before the second one (by then they have) ----
+    // Item boundary of the ping-pong.  Group 1 runs one barrier behind group 0: without the next two lines its last barrier of
+    // the item pairs with group 0's FIRST barrier of the next item (or the one behind the loop), i.e. group 1 sits out group 0's
+    // whole epilogue and group 0 then waits for group 1's -- the two epilogues ran one after the other (measured on conv_pt, scripts/pt_phases.py).  Group 0 takes one extra
+    // barrier BEFORE its epilogue (pairs with group 1's last), so both epilogues run side by side; group 1 takes one extra
+    // barrier AFTER its epilogue when another item follows, which restores the one-barrier offset exactly as at the start.
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       int drow[TM];
@@ -424,11 +430,11 @@ __global__ __launch_bounds__(kNT, 2) void conv_s2_kernel(S2Args q) {
         }
       }
     }
+    if (grp == 1 && it + 1 < item_end) asm volatile("s_barrier" ::: "memory");   // (see the item boundary above)
     cur = nxt_item;
   }
   // the branch-free slots of the last K-tiles wrote zeros into dead buffers: they must have landed before the LDS is
   // handed to another workgroup
-  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (group 1's last MFMA segment)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
