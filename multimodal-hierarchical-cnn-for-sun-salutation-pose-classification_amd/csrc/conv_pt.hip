@@ -171,6 +171,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   constexpr int RW = BN / 64;               // LDS-DMA instructions per wave and weight tile (64 rows per pass)
   constexpr int D = NBW - 1;                // weight tiles in flight
   constexpr bool WFIRST = NTAPS == 9;       // L segments issue the weight tile before the patch pass (see the K loop)
+#ifdef QT_PT_ABLATE   // experiment build only (scripts/pt_ablate.sh): K-loop parts switched off by bits of -stagger
+  const int abl = q.stagger < 0 ? -q.stagger : 0;
+#define QT_ABL(bit) (abl & (bit))
+#else
+#define QT_ABL(bit) false
+#endif
   constexpr int WSLOT = BN * kKB;           // bytes of a weight ring slot
   constexpr bool AFF_LDS = BN == 128;       // room behind the rings for the per-channel vectors of the epilogue
   static_assert(TN % 2 == 0 && TN >= 2, "a wave owns whole 32-channel groups");
@@ -395,12 +401,14 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
           });
         };
         if constexpr (!WFIRST) issue_patch();
-        {
+        if (!QT_ABL(1)) {
           constexpr int u = (tap + D) % NTAPS;
           constexpr bool wrap = tap + D >= NTAPS;
           dma_weights(wrap ? rs_wgt_n : rs_wgt, (wrap ? n_woff : c_woff) + (unsigned)u * tap_bytes, wr);
         }
-        if constexpr (WFIRST) issue_patch();
+        if constexpr (WFIRST) {
+          if (!QT_ABL(2)) issue_patch();
+        }
         wr = wr + 1 == NBW ? 0 : wr + 1;
         // fragments of K-tile t: patch rows shifted by the tap, this K-tile's weight slot
         const int kh = MERGE ? (tap >> 1) + 1 : tap / 3, kw = MERGE ? (tap & 1) + 1 : tap % 3;
@@ -413,12 +421,23 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         const unsigned char* pw = smem + 2 * patch_bytes + rd * WSLOT;
         rd = rd + 1 == NBW ? 0 : rd + 1;
         uint4 fw[2][TN], fa[2][TM];
+#ifdef QT_PT_ABLATE   // (fragments that are not read: whatever the registers hold, no instruction)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
-          fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) asm volatile("" : "=v"(fw[kk][i].x), "=v"(fw[kk][i].y), "=v"(fw[kk][i].z), "=v"(fw[kk][i].w));
+#pragma unroll
+          for (int j = 0; j < TM; ++j) asm volatile("" : "=v"(fa[kk][j].x), "=v"(fa[kk][j].y), "=v"(fa[kk][j].z), "=v"(fa[kk][j].w));
         }
-        {
+#endif
+        if (!QT_ABL(4)) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
+            fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
+          }
+        }
+        if (!QT_ABL(8)) {
           const int rowb = a_lane + sh;
           const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
 #pragma unroll
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         // (weights first: the patch passes of segment t + 1 - D sit behind the weight tile waited for and may stay in flight)
         constexpr int behind = WFIRST ? passes_in<NTAPS, NPASS, D>((tap + 1 - D + 2 * NTAPS) % NTAPS) : 0;
         constexpr int allowed = in_t + (D == 3 ? in_tm1 : 0) + behind;
-        if (tap < D - 1 && after_epilogue) {   // (uniform)
+        if ((tap < D - 1 && after_epilogue) || QT_ABL(16)) {   // (uniform)
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(allowed) : "memory");
@@ -443,12 +462,14 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- C_t ----
         __builtin_amdgcn_s_setprio(1);
+        if (!QT_ABL(32)) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+          for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[kk][i], fa[kk][j]);
+              for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[kk][i], fa[kk][j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_barrier" ::: "memory");
@@ -708,7 +729,7 @@ int launch(PtArgs q, hipStream_t stream) {
   q.c.gridM = q.tiles_m;
   q.items = q.tiles_m * q.c.gridN;
   q.ipw = BN == 128 ? qt_cdiv(q.items, pt_workgroups()) : 1;
-  q.stagger = q.ipw >= 2 ? pt_stagger(DGRAD || NTAPS == 4) : 0;
+  q.stagger = (q.ipw >= 2 || pt_stagger(DGRAD || NTAPS == 4) < 0) ? pt_stagger(DGRAD || NTAPS == 4) : 0;   // (< 0: experiment builds)
   q.prof = g_pt_prof;
   hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
   QT_CHECK_LAUNCH();
