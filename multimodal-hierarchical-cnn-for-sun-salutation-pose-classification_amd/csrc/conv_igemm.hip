@@ -54,6 +54,10 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
 
+  auto stamp = [&](int i) {
+    if (p.prof && tid == 0) p.prof[(long long)blockIdx.x * 4 + i] = wall_clock64();
+  };
+  stamp(0);   // entry
   const int bid = qt_xcd_remap(blockIdx.x, p.gridM * p.gridN);
   const int mt = bid / p.gridN, nt = bid - mt * p.gridN;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
     a_mask[i] = 0;
     a_ptr[i] = src;
     if (m < p.M) {
-      int img = m / OHW;
+      int img = (int)fdiv((unsigned)m, p.div_ohw);   // (multiply-shift: two runtime divisions per staged row were ~2 us of every workgroup)
       int rem = m - img * OHW;
-      int oh = rem / p.OW;
+      int oh = (int)fdiv((unsigned)rem, p.div_ow);
       int ow = rem - oh * p.OW;
       long long base;
       if (p.quad) {
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   // is visible and nobody still reads the buffer about to be refilled), issue stage
   // ks+NSTAGE-1, then the MFMAs of stage ks.
   constexpr int DPS = RA + RW;  // DMA instructions per wave per stage
+  stamp(1);   // addressing done
   if constexpr (NSTAGE == 1) {
     if (nk > 0) dma_stage(0, 0);
     for (int ks = 0; ks < nk; ++ks) {
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all reads done before the epilogue reuses LDS
 
+  stamp(2);   // K loop done
   // ---- epilogue: accumulators -> LDS f32 [BM][BN] (chunk-swizzled) -------------
   // lane holds channels n = 4*(lane>>4)+r of pixel (lane&15) for each 16x16 tile.
   constexpr int ROWB = BN * 4;  // bytes per staged pixel row
@@ -594,6 +600,7 @@ if (p.scale || p.shift) {  // (uniform)
       }
     }
   }
+  stamp(3);   // epilogue done
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool DGRAD, int EH = 1>
@@ -688,6 +695,9 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   return d->dst_merge > 0 ? rows * (d->n_out / d->dst_merge) : rows;  // merged parity classes: one row per class
 }
 
+unsigned long long* g_igemm_prof = nullptr;
+extern "C" void qt_set_igemm_prof(unsigned long long* buf) { g_igemm_prof = buf; }   // profiling aid, not in the header
+
 extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   QT_CHECK_ARG(d && io, "qt_conv2d_igemm: null descriptor");
   QT_CHECK_ARG(d->dtype == QT_F32 || d->dtype == QT_BF16, "qt_conv2d_igemm: bad dtype %d", d->dtype);
@@ -735,6 +745,7 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.src = io->src; a.wgt = io->weight; a.dst = io->dst;
   a.scale = io->scale; a.shift = io->shift;
   a.residual = io->residual; a.relu_mask = io->relu_mask; a.relu_mask_bits = io->relu_mask_bits;
+  a.prof = g_igemm_prof;
   a.stats_partial = io->stats_partial;
   for (int k = 0; k < 2; ++k) {
     a.bn_y[k] = io->bwd_bn[k].y; a.bn_mean[k] = io->bwd_bn[k].mean; a.bn_invstd[k] = io->bwd_bn[k].invstd;
