@@ -484,11 +484,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_tile_kernel(WTArgs a) {
             fa[(jj + 1) & 1][t - 2] = frag(a_base[t - 2] + boff + (unsigned)(jj + 1) * kStride);
           if (t == 0 || t == 4) dma_x();            // 2 NJ slots for X, NJ for dY (exactly its share when the next
           if (t == 7) dma_y();                      // tile is full)
+          // (raised priority for the four MFMAs of a tap: the SIMD's other wave gets its reads and DMA slots in between,
+          // not in the middle of a burst -- 1-3 % per launch; a start skew between the two wave groups measured slower)
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[jj & 1][i]),
                                                                 __builtin_bit_cast(bf16x8, fb[(jj * 9 + t) % 3]),
                                                                 acc[i][t], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
         }
       }
     }
