@@ -186,6 +186,13 @@ static_assert(SP_IN_ROWS * ST_ROWB <= SP_BUF, "input rows of a fused tile fit on
 constexpr int SP_PXB = 144;                        // bytes per pixel in the conv tile (128 + pad)
 constexpr int SP_TILE = 5 * 112 * SP_PXB;          // 80640
 constexpr int SP_LDS = 2 * SP_BUF + SP_TILE;
+// RAW form (round 3): the kernel reads the f32 NCHW image itself -- no qt_pack_stem_input pass, no packed copy in HBM.
+// The 45 image rows a tile needs (15 rows x 3 planes, 896 B each) arrive by LDS-DMA in a 1 KB-per-row staging area and
+// one conversion pass rewrites them as the 15 packed bf16 rows (zero border included) the conv phase reads; staging is
+// single buffered (the next tile's rows are requested right after the conversion, behind conv + pool of this tile).
+constexpr int SP_RAW_STG = 45 * 1024;
+constexpr int SP_LDS_RAW = SP_BUF + SP_RAW_STG + SP_TILE;
+static_assert(SP_LDS_RAW <= 160 * 1024, "raw-input form fits the LDS");
 
 struct StemPoolArgs {
   const bf16_t* x;        // [B][230][232][4]
@@ -194,15 +201,17 @@ struct StemPoolArgs {
   const float* scale;
   const float* shift;
   int taps, ntiles;       // ntiles = B * 28
+  const float* img;       // RAW: [B][3][224][224] f32 (x unused)
 };
 
+template <bool RAW>
 __global__ __launch_bounds__(512) void conv_stem_pool_kernel(StemPoolArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const unsigned smem_base = lds_addr_of(smem);
-  unsigned char* ctile = smem + 2 * SP_BUF;
+  unsigned char* ctile = smem + (RAW ? SP_BUF + SP_RAW_STG : 2 * SP_BUF);
 
   const int t_beg = (int)((long long)blockIdx.x * p.ntiles / gridDim.x);
   const int t_end = (int)((long long)(blockIdx.x + 1) * p.ntiles / gridDim.x);
@@ -239,12 +248,77 @@ __global__ __launch_bounds__(512) void conv_stem_pool_kernel(StemPoolArgs p) {
     }
   };
 
-  if (t_beg < t_end) dma_tile(t_beg, 0);
+  // RAW: staging row (c, j) <- image row 8k - 5 + j of plane c (packed row 8k - 2 + j is image row 8k - 5 + j), where it
+  // exists; 56 lanes x 16 B per row, 45 rows dealt over the 8 waves
+  auto dma_raw = [&](int tile) {
+    const int img = tile / 28, k = tile - img * 28;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int r = wave + 8 * i;           // c * 15 + j
+      if (r < 45) {
+        const int c = r / 15, j = r - c * 15;
+        const int h = 8 * k - 5 + j;
+        if ((unsigned)h < 224u && lane < 56)
+          glds16(p.img + (((size_t)img * 3 + c) * 224 + h) * 224 + lane * 4, smem_base + SP_BUF + r * 1024);
+      }
+    }
+  };
+  // staging -> packed rows [15][232][4] bf16 in buffer 0 (same rounding as qt_pack_stem_input).  One pixel per thread and
+  // round: consecutive lanes read consecutive floats of a plane row and write consecutive 8-byte pixels (no bank conflicts)
+  auto convert_raw = [&](int tile) {
+    const int k = tile % 28;
+    // four pixels per thread and round: image columns 4g .. 4g+3 (one aligned 16-byte read per plane) are packed pixels
+    // 4g+3 .. 4g+6; 15 x 56 = 840 items in two rounds, both rounds' reads in flight together
+    f32x4 v[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int it = tid + r * 512;
+      const int j = it / 56, g = it - j * 56;
+      const int h = 8 * k - 5 + j;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (it < 840 && (unsigned)h < 224u) {
+        const unsigned char* s0 = smem + SP_BUF + j * 1024 + g * 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[r][c] = *reinterpret_cast<const f32x4*>(s0 + c * 15 * 1024);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int it = tid + r * 512;
+      const int j = it / 56, g = it - j * 56;
+      if (it < 840) {
+        unsigned char* d = smem + j * ST_ROWB + (4 * g + 3) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bf16x4 o = {(bf16_t)v[r][0][q], (bf16_t)v[r][1][q], (bf16_t)v[r][2][q], (bf16_t)0.f};
+          *reinterpret_cast<bf16x4*>(d + q * 8) = o;
+        }
+      }
+    }
+    // the zero border: packed pixels 0..2 and 227..231 of the 15 rows
+    if (tid < 15 * 8) {
+      const int j = tid >> 3, b = tid & 7;
+      const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+      *reinterpret_cast<bf16x4*>(smem + j * ST_ROWB + (b < 3 ? b : 224 + b) * 8) = z;
+    }
+  };
+
+  if (t_beg < t_end) {
+    if constexpr (RAW) dma_raw(t_beg);
+    else dma_tile(t_beg, 0);
+  }
   for (int t = t_beg; t < t_end; ++t) {
-    const int buf = (t - t_beg) & 1;
+    const int buf = RAW ? 0 : (t - t_beg) & 1;
     // this tile's rows have landed; every wave is done pooling the previous tile (conv tile free) and reading its input
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);
+    if constexpr (RAW) {
+      convert_raw(t);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // packed rows complete, staging free
+      if (t + 1 < t_end) dma_raw(t + 1);
+    } else {
+      if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);
+    }
     const unsigned char* in = smem + buf * SP_BUF;
     const int img = t / 28, k = t - img * 28;
     // ---- conv phase: 35 blocks of 16 pixels (tile row tr = 0..4 <-> conv row 4k - 1 + tr), wave w takes w, w+8, ... ----
@@ -369,12 +443,39 @@ extern "C" int qt_stem_conv_pool(int dtype, const void* xpad, const void* weight
     return QT_ERR_UNSUPPORTED;
   }
   StemPoolArgs a;
-  a.x = static_cast<const bf16_t*>(xpad); a.w = static_cast<const bf16_t*>(weight);
+  a.x = static_cast<const bf16_t*>(xpad); a.w = static_cast<const bf16_t*>(weight); a.img = nullptr;
   a.pooled = static_cast<bf16_t*>(pooled); a.scale = scale; a.shift = shift; a.taps = taps; a.ntiles = batch * 28;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
-  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(conv_stem_pool_kernel), SP_LDS, lds_limit_set)) return rc;
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(conv_stem_pool_kernel<false>), SP_LDS, lds_limit_set)) return rc;
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
-  hipLaunchKernelGGL(conv_stem_pool_kernel, dim3(grid), dim3(512), SP_LDS, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(conv_stem_pool_kernel<false>, dim3(grid), dim3(512), SP_LDS, static_cast<hipStream_t>(stream), a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+// The same from the f32 NCHW image the reference's dataloader hands over ([B][3][224][224]): packing, conv1, BatchNorm,
+// ReLU and the max pool in one launch; bit-identical to qt_pack_stem_input + qt_stem_conv_pool.
+extern "C" int qt_stem_conv_pool_nchw(int dtype, const float* image_nchw, const void* weight, int taps, const float* scale,
+                                      const float* shift, void* pooled, int batch, void* stream) {
+  QT_CHECK_ARG(image_nchw && weight && scale && shift && pooled && batch > 0 && (taps == 7 || taps == 8),
+               "qt_stem_conv_pool_nchw: bad argument");
+  QT_CHECK_ARG(((uintptr_t)image_nchw % 16) == 0, "qt_stem_conv_pool_nchw: the image must be 16-byte aligned");
+  static int raw_on = -1;
+  if (raw_on < 0) {
+    const char* e = getenv("QTCNN_STEM_NCHW");
+    raw_on = e ? atoi(e) : 1;
+  }
+  if (dtype != QT_BF16 || !stem_enabled() || !raw_on) {
+    qt_set_error("qt_stem_conv_pool_nchw: bf16 only (use qt_pack_stem_input + qt_stem_conv_pool)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  StemPoolArgs a;
+  a.x = nullptr; a.img = image_nchw; a.w = static_cast<const bf16_t*>(weight);
+  a.pooled = static_cast<bf16_t*>(pooled); a.scale = scale; a.shift = shift; a.taps = taps; a.ntiles = batch * 28;
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(conv_stem_pool_kernel<true>), SP_LDS_RAW, lds_limit_set)) return rc;
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  hipLaunchKernelGGL(conv_stem_pool_kernel<true>, dim3(grid), dim3(512), SP_LDS_RAW, static_cast<hipStream_t>(stream), a);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

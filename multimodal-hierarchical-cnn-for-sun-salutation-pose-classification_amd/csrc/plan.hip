@@ -916,20 +916,31 @@ int forward(qt_plan* p, void* workspace, void* const* T, const float* image, con
   if (p->has_image) {
     if (!tr) e.eval_affines(unf);
     // ---- stem: pack -> conv7x7/2 (7 row taps x 32) -> BN -> ReLU -> maxpool ----
-    e.run(qt_pack_stem_input(dt, image, e.at(p->xpad), batch, stream));
     const ConvL& c0 = p->convs[0];
     const BnL& bn0 = p->bns[c0.bn];
     const qt_conv_desc sd = e.stem_desc();
-    e.conv_bn_stats(c0, sd, e.at(p->xpad), training);
+    // eval (bf16): the f32 NCHW image -> packing, conv1, folded bn1, ReLU and the max pool in ONE kernel; neither the packed
+    // copy of the input nor the conv1 map is materialised
+    int fused = QT_ERR_UNSUPPORTED;
+    if (!unf) {
+      const int slot = e.begin_timed(e.conv_flops(sd), 0, nullptr,
+                                     (double)batch * (3.0 * 224 * 224 * 4 + p->esz * 56.0 * 56 * 64));
+      fused = qt_stem_conv_pool_nchw(dt, image, e.at(c0.w_fwd), e.stem_taps(), e.at<float>(bn0.scale),
+                                     e.at<float>(bn0.shift), e.at(p->p0), batch, stream);
+      e.end_timed(slot);
+      if (fused != QT_ERR_UNSUPPORTED) e.run(fused);
+    }
+    if (fused == QT_ERR_UNSUPPORTED) e.run(qt_pack_stem_input(dt, image, e.at(p->xpad), batch, stream));
+    if (fused == QT_ERR_UNSUPPORTED) e.conv_bn_stats(c0, sd, e.at(p->xpad), training);
     if (unf) {
       e.run(qt_stem_pool(dt, e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), e.at(p->p0),
                          e.at<unsigned char>(p->argmax), e.at(p->ymax), batch, stream));
-    } else {
-      // eval: conv1 + folded bn1 + ReLU + max pool in one kernel (bf16); the conv1 map is not materialised
+    } else if (fused == QT_ERR_UNSUPPORTED) {
+      // conv1 + folded bn1 + ReLU + max pool on the packed input (f32 build: two kernels)
       const int slot = e.begin_timed(e.conv_flops(sd), 0, nullptr,
                                      (double)batch * p->esz * ((double)QT_STEM_PAD_H * QT_STEM_PAD_W * 4 + 56.0 * 56 * 64));
-      const int fused = qt_stem_conv_pool(dt, e.at(p->xpad), e.at(c0.w_fwd), e.stem_taps(), e.at<float>(bn0.scale),
-                                          e.at<float>(bn0.shift), e.at(p->p0), batch, stream);
+      fused = qt_stem_conv_pool(dt, e.at(p->xpad), e.at(c0.w_fwd), e.stem_taps(), e.at<float>(bn0.scale),
+                                e.at<float>(bn0.shift), e.at(p->p0), batch, stream);
       e.end_timed(slot);
       if (fused == QT_ERR_UNSUPPORTED) {
         e.igemm(sd, e.at(p->xpad), e.at(c0.w_fwd), e.at(c0.y), e.at<float>(bn0.scale), e.at<float>(bn0.shift), nullptr,

@@ -210,9 +210,21 @@ def test_stem_conv_pool_fused_eval_kernel(B):
     ones, zeros = torch.ones(64, device=dev), torch.zeros(64, device=dev)
     pooled2 = torch.empty(B, 56, 56, 64, device=dev, dtype=dt)
     L.check(lib.qt_stem_pool(qdt, L.ptr(y), L.ptr(ones), L.ptr(zeros), L.ptr(pooled2), None, None, B, st), "qt_stem_pool")
+    # the form that reads the f32 NCHW image itself (no packed copy): images that are not bf16-exact, so that the in-kernel
+    # rounding is exercised, against qt_pack_stem_input + qt_stem_conv_pool on the same images
+    image2 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    xpad2 = torch.empty(B, 230, 232, 4, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_input(qdt, L.ptr(image2), L.ptr(xpad2), B, st), "qt_pack_stem_input")
+    pooled3 = torch.full((B, 56, 56, 64), float("nan"), device=dev, dtype=dt)
+    L.check(lib.qt_stem_conv_pool(qdt, L.ptr(xpad2), L.ptr(wp), 8, L.ptr(sc), L.ptr(sh), L.ptr(pooled3), B, st), "qt_stem_conv_pool")
+    pooled4 = torch.full((B, 56, 56, 64), float("nan"), device=dev, dtype=dt)
+    L.check(lib.qt_stem_conv_pool_nchw(qdt, L.ptr(image2), L.ptr(wp), 8, L.ptr(sc), L.ptr(sh), L.ptr(pooled4), B, st),
+            "qt_stem_conv_pool_nchw")
     torch.cuda.synchronize()
     assert torch.equal(pooled, pooled2)                       # same MFMA order, same rounding: bit-identical
     assert rel_err(pooled.float().cpu().permute(0, 3, 1, 2), ref) <= 4e-3
+    assert not torch.isnan(pooled4.float()).any()
+    assert torch.equal(pooled3, pooled4)
 
 
 def test_stem_conv_pool_negative_zero_is_not_a_maximum():
