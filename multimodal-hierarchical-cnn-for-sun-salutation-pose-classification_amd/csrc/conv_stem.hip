@@ -348,32 +348,41 @@ __global__ __launch_bounds__(512) void conv_stem_pool_kernel(StemPoolArgs p) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the conv tile is complete
-    // ---- pool phase: 2 pooled rows x 56 pixels x 8 channel groups = 896 items ----
-    for (int it = tid; it < 896; it += 512) {
-      const int cg = it & 7, pw = (it >> 3) % 56, pi = it / (8 * 56);
+    // ---- pool phase: one thread per (pooled column, 8-channel group) does BOTH pooled rows of the tile: the five conv rows
+    // x three columns it needs are 15 reads in flight at once (two rounds of nine-read items before: 18 reads per pair and
+    // two exposed LDS latencies), the middle row's column maximum is shared ----
+    if (tid < 448) {
+      const int cg = tid & 7, pw = tid >> 3;
       // The tile holds ReLU outputs: non-negative bf16 values order like their bit patterns, so the 3x3 maximum is a
       // packed SIGNED 16-bit maximum on the raw words (a -0 the ReLU may have let through is then the smallest value,
       // as it is for the float maximum against the +0 start): 4 instructions per 8 channels and window cell instead of
       // 8 unpacks + 8 float maxima, and the result is the same bf16 value, bit for bit.
       typedef short us2 __attribute__((ext_vector_type(2)));
-      uint4 best = make_uint4(0u, 0u, 0u, 0u);
       auto pkmax = [](unsigned a, unsigned b) -> unsigned {
         return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
       };
+      auto max4 = [&](const uint4& a, const uint4& b) -> uint4 {
+        return make_uint4(pkmax(a.x, b.x), pkmax(a.y, b.y), pkmax(a.z, b.z), pkmax(a.w, b.w));
+      };
+      const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+      uint4 raw[5][3];
 #pragma unroll
-      for (int dr = 0; dr < 3; ++dr) {
-        const int tr = 2 * pi + dr;               // conv row 4k - 1 + tr
-        if (k == 0 && tr == 0) continue;
+      for (int tr = 0; tr < 5; ++tr)
 #pragma unroll
         for (int dc = 0; dc < 3; ++dc) {
           const int col = 2 * pw - 1 + dc;
-          if ((unsigned)col >= 112u) continue;
-          const uint4 raw = *reinterpret_cast<const uint4*>(ctile + (tr * 112 + col) * SP_PXB + cg * 16);
-          best.x = pkmax(best.x, raw.x); best.y = pkmax(best.y, raw.y);
-          best.z = pkmax(best.z, raw.z); best.w = pkmax(best.w, raw.w);
+          raw[tr][dc] = zero;                       // (out-of-image cells: 0 never beats a ReLU output)
+          if (!(k == 0 && tr == 0) && (unsigned)col < 112u)
+            raw[tr][dc] = *reinterpret_cast<const uint4*>(ctile + (tr * 112 + col) * SP_PXB + cg * 16);
         }
+      uint4 rowmax[5];
+#pragma unroll
+      for (int tr = 0; tr < 5; ++tr) rowmax[tr] = max4(max4(raw[tr][0], raw[tr][1]), raw[tr][2]);
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const uint4 best = max4(max4(rowmax[2 * pi], rowmax[2 * pi + 1]), rowmax[2 * pi + 2]);
+        *reinterpret_cast<uint4*>(p.pooled + (((size_t)img * 56 + 2 * k + pi) * 56 + pw) * 64 + cg * 8) = best;
       }
-      *reinterpret_cast<uint4*>(p.pooled + (((size_t)img * 56 + 2 * k + pi) * 56 + pw) * 64 + cg * 8) = best;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
