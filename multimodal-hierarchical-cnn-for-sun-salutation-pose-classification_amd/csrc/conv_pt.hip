@@ -156,7 +156,7 @@ constexpr int passes_before(int tap) {
 // (2r + class/2, 2c + class%2) of the C-channel map, where residual / mask / BatchNorm links are read.  All four slots are
 // multiplied for every class (the slots a class does not use hold zero weights: 16/9 of the products) -- still 2-3 x
 // faster than the generic tile on these short-K launches.
-template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9>
+template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9, bool KS = false>
 __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   static_assert(NTAPS == 9 || (NTAPS == 4 && !DGRAD && BN == 128 && NBW == 3), "tap sets");
   static_assert(NPASS >= 1 && NPASS <= kMaxPass && (NTAPS != 9 || NPASS - 1 <= 9 - (NBW - 1)),
@@ -166,8 +166,16 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   static_assert(BN == 128 || BN == 256, "channel tile");
   static_assert(NBW == 3 || NBW == 4, "weight ring slots");
   constexpr int TM = GEO == GEO_STACK ? 8 : 7;   // 16-row tiles per wave (two wave rows)
-  constexpr int TN = BN / 4 / 16;           // 16-channel tiles per wave (4 channel quarters)
-  constexpr int NP = TN / 2;                // pairs of them = 32-channel groups
+  // KS ("K-split", 128-channel tile): a wave group owns the WHOLE 224 x 128 tile for one of the two 32-wide k-steps of every
+  // K-tile -- wave tile 112 pixels x 64 channels, 11 fragment reads per 28 MFMAs instead of 18 (the 112 x 32 wave tile is
+  // bound by its load segments: DESIGN.md 5) -- and the two groups add their partial sums through LDS before the epilogue,
+  // each finalising one 32-channel half of the wave tile.  One item per workgroup (the exchange needs the LDS the
+  // persistent walk keeps busy with the next item's tiles).
+  static_assert(!KS || (BN == 128 && NTAPS == 9), "K-split: 128-channel tile, nine taps");
+  constexpr int CW = KS ? 64 : BN / 4;      // channels per wave
+  constexpr int TN = CW / 16;               // 16-channel tiles per wave
+  constexpr int NP = KS ? 1 : TN / 2;       // 32-channel groups a wave FINALISES
+  constexpr int NKK = KS ? 1 : 2;           // k-steps of a K-tile a wave multiplies
   constexpr int RW = BN / 64;               // LDS-DMA instructions per wave and weight tile (64 rows per pass)
   constexpr int D = NBW - 1;                // weight tiles in flight
   constexpr bool WFIRST = NTAPS == 9;       // L segments issue the weight tile before the patch pass (see the K loop)
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;               // waves w and w+4 share a SIMD: one of each group per SIMD
-  const int wm = grp, wn = wave & 3;       // pixel half, channel quarter
+  const int wm = KS ? (wave >> 1) & 1 : grp, wn = KS ? wave & 1 : wave & 3;   // pixel half, channel quarter (K-split: half)
   const int frow = lane & 15, fk = lane >> 4;
 
   // PERSISTENT (round 3): a workgroup walks `ipw` consecutive items = (channel tile nt, pixel tile mt), nt-major; the
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int wg = qt_xcd_remap(blockIdx.x, gridDim.x);
   // (the 256-channel tile has no register room for the walk's state next to its epilogue: one item per workgroup there --
   // which is what 256 images give its 14x14 stage anyway; the loop below then runs once and its state dies in the epilogue)
-  constexpr bool PERSIST = BN == 128;
+  constexpr bool PERSIST = BN == 128 && !KS;
   const int item_begin = __builtin_amdgcn_readfirstlane(PERSIST ? wg * q.ipw : wg);
   const int item_end = PERSIST ? min(item_begin + q.ipw, q.items) : item_begin + 1;
   if (item_begin >= q.items) return;   // (uniform, before any barrier)
@@ -317,7 +325,8 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   const int a_lane = (wm * (TM * 16) + frow) * kKB;
   int b_off[2];       // lane part of a weight-fragment address: row frow, chunk (kk*4 + fk) ^ (frow & 7)
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) b_off[kk] = (wn * (BN / 4) + frow) * kKB + (((kk * 4 + fk) ^ (frow & 7)) << 4);
+  for (int kk = 0; kk < 2; ++kk) b_off[kk] = (wn * CW + frow) * kKB + (((kk * 4 + fk) ^ (frow & 7)) << 4);
+  if constexpr (KS) b_off[0] = grp ? b_off[1] : b_off[0];   // (the group's k-step)
 
   f32x4 acc[TN][TM];
 
@@ -420,10 +429,10 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         const unsigned char* pa = patch + sh;
         const unsigned char* pw = smem + 2 * patch_bytes + rd * WSLOT;
         rd = rd + 1 == NBW ? 0 : rd + 1;
-        uint4 fw[2][TN], fa[2][TM];
+        uint4 fw[NKK][TN], fa[NKK][TM];
 #ifdef QT_PT_ABLATE   // (fragments that are not read: whatever the registers hold, no instruction)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
           for (int i = 0; i < TN; ++i) asm volatile("" : "=v"(fw[kk][i].x), "=v"(fw[kk][i].y), "=v"(fw[kk][i].z), "=v"(fw[kk][i].w));
 #pragma unroll
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
 #pragma unroll
           for (int i = 0; i < TN; ++i) {
             fw[0][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[0]);
-            fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
+            if constexpr (!KS) fw[1][i] = *reinterpret_cast<const uint4*>(pw + i * (16 * kKB) + b_off[1]);
           }
         }
         if (!QT_ABL(8)) {
@@ -442,8 +451,12 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
           const int a0 = a_lane + (((fk ^ (rowb >> 7)) & 7) << 4);   // chunk fk ^ (row & 7); chunk 4+fk is that ^ 64 bytes
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
-            fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0 + j * (16 * kKB));
-            fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64) + j * (16 * kKB));
+            if constexpr (KS) {
+              fa[0][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ (grp << 6)) + j * (16 * kKB));   // (the group's k-step)
+            } else {
+              fa[0][j] = *reinterpret_cast<const uint4*>(pa + a0 + j * (16 * kKB));
+              fa[1][j] = *reinterpret_cast<const uint4*>(pa + (a0 ^ 64) + j * (16 * kKB));
+            }
           }
         }
         // Weight tile t+1 has landed once at most the instructions issued AFTER it are outstanding: those of
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
         __builtin_amdgcn_s_setprio(1);
         if (!QT_ABL(32)) {
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
+          for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -490,6 +503,38 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
     stamp();   // 1 + 3k: K loop of item k done
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp();   // 2 + 3k: the next item's first tiles have landed
+    if constexpr (KS) {
+      // K-split: the groups hold partial sums of the same 112 x 64 wave tiles.  Group 0 finalises the lower 32-channel
+      // half (accumulator tiles 0, 1), group 1 the upper (tiles 2, 3): each writes the half it does NOT finalise
+      // ((2 TM) x 1 KB per wave, lane-linear 16-byte stores: conflict free) and adds the partner's copy of its own half.
+      // The whole LDS is free: every wave has finished its K loop (barrier) and its DMA has landed (vmcnt(0) above).
+      asm volatile("s_barrier" ::: "memory");
+      unsigned char* xch = smem + (unsigned)((grp * 4 + (wave & 3)) * (2 * TM)) * 1024u + lane * 16;
+      if (grp) {   // (uniform branches: no per-lane selects, no second copy of the tiles)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) *reinterpret_cast<f32x4*>(xch + (i * TM + j) * 1024) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) *reinterpret_cast<f32x4*>(xch + (i * TM + j) * 1024) = acc[2 + i][j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned char* xin = smem + (unsigned)(((grp ^ 1) * 4 + (wave & 3)) * (2 * TM)) * 1024u + lane * 16;
+      if (grp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = acc[2 + i][j] + *reinterpret_cast<const f32x4*>(xin + (i * TM + j) * 1024);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(xin + (i * TM + j) * 1024);
+      }
+    }
     const int mt = cur_mt, n0 = cur_nt * BN;
     const int img0 = GEO == GEO_ROWS ? mt / q.tpi : mt * 4;
     const int row0 = GEO == GEO_ROWS ? (mt - img0 * q.tpi) * q.R : 0;
@@ -519,7 +564,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
       __builtin_amdgcn_sched_barrier(0);
-      const int cl = wn * (BN / 4) + pi * 32 + fk * 8;   // channel inside the tile
+      const int cl = wn * CW + (KS ? grp : pi) * 32 + fk * 8;   // channel inside the tile (K-split: the group's half)
       // merged parity classes: channel n0 + cl of the 4 C outputs is channel c0 of class mcls (uniform per wave: 32 | C)
       const int mcls = MERGE ? (n0 + cl) / NC : 0;
       const int c0 = MERGE ? (n0 + cl) - mcls * NC : n0 + cl;
@@ -718,17 +763,17 @@ inline int pt_workgroups() {
   return cus;
 }
 
-template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9>
+template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9, bool KS = false>
 int launch(PtArgs q, hipStream_t stream) {
   constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB + (BN == 128 ? 6 * 512 * 4 : 0);   // (+ the epilogue's vectors)
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, GEO, DGRAD, NTAPS>;
+  auto kern = conv_pt_kernel<T, BN, NBW, NPASS, GEO, DGRAD, NTAPS, KS>;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
   if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
   q.c.gridN = q.c.N / BN;
   q.c.gridM = q.tiles_m;
   q.items = q.tiles_m * q.c.gridN;
-  q.ipw = BN == 128 ? qt_cdiv(q.items, pt_workgroups()) : 1;
+  q.ipw = (BN == 128 && !KS) ? qt_cdiv(q.items, pt_workgroups()) : 1;
   q.stagger = (q.ipw >= 2 || pt_stagger(DGRAD || NTAPS == 4) < 0) ? pt_stagger(DGRAD || NTAPS == 4) : 0;   // (< 0: experiment builds)
   q.prof = g_pt_prof;
   hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
@@ -747,8 +792,33 @@ int dispatch_merged(const PtArgs& q, hipStream_t stream) {
   return QT_ERR_UNSUPPORTED;
 }
 
+// QTCNN_PT_KSPLIT (default 1): the 128-channel tile of the bf16 build in its K-split form (see the kernel); 0: the persistent
+// M-split form
+inline bool ksplit_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("QTCNN_PT_KSPLIT");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+
+inline bool ksplit_enabled_rows() {   // QTCNN_PT_KSPLIT=2: also the 28x28 stage (measurement)
+  const char* e = getenv("QTCNN_PT_KSPLIT");
+  return e && atoi(e) >= 2;
+}
+
 template <typename T, bool DGRAD>
 int dispatch(const PtArgs& q, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    if (ksplit_enabled() && g_pt_max_wgs_fwd == 0) {
+      // (7x7 stage: one item per workgroup in either form -- 50-57 -> 45-49 us of K loop per launch.  On the 28x28 stage the
+      // K loop gains as much, 14 -> 12 us per item, but four one-item workgroups per CU with their un-hidden prologues are
+      // slower than the persistent walk: 74 / 84 / 88 us against 69 / 79 / 86 (plain / eval epilogue / mask + link); not used)
+      if (q.G == 4) return launch<T, 128, 4, 5, GEO_STACK, DGRAD, 9, true>(q, stream);
+      if (q.npass == 5 && ksplit_enabled_rows()) return launch<T, 128, 4, 5, GEO_ROWS, DGRAD, 9, true>(q, stream);
+    }
+  }
   if (q.G == 4) return launch<T, 128, 4, 5, GEO_STACK, DGRAD>(q, stream);            // 7x7: 265 patch positions
   if (q.npass == 5) return launch<T, 128, 4, 5, GEO_ROWS, DGRAD>(q, stream);        // 28x28 quarter: 270
   if (q.npass == 4) {                                                                // 14x14: 256
