@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   // bound by its load segments: DESIGN.md 5) -- and the two groups add their partial sums through LDS before the epilogue,
   // each finalising one 32-channel half of the wave tile.  One item per workgroup (the exchange needs the LDS the
   // persistent walk keeps busy with the next item's tiles).
-  static_assert(!KS || (BN == 128 && NTAPS == 9), "K-split: 128-channel tile, nine taps");
+  static_assert(!KS || BN == 128, "K-split: 128-channel tile");
   constexpr int CW = KS ? 64 : BN / 4;      // channels per wave
   constexpr int TN = CW / 16;               // 16-channel tiles per wave
   constexpr int NP = KS ? 1 : TN / 2;       // 32-channel groups a wave FINALISES
@@ -781,17 +781,6 @@ int launch(PtArgs q, hipStream_t stream) {
   return QT_OK;
 }
 
-// merged stride-2 data gradient (four tap slots, 128-channel tiles of the 4 C class channels)
-template <typename T>
-int dispatch_merged(const PtArgs& q, hipStream_t stream) {
-  if (q.G == 4) return launch<T, 128, 3, 5, GEO_STACK, false, 4>(q, stream);
-  // (the GEO_ROWS forms - 28x28 and 14x14 gradient maps - were measured and are not instantiated: 8 / 16 K-tiles per item do not
-  // cover an epilogue that scatters 64-byte runs, 276 / 229 us in the train step against 156 / 118 us of the generic tile whose
-  // three workgroups per CU overlap their epilogues; on the 7x7 map, 32 K-tiles per item, this kernel wins 121 against 136 us)
-  qt_set_error("conv_pt (merged): only the 7x7 gradient map is instantiated");
-  return QT_ERR_UNSUPPORTED;
-}
-
 // QTCNN_PT_KSPLIT (default 1): the 128-channel tile of the bf16 build in its K-split form (see the kernel); 0: the persistent
 // M-split form
 inline bool ksplit_enabled() {
@@ -801,6 +790,20 @@ inline bool ksplit_enabled() {
     v = e ? atoi(e) : 1;
   }
   return v != 0;
+}
+
+// merged stride-2 data gradient (four tap slots, 128-channel tiles of the 4 C class channels)
+template <typename T>
+int dispatch_merged(const PtArgs& q, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    if (q.G == 4 && ksplit_enabled() && g_pt_max_wgs_fwd == 0) return launch<T, 128, 3, 5, GEO_STACK, false, 4, true>(q, stream);
+  }
+  if (q.G == 4) return launch<T, 128, 3, 5, GEO_STACK, false, 4>(q, stream);
+  // (the GEO_ROWS forms - 28x28 and 14x14 gradient maps - were measured and are not instantiated: 8 / 16 K-tiles per item do not
+  // cover an epilogue that scatters 64-byte runs, 276 / 229 us in the train step against 156 / 118 us of the generic tile whose
+  // three workgroups per CU overlap their epilogues; on the 7x7 map, 32 K-tiles per item, this kernel wins 121 against 136 us)
+  qt_set_error("conv_pt (merged): only the 7x7 gradient map is instantiated");
+  return QT_ERR_UNSUPPORTED;
 }
 
 inline bool ksplit_enabled_rows() {   // QTCNN_PT_KSPLIT=2: also the 28x28 stage (measurement)
