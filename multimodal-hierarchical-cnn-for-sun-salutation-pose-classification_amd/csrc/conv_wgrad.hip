@@ -367,6 +367,142 @@ int launch(WgradArgs a, hipStream_t stream) {
   return QT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stem (conv1 7x7 / 2, packed NHWC4 input) weight gradient from RAW input rows (round 3, bf16).
+//
+// The generic kernel above stages, per output pixel, its 7 x 64-byte window rows (40 KB per 64 pixels: ten LDS-DMA
+// instructions per wave and K-step for 28 MFMAs -- DMA-issue bound, 184 us) although neighbouring pixels share 3/4 of
+// every window row.  Here a workgroup stages the nine packed input rows of TWO output rows once (16.7 KB, one contiguous
+// block of the [B][230][232][4] image) next to their 224 x 64 gradient tile (28 KB): 45 KB per 224 pixels.  The pixel-major
+// MFMA fragments come from the transposing LDS read at PER-LANE addresses, so the im2col overlap costs nothing: the
+// fragment of pixel ow, window row kh, columns kw = 4h .. 4h+3 is the 32 bytes at byte 16 ow + 32 h of row 2 oh + kh.
+// Wave w < 7 owns window row kh = w: dW[64][kh][32] = 4 x 2 accumulator tiles; the pixel axis is the MFMA K axis
+// (7 blocks of 32 per tile).  Workgroups walk tiles persistently and add their filters with f32 atomics at the end.
+// ---------------------------------------------------------------------------------------------
+constexpr int SW_ROWB = QT_STEM_PAD_W * 4 * 2;     // 1856 bytes per packed input row
+constexpr int SW_XB = 17 * 1024;                   // >= 9 rows
+constexpr int SW_DYB = 224 * 128;                  // 28 KB: two output rows x 112 pixels x 64 channels
+constexpr int SW_BUF = SW_XB + SW_DYB;
+constexpr int SW_LDS = 2 * SW_BUF;
+static_assert(9 * SW_ROWB <= SW_XB, "nine input rows fit their block");
+
+struct StemWgArgs {
+  const bf16_t* dy;   // [B][112][112][64]
+  const bf16_t* x;    // [B][230][232][4]
+  float* dw;          // [64][7][32], accumulated into
+  int ntiles;         // B * 56
+};
+
+__global__ __launch_bounds__(512) void stem_wgrad_rows_kernel(StemWgArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4, q = li >> 2, pp = li & 3;
+  const unsigned smem_base = lds_addr_of(smem);
+  const int t_beg = (int)((long long)blockIdx.x * p.ntiles / gridDim.x);
+  const int t_end = (int)((long long)(blockIdx.x + 1) * p.ntiles / gridDim.x);
+  if (t_beg >= t_end) return;
+
+  // 45 transfers of 1 KB per tile, dealt over the 8 waves: 17 of the input rows (a linear copy), 28 of the gradient tile
+  // (its 32-byte blocks XOR-swizzled by (row >> 1) & 3 on the source side, as in conv_wgrad_kernel: conflict-free reads)
+  auto dma_tile = [&](int tile, int buf) {
+    const int img = tile / 56, rp = tile - img * 56;
+    const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)img * QT_STEM_PAD_H + 4 * rp) * SW_ROWB;
+    const unsigned char* ds = reinterpret_cast<const unsigned char*>(p.dy) + ((size_t)img * 112 + 2 * rp) * (112 * 128);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int b = wave + 8 * i;
+      if (b < 17) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * SW_BUF + b * 1024);
+        if (b * 1024 + lane * 16 < 9 * SW_ROWB) glds16(xs + b * 1024 + lane * 16, dst);
+      } else if (b < 45) {
+        const int d = b - 17, r = d * 8 + (lane >> 3), sl = lane & 7;
+        const int c = (((sl >> 1) ^ ((r >> 1) & 3)) << 1) | (sl & 1);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * SW_BUF + SW_XB + d * 1024);
+        glds16(ds + r * 128 + c * 16, dst);
+      }
+    }
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_tile(t_beg, 0);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int buf = (t - t_beg) & 1;
+    // tile t has landed (every wave's share), and nobody reads the other buffer any more
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);
+    if (wave < 7) {
+      const unsigned char* xb = smem + buf * SW_BUF;
+      const unsigned char* db = xb + SW_XB;
+      const int kh = wave;
+      // fragments of K block kb: the lane's two pixel rows are r1 = 32 kb + 4 lg + q and r1 + 16
+      auto load_frags = [&](int kb, uint4 (&fa)[4], uint4 (&fb)[2]) {
+        const int r1 = kb * 32 + 4 * lg + q, r2 = r1 + 16;
+        const int key = (r1 >> 1) & 3;   // (== the key of r2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(db + r1 * 128 + ((i ^ key) << 5) + pp * 8));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(db + r2 * 128 + ((i ^ key) << 5) + pp * 8));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+        const int o1 = r1 >= 112, o2 = r2 >= 112;
+        const unsigned char* x1 = xb + (2 * o1 + kh) * SW_ROWB + (2 * (r1 - 112 * o1) + pp) * 8;
+        const unsigned char* x2 = xb + (2 * o2 + kh) * SW_ROWB + (2 * (r2 - 112 * o2) + pp) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(x1 + h * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(x2 + h * 32));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fb[h] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+      };
+      // (the next block's twelve transposing reads are in flight under the eight MFMAs of the current one)
+      uint4 fa[2][4], fb[2][2];
+      load_frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int kb = 0; kb < 7; ++kb) {
+        if (kb + 1 < 7) load_frags(kb + 1, fa[(kb + 1) & 1], fb[(kb + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[kb & 1][i]),
+                                                                __builtin_bit_cast(bf16x8, fb[kb & 1][h]), acc[i][h], 0, 0, 0);
+      }
+    }
+  }
+  // lane holds rows co = 16 i + 4 lg + r, column n = 16 h + li of its window row
+  if (wave < 7) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = i * 16 + lg * 4 + r, n = h * 16 + li;
+          atomicAdd(p.dw + (co * 7 + wave) * 32 + n, acc[i][h][r]);
+        }
+  }
+}
+
+int launch_stem_rows(const void* dy, const void* x, float* dw, int batch, hipStream_t stream) {
+  StemWgArgs a;
+  a.dy = static_cast<const bf16_t*>(dy); a.x = static_cast<const bf16_t*>(x); a.dw = dw; a.ntiles = batch * 56;
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(stem_wgrad_rows_kernel), SW_LDS, lds_limit_set)) return rc;
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  hipLaunchKernelGGL(stem_wgrad_rows_kernel, dim3(grid), dim3(512), SW_LDS, stream, a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
 }  // namespace
 
 // conv_wgrad_patch.hip: streaming kernel for 3x3 / stride 1 / pad 1 (bf16)
@@ -423,7 +559,19 @@ extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const v
   // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
   const bool stem = d->k_per_tap == 32 && d->kw == 1 && d->kh == 7 && d->n_out == 64;
   if (d->dtype == QT_BF16) {
-    if (stem) return launch<bf16_t, 64, 224, true>(a, s);
+    if (stem) {
+      // QTCNN_STEM_WGRAD_ROWS (default 1): the raw-row kernel for the canonical stem geometry; 0: the generic kernel
+      static int rows_on = -1;
+      if (rows_on < 0) {
+        const char* e = getenv("QTCNN_STEM_WGRAD_ROWS");
+        rows_on = e ? atoi(e) : 1;
+      }
+      if (rows_on && d->kh == 7 && d->stride == 2 && d->pad == 0 && d->out_h == 112 && d->out_w == 112 &&
+          d->in_h == QT_STEM_PAD_H && d->in_w == QT_STEM_PAD_W && d->src_pix_stride == 4 &&
+          d->src_row_stride == QT_STEM_PAD_W * 4 && d->src_img_stride == (long long)QT_STEM_PAD_H * QT_STEM_PAD_W * 4 && !d->quad)
+        return launch_stem_rows(dy, x, dw, d->batch, s);
+      return launch<bf16_t, 64, 224, true>(a, s);
+    }
     const bool n64 = d->n_out <= 64, c64 = d->k_per_tap <= 64;
     if (n64 && c64) return launch<bf16_t, 64, 64, false>(a, s);
     if (n64) return launch<bf16_t, 64, 128, false>(a, s);

@@ -257,3 +257,38 @@ def test_stem_conv_pool_negative_zero_is_not_a_maximum():
     assert (got[:, 1::2] == 0).all()                           # negative scale: relu(-x) = 0 everywhere, never a stray -0 win
     assert rel_err(got, ref) <= 4e-3
     assert (pooled.view(torch.int16) >= 0).all()               # no sign bit in the result: +0, not -0
+
+
+@pytest.mark.parametrize("B", [1, 3, 9])   # 56 / 168 / 504 tiles: fewer and more tiles than workgroups
+def test_stem_weight_gradient_from_raw_rows(B):
+    """conv1's weight gradient (conv2d backward-weight inside loss.backward(), /root/reference/Quadtree_from
+    scratch/Quadtree_train.py:65, layer built at models.py:222-223) through qt_conv2d_wgrad on the packed stem descriptor
+    (bf16: csrc/conv_wgrad.hip::stem_wgrad_rows_kernel) against torch on the CPU."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    dt = torch.bfloat16
+    qdt = L.qt_dtype(dt)
+    g = torch.Generator().manual_seed(300 + B)
+    image = torch.randn(B, 3, 224, 224, generator=g).to(dt).float()
+    dy = (torch.randn(B, 64, 112, 112, generator=g) * 0.1).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(image, (64, 3, 7, 7), dy, stride=2, padding=3)
+    st = L.stream_ptr()
+    imd = image.to(dev)
+    xpad = torch.empty(B, 230, 232, 4, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_input(qdt, L.ptr(imd), L.ptr(xpad), B, st), "qt_pack_stem_input")
+    dyd = nhwc(dy).to(dev, dt).contiguous()
+    d = L.ConvDesc()
+    d.dtype = qdt; d.mode = L.QT_CONV_FWD; d.batch = B
+    d.in_h, d.in_w, d.out_h, d.out_w = 230, 232, 112, 112
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = 32, 64, 7, 1, 2, 0
+    d.src_pix_stride, d.src_row_stride, d.src_img_stride = 4, 232 * 4, 230 * 232 * 4
+    dw = torch.zeros(64, 7, 32, device=dev)
+    L.check(lib.qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dyd), L.ptr(xpad), L.ptr(dw), st), "qt_conv2d_wgrad")
+    grad = torch.empty(64, 3, 7, 7, device=dev)
+    L.check(lib.qt_unpack_stem_wgrad(L.ptr(dw), L.ptr(grad), 0, st), "qt_unpack_stem_wgrad")
+    torch.cuda.synchronize()
+    assert rel_err(grad.cpu(), ref) <= 2e-3
+    # the pad columns of the packed layout (kw = 7, channel 3) receive no gradient from real data: channel 3 of the packed
+    # input is zero
+    assert float(dw.view(64, 7, 8, 4)[..., 3].abs().max()) == 0.0
