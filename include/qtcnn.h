@@ -366,6 +366,14 @@ int qt_stem_bn_bwd_sums(int dtype, const void* dpooled, const void* y_at_max, co
 int qt_stem_bn_bwd_apply(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
                          const float* shift, const float* mean, const float* invstd, const float* coef, void* dy,
                          int batch, void* stream);
+/* Stem backward in one launch (bf16): the gradient of conv1's output (max-pool backward + ReLU mask + BatchNorm backward,
+ * the arithmetic of qt_stem_bn_bwd_apply) is computed tile by tile in LDS and contracted with the packed input at once:
+ * dw[64][7][32] (the layout qt_unpack_stem_wgrad reads, zeroed by the caller) += conv1's weight gradient.  The 411 MB map
+ * d(loss)/d(conv1 output) is neither written nor read.  QT_ERR_UNSUPPORTED for f32 / QTCNN_STEM_BWD_FUSED=0: use
+ * qt_stem_bn_bwd_apply + qt_conv2d_wgrad. */
+int qt_stem_bn_bwd_wgrad(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* coef, const void* xpad,
+                         float* dw, int batch, void* stream);
 /* AdaptiveAvgPool2d(1,1)+flatten into columns [col0, col0+C) of the fused feature
  * matrix (Quadtree_from scratch/models.py:242,289-294) and its backward fused with the
  * ReLU mask of the pooled map. */

@@ -387,14 +387,30 @@ constexpr int SW_BUF = SW_XB + SW_DYB;
 constexpr int SW_LDS = 2 * SW_BUF;
 static_assert(9 * SW_ROWB <= SW_XB, "nine input rows fit their block");
 
+// FUSED form: the gradient tile is not read but COMPUTED in LDS -- max-pool backward (gather of the <= 4 pooled cells whose
+// argmax is the position), ReLU mask and BatchNorm backward, exactly the arithmetic of stem_bn_bwd_apply2x2_kernel
+// (elementwise.hip) -- from the raw conv1 output tile (same shape, staged in its place), two rows of the pooled gradient
+// and of the argmax map: d(loss)/d(conv1 output), 411 MB at 256 images, is neither written nor read.
+constexpr int SW_DPB = 2 * 56 * 128;               // two pooled-gradient rows
+constexpr int SW_AMB = 2 * 56 * 64;                // two argmax rows
+constexpr int SW_BUF_F = SW_BUF + SW_DPB + SW_AMB; // 66 KB
+constexpr int SW_LDS_F = 2 * SW_BUF_F + 7 * 64 * 4;   // (+ the BatchNorm constants: scale, shift, mean, invstd, a, b, c)
+static_assert(SW_LDS_F <= 160 * 1024, "fused stem backward fits the LDS");
+
 struct StemWgArgs {
-  const bf16_t* dy;   // [B][112][112][64]
+  const bf16_t* dy;   // [B][112][112][64]  (FUSED: the raw conv1 output y)
   const bf16_t* x;    // [B][230][232][4]
   float* dw;          // [64][7][32], accumulated into
   int ntiles;         // B * 56
+  // FUSED
+  const bf16_t* dpooled;            // [B][56][56][64]
+  const unsigned char* argmax;      // [B][56][56][64]
+  const float *scale, *shift, *mean, *invstd, *coef;   // [64] each, coef = [3][64] (a, b, c of qt_bn_bwd_finalize)
 };
 
+template <bool FUSED>
 __global__ __launch_bounds__(512) void stem_wgrad_rows_kernel(StemWgArgs p) {
+  constexpr int BUF = FUSED ? SW_BUF_F : SW_BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -411,16 +427,99 @@ __global__ __launch_bounds__(512) void stem_wgrad_rows_kernel(StemWgArgs p) {
     const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)img * QT_STEM_PAD_H + 4 * rp) * SW_ROWB;
     const unsigned char* ds = reinterpret_cast<const unsigned char*>(p.dy) + ((size_t)img * 112 + 2 * rp) * (112 * 128);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < (FUSED ? 9 : 6); ++i) {
       const int b = wave + 8 * i;
       if (b < 17) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * SW_BUF + b * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * BUF + b * 1024);
         if (b * 1024 + lane * 16 < 9 * SW_ROWB) glds16(xs + b * 1024 + lane * 16, dst);
       } else if (b < 45) {
         const int d = b - 17, r = d * 8 + (lane >> 3), sl = lane & 7;
         const int c = (((sl >> 1) ^ ((r >> 1) & 3)) << 1) | (sl & 1);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * SW_BUF + SW_XB + d * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * BUF + SW_XB + d * 1024);
         glds16(ds + r * 128 + c * 16, dst);
+      } else if (FUSED && b < 66) {
+        // pooled rows rp, rp + 1 (the second does not exist for rp = 55): 14 KB of gradient, 7 KB of argmax, linear
+        const int e = b - 45;
+        const bool two = rp + 1 < 56;
+        if (e < 14) {
+          const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * BUF + SW_BUF + e * 1024);
+          if (two || e < 7)
+            glds16(reinterpret_cast<const unsigned char*>(p.dpooled) + ((size_t)img * 56 + rp) * (56 * 128) + e * 1024 + lane * 16, dst);
+        } else {
+          const int f = e - 14;
+          const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * BUF + SW_BUF + SW_DPB + f * 1024);
+          if (two || f * 1024 + lane * 16 < 56 * 64)
+            glds16(p.argmax + ((size_t)img * 56 + rp) * (56 * 64) + f * 1024 + lane * 16, dst);
+        }
+      }
+    }
+  };
+  // d(loss)/d(conv1 output) of the tile's 2 x 112 positions, in place over the staged conv1 output (same swizzle)
+  auto grad_pass = [&](int tile, int buf) {
+    if (tid >= 448) return;
+    const int rp = tile % 56;
+    const int b = tid >> 3, cg = tid & 7;
+    unsigned char* tb = smem + buf * BUF + SW_XB;
+    const unsigned char* dp = smem + buf * BUF + SW_BUF;
+    const unsigned char* am = dp + SW_DPB;
+    const bool a1 = rp + 1 < 56, b1 = b + 1 < 56;
+    // tile row r = 112 * (conv row parity) + column; the 16 bytes of channel group cg sit in slot ((cg >> 1) ^ key(r)) * 2 + (cg & 1)
+    auto at = [&](int r) -> unsigned char* { return tb + r * 128 + (((((cg >> 1) ^ ((r >> 1) & 3)) << 1) | (cg & 1)) << 4); };
+    unsigned char* pos[4] = {at(2 * b), at(2 * b + 1), at(112 + 2 * b), at(112 + 2 * b + 1)};
+    auto ld4 = [](const unsigned char* q, float (&f)[4]) {   // four bf16 -> f32
+      const uint2 u = *reinterpret_cast<const uint2*>(q);
+      f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+      f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    };
+    // two halves of four channels each (the whole group at once needs more registers than the MFMA phase leaves)
+#pragma unroll 1
+    for (int hf = 0; hf < 2; ++hf) {
+      const int c0 = cg * 8 + hf * 4;
+      const float* cf = reinterpret_cast<const float*>(smem + 2 * BUF) + c0;   // (LDS copy: a global load here is an exposed latency per tile)
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(cf), sh = *reinterpret_cast<const f32x4*>(cf + 64);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(cf + 128), is = *reinterpret_cast<const f32x4*>(cf + 192);
+      const f32x4 ca = *reinterpret_cast<const f32x4*>(cf + 256), cb = *reinterpret_cast<const f32x4*>(cf + 320);
+      const f32x4 cc = *reinterpret_cast<const f32x4*>(cf + 384);
+      unsigned k[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // argmax bytes of cells (a,b) (a,b+1) (a+1,b) (a+1,b+1)
+      float d[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[c][e] = 0.f;
+      const int cell[4] = {b, b + 1, 56 + b, 56 + b + 1};
+      const bool have[4] = {true, b1, a1, a1 && b1};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (have[c]) {
+          k[c] = *reinterpret_cast<const unsigned*>(am + cell[c] * 64 + cg * 8 + hf * 4);
+          ld4(dp + cell[c] * 128 + cg * 16 + hf * 8, d[c]);
+        }
+      float y[4][4], o[4][4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) ld4(pos[q4] + hf * 8, y[q4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int sft = e * 8;
+        const int i00 = (k[0] >> sft) & 0xff, i01 = (k[1] >> sft) & 0xff, i10 = (k[2] >> sft) & 0xff, i11 = (k[3] >> sft) & 0xff;
+        // taps kh*3+kw with kh = h - (2*ph - 1), kw = w - (2*pw - 1)  (stem_bn_bwd_apply2x2_kernel: same sums, same order)
+        float g[4];
+        g[0] = i00 == 4 ? d[0][e] : 0.f;
+        g[1] = (i00 == 5 ? d[0][e] : 0.f) + (i01 == 3 ? d[1][e] : 0.f);
+        g[2] = (i00 == 7 ? d[0][e] : 0.f) + (i10 == 1 ? d[2][e] : 0.f);
+        g[3] = (i00 == 8 ? d[0][e] : 0.f);
+        g[3] += (i01 == 6 ? d[1][e] : 0.f);
+        g[3] += (i10 == 2 ? d[2][e] : 0.f);
+        g[3] += (i11 == 0 ? d[3][e] : 0.f);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float gm = (y[q4][e] * sc[e] + sh[e] > 0.f) ? g[q4] : 0.f;
+          o[q4][e] = ca[e] * (gm - cb[e] - (y[q4][e] - mu[e]) * is[e] * cc[e]);
+        }
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const bf16x4 v = {(bf16_t)o[q4][0], (bf16_t)o[q4][1], (bf16_t)o[q4][2], (bf16_t)o[q4][3]};
+        *reinterpret_cast<bf16x4*>(pos[q4] + hf * 8) = v;
       }
     }
   };
@@ -431,14 +530,27 @@ __global__ __launch_bounds__(512) void stem_wgrad_rows_kernel(StemWgArgs p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) acc[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (FUSED) {
+    float* cf = reinterpret_cast<float*>(smem + 2 * BUF);
+    if (tid < 448) {
+      const int v = tid >> 6, c = tid & 63;
+      const float* src = v == 0 ? p.scale : v == 1 ? p.shift : v == 2 ? p.mean : v == 3 ? p.invstd : p.coef + (v - 4) * 64;
+      cf[tid] = src[c];
+    }
+    // (visible to every thread behind the first tile's barrier)
+  }
   dma_tile(t_beg, 0);
   for (int t = t_beg; t < t_end; ++t) {
     const int buf = (t - t_beg) & 1;
     // tile t has landed (every wave's share), and nobody reads the other buffer any more
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);
+    if constexpr (FUSED) {
+      grad_pass(t, buf);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the gradient tile is complete
+    }
     if (wave < 7) {
-      const unsigned char* xb = smem + buf * SW_BUF;
+      const unsigned char* xb = smem + buf * BUF;
       const unsigned char* db = xb + SW_XB;
       const int kh = wave;
       // fragments of K block kb: the lane's two pixel rows are r1 = 32 kb + 4 lg + q and r1 + 16
@@ -493,12 +605,12 @@ __global__ __launch_bounds__(512) void stem_wgrad_rows_kernel(StemWgArgs p) {
 }
 
 int launch_stem_rows(const void* dy, const void* x, float* dw, int batch, hipStream_t stream) {
-  StemWgArgs a;
+  StemWgArgs a = {};
   a.dy = static_cast<const bf16_t*>(dy); a.x = static_cast<const bf16_t*>(x); a.dw = dw; a.ntiles = batch * 56;
   static std::atomic<unsigned long long> lds_limit_set{0};  // per device
-  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(stem_wgrad_rows_kernel), SW_LDS, lds_limit_set)) return rc;
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(stem_wgrad_rows_kernel<false>), SW_LDS, lds_limit_set)) return rc;
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
-  hipLaunchKernelGGL(stem_wgrad_rows_kernel, dim3(grid), dim3(512), SW_LDS, stream, a);
+  hipLaunchKernelGGL(stem_wgrad_rows_kernel<false>, dim3(grid), dim3(512), SW_LDS, stream, a);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }
@@ -510,6 +622,35 @@ bool qt_wgrad_patch_eligible(const qt_conv_desc* d);
 size_t qt_wgrad_patch_workspace_bytes(const qt_conv_desc* d);
 int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
                           size_t workspace_bytes, int oihw, void* stream);
+
+// Stem backward in one launch (bf16): max-pool backward + ReLU mask + BatchNorm backward of conv1's output computed tile by
+// tile in LDS and contracted with the packed input at once: dw[64][7][32] += conv1's weight gradient (qt_unpack_stem_wgrad
+// layout).  Inputs as qt_stem_bn_bwd_apply; d(loss)/d(conv1 output) is never materialised.
+extern "C" int qt_stem_bn_bwd_wgrad(int dtype, const void* dpooled, const unsigned char* argmax, const void* y,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    const float* coef, const void* xpad, float* dw, int batch, void* stream) {
+  QT_CHECK_ARG(dpooled && argmax && y && scale && shift && mean && invstd && coef && xpad && dw && batch > 0,
+               "qt_stem_bn_bwd_wgrad: bad argument");
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("QTCNN_STEM_BWD_FUSED");
+    on = e ? atoi(e) : 1;
+  }
+  if (dtype != QT_BF16 || !on) {
+    qt_set_error("qt_stem_bn_bwd_wgrad: bf16 only (use qt_stem_bn_bwd_apply + qt_conv2d_wgrad)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  StemWgArgs a;
+  a.dy = static_cast<const bf16_t*>(y); a.x = static_cast<const bf16_t*>(xpad); a.dw = dw; a.ntiles = batch * 56;
+  a.dpooled = static_cast<const bf16_t*>(dpooled); a.argmax = argmax;
+  a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.coef = coef;
+  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
+  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(stem_wgrad_rows_kernel<true>), SW_LDS_F, lds_limit_set)) return rc;
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  hipLaunchKernelGGL(stem_wgrad_rows_kernel<true>, dim3(grid), dim3(512), SW_LDS_F, static_cast<hipStream_t>(stream), a);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
 
 extern "C" size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* d) {
   return d ? qt_wgrad_patch_workspace_bytes(d) : 0;

@@ -1538,21 +1538,41 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // the <= 4 pooled cells of every conv1 position and writes d(loss)/d(conv1 output) directly.
     // QTCNN_STEM_FUSED=0 keeps the three-pass form (pool backward, reduce, apply) for A/B runs.
     static const bool fused = !(getenv("QTCNN_STEM_FUSED") && atoi(getenv("QTCNN_STEM_FUSED")) == 0);
+    bool stem_done = false;   // conv1's weight gradient has been produced by the one-launch stem backward
     if (fused) {
       const int rows = qt_stem_bn_bwd_sums_rows(B);
       e.run(qt_stem_bn_bwd_sums(dt, e.at(p->g_p0), e.at(p->ymax), e.at<float>(bn0.scale), e.at<float>(bn0.shift),
                                 e.at<float>(bn0.mean), e.at<float>(bn0.invstd), e.at<float>(p->stats), B, stream));
       e.run(qt_bn_bwd_finalize(e.at<float>(p->stats), rows, bn0.C, e.bn_count((long long)B * 112 * 112), e.tf(bn0.gamma),
                                e.at<float>(bn0.invstd), e.gf(bn0.gamma), e.gf(bn0.beta), 0, e.at<float>(bn0.coef), stream));
-      e.run(qt_stem_bn_bwd_apply(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
-                                 e.at<float>(bn0.shift), e.at<float>(bn0.mean), e.at<float>(bn0.invstd),
-                                 e.at<float>(bn0.coef), e.at(c0.gy), B, stream));
+      // bf16: BatchNorm / ReLU / max-pool backward of conv1's output AND conv1's weight gradient in one launch on the
+      // weight-gradient stream (the map d(loss)/d(conv1 output) never exists); otherwise the apply pass, then wgrad below
+      if (e.gf(c0.w)) {
+        e.fork();
+        void* ws_ = e.wstream;
+        const int slot = e.begin_timed(e.conv_flops(e.stem_desc(true)), 2, ws_, e.wgrad_bytes(c0, e.stem_desc(true)));
+        const int st = qt_stem_bn_bwd_wgrad(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y),
+                                            e.at<float>(bn0.scale), e.at<float>(bn0.shift), e.at<float>(bn0.mean),
+                                            e.at<float>(bn0.invstd), e.at<float>(bn0.coef), e.at(p->xpad),
+                                            e.at<float>(c0.dw), B, ws_);
+        e.end_timed(slot, ws_);
+        if (st == QT_OK) {
+          e.run(qt_unpack_stem_wgrad(e.at<float>(c0.dw), e.gf(c0.w), 0, ws_));
+          stem_done = true;
+        } else if (st != QT_ERR_UNSUPPORTED) {
+          e.run(st);
+        }
+      }
+      if (!stem_done)
+        e.run(qt_stem_bn_bwd_apply(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
+                                   e.at<float>(bn0.shift), e.at<float>(bn0.mean), e.at<float>(bn0.invstd),
+                                   e.at<float>(bn0.coef), e.at(c0.gy), B, stream));
     } else {
       e.run(qt_stem_pool_bwd(dt, e.at(p->g_p0), e.at<unsigned char>(p->argmax), e.at(c0.y), e.at<float>(bn0.scale),
                              e.at<float>(bn0.shift), e.at(c0.gy), B, stream));
       e.bn_backward(c0, e.at(c0.gy), nullptr);
     }
-    e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
+    if (!stem_done) e.wgrad(c0, e.stem_desc(true), e.at(p->xpad), true);
     }
   }
   // the last phase (or a head-only model) joins: afterwards the caller's stream sees every gradient

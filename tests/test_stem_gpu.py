@@ -118,6 +118,27 @@ def test_stem_pool_and_fused_backward(dt, tol):
     assert rel_err(dy3.float().cpu().permute(0, 3, 1, 2), ref) <= tol
     if dt == torch.float32:
         assert rel_err(dy.cpu(), dy3.cpu()) <= 1e-6
+    # one-launch stem backward (bf16): the same d(loss)/d(conv1 output), computed tile by tile in LDS and contracted with the
+    # packed input at once, against qt_stem_bn_bwd_apply + qt_conv2d_wgrad on the materialised map
+    image = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    xpad = torch.empty(B, 230, 232, 4, device=dev, dtype=dt)
+    L.check(lib.qt_pack_stem_input(qdt, L.ptr(image), L.ptr(xpad), B, st), "qt_pack_stem_input")
+    d = L.ConvDesc()
+    d.dtype = qdt; d.mode = L.QT_CONV_FWD; d.batch = B
+    d.in_h, d.in_w, d.out_h, d.out_w = 230, 232, 112, 112
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = 32, 64, 7, 1, 2, 0
+    d.src_pix_stride, d.src_row_stride, d.src_img_stride = 4, 232 * 4, 230 * 232 * 4
+    dw_ref = torch.zeros(64, 7, 32, **f32)
+    L.check(lib.qt_conv2d_wgrad(ctypes.byref(d), L.ptr(dy), L.ptr(xpad), L.ptr(dw_ref), st), "qt_conv2d_wgrad")
+    dw = torch.zeros(64, 7, 32, **f32)
+    rc = lib.qt_stem_bn_bwd_wgrad(qdt, L.ptr(dpd), L.ptr(argmax), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(isd),
+                                  L.ptr(coef), L.ptr(xpad), L.ptr(dw), B, st)
+    torch.cuda.synchronize()
+    if dt == torch.float32:
+        assert rc != 0                                        # (the f32 build keeps the two-kernel form)
+    else:
+        assert rc == 0, L.last_error()
+        assert rel_err(dw.cpu(), dw_ref.cpu()) <= 2e-3        # same bf16 gradient values, another summation order
 
 
 def _stem_conv(L, dt, image, w, taps, want_stats, scale=None, shift=None, relu=0):
