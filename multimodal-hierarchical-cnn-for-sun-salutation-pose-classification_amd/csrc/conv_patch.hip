@@ -561,10 +561,12 @@ __global__ __launch_bounds__(NT) void conv_l1_ring_kernel(PatchArgs p) {
     for (int g = 0; g < 18; ++g) {
       if (g + 1 < 18) read_group(g + 1, fwp[(g + 1) & 1], fap[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);   // (the reads of group g+1 stay in front of the MFMAs of group g)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) QtMma<T>::run(acc[i][j], fwp[g & 1][i], fap[g & 1][j]);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     base += BM;
