@@ -109,12 +109,14 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs p) {
       f32x4 acc[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
           acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kh][cb]),
                                                             __builtin_bit_cast(bf16x8, xf[kh]), acc[cb], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
       // lane: pixel li of the block, channels 16*cb + 4*lg + r
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
@@ -333,12 +335,14 @@ __global__ __launch_bounds__(512) void conv_stem_pool_kernel(StemPoolArgs p) {
       f32x4 acc[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
           acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kh][cb]),
                                                             __builtin_bit_cast(bf16x8, xf[kh]), acc[cb], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
         bf16x4 o;
