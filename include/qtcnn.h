@@ -346,7 +346,8 @@ int qt_stem_conv_pool(int dtype, const void* xpad, const void* weight, int taps,
                       void* pooled, int batch, void* stream);
 /* The same straight from the f32 NCHW image [B][3][224][224] the reference's dataloader hands over (16-byte aligned): the
  * kernel packs its input rows in LDS (same rounding as qt_pack_stem_input), so neither xpad nor the conv1 map exists in
- * memory; bit-identical to qt_pack_stem_input + qt_stem_conv_pool.  bf16 only; QTCNN_STEM_NCHW=0: QT_ERR_UNSUPPORTED. */
+ * memory; bit-identical to qt_pack_stem_input + qt_stem_conv_pool.  QT_ERR_UNSUPPORTED (take the packed form) for f32, an
+ * image that is not 16-byte aligned, or QTCNN_STEM_NCHW=0. */
 int qt_stem_conv_pool_nchw(int dtype, const float* image_nchw, const void* weight, int taps, const float* scale,
                            const float* shift, void* pooled, int batch, void* stream);
 int qt_stem_pool_bwd(int dtype, const void* dpooled, const unsigned char* argmax, const void* y, const float* scale,

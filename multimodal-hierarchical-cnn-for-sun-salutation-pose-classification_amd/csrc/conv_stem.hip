@@ -472,14 +472,13 @@ extern "C" int qt_stem_conv_pool_nchw(int dtype, const float* image_nchw, const 
                                       const float* shift, void* pooled, int batch, void* stream) {
   QT_CHECK_ARG(image_nchw && weight && scale && shift && pooled && batch > 0 && (taps == 7 || taps == 8),
                "qt_stem_conv_pool_nchw: bad argument");
-  QT_CHECK_ARG(((uintptr_t)image_nchw % 16) == 0, "qt_stem_conv_pool_nchw: the image must be 16-byte aligned");
   static int raw_on = -1;
   if (raw_on < 0) {
     const char* e = getenv("QTCNN_STEM_NCHW");
     raw_on = e ? atoi(e) : 1;
   }
-  if (dtype != QT_BF16 || !stem_enabled() || !raw_on) {
-    qt_set_error("qt_stem_conv_pool_nchw: bf16 only (use qt_pack_stem_input + qt_stem_conv_pool)");
+  if (dtype != QT_BF16 || !stem_enabled() || !raw_on || ((uintptr_t)image_nchw % 16) != 0) {
+    qt_set_error("qt_stem_conv_pool_nchw: bf16 and a 16-byte aligned image only (use qt_pack_stem_input + qt_stem_conv_pool)");
     return QT_ERR_UNSUPPORTED;
   }
   StemPoolArgs a;
