@@ -87,6 +87,62 @@ __global__ __launch_bounds__(256) void gemm_small_wave_kernel(SmallArgs a) {
   }
 }
 
+// 32 x 32 output tile per 256-thread workgroup, K in steps of 32 through LDS (f32 math, fixed summation order): the products
+// that are neither short in K (thread kernel) nor thin in M or N (wave kernels: one wave per output element) -- the LSTM
+// input products and weight gradients of the clip models (M = 256..752, N = 188..752, K = 188..256) took 102 us per launch
+// with a wave per output element; 141 k waves of four loads each for 72 MFLOP.
+__global__ __launch_bounds__(256) void gemm_small_tile_kernel(SmallArgs a) {
+  __shared__ float As[32][33], Bs[32][33];
+  const int tn = blockIdx.x % ((a.N + 31) / 32), tm = blockIdx.x / ((a.N + 31) / 32);
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // outputs (m0 + ty*2 + i, n0 + tx*2 + j)
+  const int lr = threadIdx.x >> 3, lc = (threadIdx.x & 7) * 4; // staging: row lr, k columns lc .. lc+3
+  const bool a_kfast = a.aks <= a.ars, b_kfast = a.bks <= a.brs;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  // staging follows the operand's contiguous axis (the weight-gradient products read their operands k-strided); the next
+  // K step's eight values per thread are requested before the current step is multiplied (one global latency per step otherwise)
+  float ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      {
+        const int r = a_kfast ? lr : (int)(threadIdx.x & 31), c = a_kfast ? lc + u : (int)(threadIdx.x >> 5) + 8 * u;
+        const int m = m0 + r, k = k0 + c;
+        ra[u] = (m < a.M && k < a.K) ? ld(a.A, (long long)m * a.ars + (long long)k * a.aks, a.a_bf16) : 0.f;
+      }
+      {
+        const int r = b_kfast ? lr : (int)(threadIdx.x & 31), c = b_kfast ? lc + u : (int)(threadIdx.x >> 5) + 8 * u;
+        const int n = n0 + r, k = k0 + c;
+        rb[u] = (n < a.N && k < a.K) ? ld(a.B, (long long)n * a.brs + (long long)k * a.bks, a.b_bf16) : 0.f;
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < a.K; k0 += 32) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      As[a_kfast ? lr : (int)(threadIdx.x & 31)][a_kfast ? lc + u : (int)(threadIdx.x >> 5) + 8 * u] = ra[u];
+      Bs[b_kfast ? lr : (int)(threadIdx.x & 31)][b_kfast ? lc + u : (int)(threadIdx.x >> 5) + 8 * u] = rb[u];
+    }
+    __syncthreads();
+    if (k0 + 32 < a.K) fetch(k0 + 32);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float a0 = As[ty * 2][k], a1 = As[ty * 2 + 1][k], b0 = Bs[tx * 2][k], b1 = Bs[tx * 2 + 1][k];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1;
+      acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+      if (m < a.M && n < a.N) finish(a, m, n, acc[i][j]);
+    }
+}
+
 // one wave per output element, K contiguous in both operands and a multiple of 8: every lane requests all its 8-element
 // pieces (16 B of bf16 / 32 B of f32) before the first multiply -- classifier.3's forward (K = 2688: 22 us as 42 trips of
 // two scalar loads per lane, one memory latency per group of four) is then ONE latency
@@ -142,7 +198,10 @@ extern "C" int qt_gemm_small(const qt_gemm_small_desc* d, const void* A, const v
   a.relu = d->relu; a.accumulate = d->accumulate;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long long total = (long long)d->M * d->N;
-  if (d->K <= 96) {
+  if (d->K > 96 && d->M >= 32 && d->N >= 32) {
+    const int tiles = ((d->M + 31) / 32) * ((d->N + 31) / 32);
+    hipLaunchKernelGGL(gemm_small_tile_kernel, dim3(tiles), dim3(256), 0, s, a);
+  } else if (d->K <= 96) {
     long long g = (total + 255) / 256;
     hipLaunchKernelGGL(gemm_small_thread_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, a);
   } else {
