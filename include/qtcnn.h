@@ -490,6 +490,19 @@ int qt_pool3d_max(int dtype, const void* x, void* out, unsigned char* argmax, in
                   int pool_t, void* stream);
 int qt_pool3d_max_bwd(int dtype, const void* dout, const unsigned char* argmax, void* dx, int frames, int batch, int h,
                       int w, int C, int pool_t, void* stream);
+/* Round 3: BatchNorm3d (scale / shift) + ReLU + MaxPool3d (pool_t, 2, 2) in one pass over the RAW conv output y -- the
+ * activation map relu(bn(y)) is not materialised; y_at_max (nullable) keeps y at each pooled cell's argmax, so that the
+ * BatchNorm-backward sums can be taken from the pooled side: qt_bn_bwd_reduce(g = d(loss)/d(pooled), mask = pooled,
+ * y = y_at_max, M = pooled cells) followed by qt_bn_bwd_finalize with count = ALL positions of the map.  Values compared are
+ * the activation rounded to `dtype`, i.e. exactly what qt_bn_act + qt_pool3d_max compare. */
+int qt_pool3d_bn_relu_max(int dtype, const void* y, const float* scale, const float* shift, void* out, unsigned char* argmax,
+                          void* y_at_max, int frames, int batch, int h, int w, int C, int pool_t, void* stream);
+/* ... and the backward of the three in one pass: dy = a (g - b - xhat c) with g = dout at the window's argmax where
+ * pooled > 0, zero elsewhere (coef = qt_bn_bwd_finalize's [3][C]); replaces qt_pool3d_max_bwd + qt_bn_bwd_apply and the
+ * full-size gradient map between them. */
+int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* argmax, const void* pooled, const void* y,
+                           const float* mean, const float* invstd, const float* coef, void* dy, int frames, int batch, int h,
+                           int w, int C, int pool_t, void* stream);
 /* nn.AdaptiveAvgPool3d((1,1,1)) + flatten(1) into columns [col0, col0+C) of an f32 [B][ld] matrix, and its backward */
 int qt_avgpool_tb(int dtype, const void* x, float* dst, int frames, int batch, int hw, int C, int ld, int col0, void* stream);
 int qt_avgpool_tb_bwd(int dtype, const float* d, void* g, int frames, int batch, int hw, int C, int ld, int col0,

@@ -162,6 +162,107 @@ __global__ void pool3d_max_bwd_kernel(const T* __restrict__ dout, const unsigned
   }
 }
 
+// ---- BatchNorm3d (as scale / shift) + ReLU + MaxPool3d (PT, 2, 2) in ONE pass over the raw conv output (round 3) ----
+// The train forward of a conv block wrote a = relu(bn(y)) (one pass over the map) and pooled it (a second one), although
+// nothing but the pool reads `a`: the next block consumes the pooled map, the backward's ReLU mask is `pooled > 0` at the
+// argmax and zero gradient elsewhere.  Here a thread applies the affine + ReLU to its window on the fly -- rounded to the
+// activation type before the comparison, exactly the values the two-kernel form compared -- and also keeps the RAW conv
+// output at the argmax (ymax): the BatchNorm-backward sums then come from the pooled side (every pooled cell sends its
+// gradient to exactly one position).  Floor mode, first maximum in (t, h, w) scan order, as pool3d_max_kernel.
+template <typename T, int PT>
+__global__ void pool3d_bn_relu_max_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                          T* __restrict__ out, unsigned char* __restrict__ arg, T* __restrict__ ymax, int Tn, int B,
+                                          int H, int W, int C) {
+  const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = C / 8;
+  const long long n = (long long)To * B * Ho * Wo * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int b = (int)(r % B);
+    const int to = (int)(r / B);
+    float sc[8], sh[8], best[8], braw[8];
+    QtVec8<float>::load(scale + g * 8, sc);
+    QtVec8<float>::load(shift + g * 8, sh);
+    unsigned char idx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; braw[e] = 0.f; idx[e] = 0; }
+#pragma unroll
+    for (int dt = 0; dt < PT; ++dt)
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          const long long src = ((((long long)(to * PT + dt) * B + b) * H + ho * 2 + dh) * W + wo * 2 + dw) * C + g * 8;
+          float v[8];
+          QtVec8<T>::load(y + src, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float a = (float)(T)fmaxf(v[e] * sc[e] + sh[e], 0.f);   // (the stored activation's value)
+            if (a > best[e]) { best[e] = a; braw[e] = v[e]; idx[e] = (unsigned char)((dt * 2 + dh) * 2 + dw); }
+          }
+        }
+    const long long o = ((((long long)to * B + b) * Ho + ho) * Wo + wo) * C + g * 8;
+    QtVec8<T>::store(out + o, best);
+    if (arg) {
+      uint2 pk;
+      pk.x = idx[0] | (idx[1] << 8) | (idx[2] << 16) | ((unsigned)idx[3] << 24);
+      pk.y = idx[4] | (idx[5] << 8) | (idx[6] << 16) | ((unsigned)idx[7] << 24);
+      *reinterpret_cast<uint2*>(arg + o) = pk;
+    }
+    if (ymax) QtVec8<T>::store(ymax + o, braw);
+  }
+}
+
+// ---- max-pool backward + ReLU mask + BatchNorm backward in one pass: dy [T][B][H][W][C] from the pooled gradient ----
+//   g = dout at the window's argmax where pooled > 0, else 0 (also 0 in the floor-mode remainder);  dy = a (g - b - xhat c)
+// (coef = qt_bn_bwd_finalize's [3][C]).  The full-size gradient of the ReLU output is never materialised: it was written by
+// pool3d_max_bwd and read twice (reduce, apply) -- four passes over the largest maps of the clip models.
+template <typename T, int PT>
+__global__ void pool3d_bn_bwd_apply_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg,
+                                           const T* __restrict__ pooled, const T* __restrict__ y, const float* __restrict__ mean,
+                                           const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dy,
+                                           int Tn, int B, int H, int W, int C) {
+  const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = C / 8;
+  const long long n = (long long)Tn * B * H * W * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); r /= H;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B);
+    float gv[8], yv[8], mu[8], is[8], ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+    const int to = t / PT, ho = h / 2, wo = w / 2;
+    if (to < To && ho < Ho && wo < Wo) {
+      const long long o = ((((long long)to * B + b) * Ho + ho) * Wo + wo) * C + g * 8;
+      const uint2 pk = *reinterpret_cast<const uint2*>(arg + o);
+      const unsigned me = (unsigned)(((t - to * PT) * 2 + (h & 1)) * 2 + (w & 1));
+      float d[8], pv[8];
+      QtVec8<T>::load(dout + o, d);
+      QtVec8<T>::load(pooled + o, pv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+        gv[e] = (a == me && pv[e] > 0.f) ? d[e] : 0.f;
+      }
+    }
+    QtVec8<T>::load(y + i * 8, yv);
+    QtVec8<float>::load(mean + g * 8, mu);
+    QtVec8<float>::load(invstd + g * 8, is);
+    QtVec8<float>::load(coef + g * 8, ca);
+    QtVec8<float>::load(coef + C + g * 8, cb);
+    QtVec8<float>::load(coef + 2 * C + g * 8, cc);
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = ca[e] * (gv[e] - cb[e] - (yv[e] - mu[e]) * is[e] * cc[e]);
+    QtVec8<T>::store(dy + i * 8, o8);
+  }
+}
+
 // ---- AdaptiveAvgPool3d((1,1,1)) + flatten: x [T][B][HW][C] -> dst[b*ld + col0 + c] (f32) = mean over t, hw ----
 template <typename T>
 __global__ void avgpool_tb_kernel(const T* __restrict__ x, float* __restrict__ dst, int Tn, int B, int HW, int C, int ld, int col0) {
@@ -359,6 +460,43 @@ extern "C" int qt_pool3d_max_bwd(int dtype, const void* dout, const unsigned cha
   if (dtype == QT_F32) { if (pool_t == 1) QT_POOLB(float, 1); else QT_POOLB(float, 2); }
   else { if (pool_t == 1) QT_POOLB(bf16_t, 1); else QT_POOLB(bf16_t, 2); }
 #undef QT_POOLB
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pool3d_bn_relu_max(int dtype, const void* y, const float* scale, const float* shift, void* out,
+                                     unsigned char* argmax, void* y_at_max, int frames, int batch, int h, int w, int C, int pool_t,
+                                     void* stream) {
+  QT_CHECK_ARG(y && scale && shift && out && frames > 0 && batch > 0 && h >= 2 && w >= 2 && C % 8 == 0,
+               "qt_pool3d_bn_relu_max: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pool3d_bn_relu_max: bad dtype %d", dtype);
+  QT_CHECK_ARG((pool_t == 1 || pool_t == 2) && frames >= pool_t, "qt_pool3d_bn_relu_max: pool_t=%d", pool_t);
+  const long long n = (long long)(frames / pool_t) * batch * (h / 2) * (w / 2) * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(n)), blk(256);
+#define QT_POOLF(TT, PT) hipLaunchKernelGGL((pool3d_bn_relu_max_kernel<TT, PT>), grid, blk, 0, s, (const TT*)y, scale, shift, (TT*)out, argmax, (TT*)y_at_max, frames, batch, h, w, C)
+  if (dtype == QT_F32) { if (pool_t == 1) QT_POOLF(float, 1); else QT_POOLF(float, 2); }
+  else { if (pool_t == 1) QT_POOLF(bf16_t, 1); else QT_POOLF(bf16_t, 2); }
+#undef QT_POOLF
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+extern "C" int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* argmax, const void* pooled, const void* y,
+                                      const float* mean, const float* invstd, const float* coef, void* dy, int frames, int batch,
+                                      int h, int w, int C, int pool_t, void* stream) {
+  QT_CHECK_ARG(dout && argmax && pooled && y && mean && invstd && coef && dy && frames > 0 && batch > 0 && h >= 2 && w >= 2 &&
+                   C % 8 == 0,
+               "qt_pool3d_bn_bwd_apply: bad argument");
+  QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pool3d_bn_bwd_apply: bad dtype %d", dtype);
+  QT_CHECK_ARG((pool_t == 1 || pool_t == 2) && frames >= pool_t, "qt_pool3d_bn_bwd_apply: pool_t=%d", pool_t);
+  const long long n = (long long)frames * batch * h * w * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(n)), blk(256);
+#define QT_POOLA(TT, PT) hipLaunchKernelGGL((pool3d_bn_bwd_apply_kernel<TT, PT>), grid, blk, 0, s, (const TT*)dout, argmax, (const TT*)pooled, (const TT*)y, mean, invstd, coef, (TT*)dy, frames, batch, h, w, C)
+  if (dtype == QT_F32) { if (pool_t == 1) QT_POOLA(float, 1); else QT_POOLA(float, 2); }
+  else { if (pool_t == 1) QT_POOLA(bf16_t, 1); else QT_POOLA(bf16_t, 2); }
+#undef QT_POOLA
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

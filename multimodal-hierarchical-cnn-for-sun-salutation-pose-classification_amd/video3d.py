@@ -19,6 +19,7 @@ thin dense products from csrc/gemm_small.hip.  The whole forward / backward is O
 buffers.  There is no torch / CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -166,6 +167,32 @@ class _Ops:
         self.check(self.L.qt_pool3d_max(_lib.qt_dtype(dt), _ptr(x), _ptr(out), _ptr(arg), T, B, H, W, C, pt,
                                         _lib.stream_ptr()), "qt_pool3d_max")
 
+    def pool_bn(self, dt, y, stats, out, arg, ymax, T, B, H, W, C, pt):
+        """BatchNorm3d (scale / shift) + ReLU + MaxPool3d in one pass over the raw conv output (csrc/video3d.hip)"""
+        self.check(self.L.qt_pool3d_bn_relu_max(_lib.qt_dtype(dt), _ptr(y), _ptr(stats[2]), _ptr(stats[3]), _ptr(out), _ptr(arg),
+                                                _ptr(ymax), T, B, H, W, C, pt, _lib.stream_ptr()), "qt_pool3d_bn_relu_max")
+
+    def pool_bn_backward(self, dt, dout, arg, pooled, ymax, y, stats, gamma, T, B, H, W, C, pt, dev, batch_stats):
+        """d/d(pooled) -> (dy, dgamma, dbeta): the BatchNorm sums from the pooled side (every cell sends its gradient to one
+        position), then max-pool backward + ReLU mask + BatchNorm backward in one pass; no full-size gradient map in between"""
+        cells = (T // pt) * B * (H // 2) * (W // 2)
+        Mrows = T * B * H * W
+        rows = self.L.qt_bn_bwd_partial_rows(_c.c_longlong(cells), C)
+        part = torch.empty(self.L.qt_stats_capacity_rows(rows), 2, C, dtype=torch.float32, device=dev)
+        q = _lib.qt_dtype(dt)
+        self.check(self.L.qt_bn_bwd_reduce(q, _ptr(dout), _ptr(pooled), _ptr(ymax), _ptr(stats[0]), _ptr(stats[1]), _ptr(part),
+                                           _c.c_longlong(cells), C, _lib.stream_ptr()), "qt_bn_bwd_reduce")
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        self.check(self.L.qt_bn_bwd_finalize(_ptr(part), rows, C, _c.c_longlong(Mrows if batch_stats else 0), _ptr(gamma),
+                                             _ptr(stats[1]), _ptr(dgb[0]), _ptr(dgb[1]), 0, _ptr(coef), _lib.stream_ptr()),
+                   "qt_bn_bwd_finalize")
+        dy = torch.empty_like(y)
+        self.check(self.L.qt_pool3d_bn_bwd_apply(q, _ptr(dout), _ptr(arg), _ptr(pooled), _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
+                                                 _ptr(coef), _ptr(dy), T, B, H, W, C, pt, _lib.stream_ptr()),
+                   "qt_pool3d_bn_bwd_apply")
+        return dy, dgb[0], dgb[1]
+
     def pool_bwd(self, dt, dout, arg, dx, T, B, H, W, C, pt):
         self.check(self.L.qt_pool3d_max_bwd(_lib.qt_dtype(dt), _ptr(dout), _ptr(arg), _ptr(dx), T, B, H, W, C, pt,
                                             _lib.stream_ptr()), "qt_pool3d_max_bwd")
@@ -189,6 +216,10 @@ class _Ops:
         self.check(self.L.qt_dropout(_lib.QT_F32, _ptr(x, off * 4), _c.c_longlong(rows), cols, ld, _c.c_ulonglong(seed),
                                      _c.c_float(p), _lib.stream_ptr()), "qt_dropout")
 
+
+# QTCNN_POOL3D_FUSED (default 1): conv blocks with a pool run BatchNorm3d + ReLU + MaxPool3d as one pass forward and one
+# pass backward (csrc/video3d.hip); 0: qt_bn_act + qt_pool3d_max / qt_pool3d_max_bwd + qt_bn_bwd_reduce + qt_bn_bwd_apply
+FUSED_POOL = os.environ.get("QTCNN_POOL3D_FUSED", "1") != "0"
 
 _ops = None
 
@@ -277,18 +308,29 @@ class _ConvBlock:
                 o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), scale=stats[2], shift=shift, relu=1, **tk)
             else:
                 o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), shift=self.bias_p, **tk)
-        if fused_eval:
-            a = y
-        else:
-            a = torch.empty_like(y)
-            o.bn_act(dt, y, stats, a, rows, self.cout_p)
-        arg, out, To, Ho, Wo = None, a, T, H, W
-        if self.pool_t:
+        ymax = None
+        if self.pool_t and not fused_eval and FUSED_POOL:
+            # BatchNorm3d + ReLU + MaxPool3d in one pass: relu(bn(y)) is read by nothing but the pool (the next block takes the
+            # pooled map, the backward's ReLU mask is `pooled > 0` at the argmax), so it is not materialised
+            a = None
             To, Ho, Wo = T // self.pool_t, H // 2, W // 2
             out = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=dt, device=dev)
             arg = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=torch.uint8, device=dev) if keep else None
-            o.pool(dt, a, out, arg, T, B, H, W, self.cout_p, self.pool_t)
-        saved = (x, y, a, arg, stats, (T, B, H, W), training) if keep else None
+            ymax = torch.empty_like(out) if keep else None
+            o.pool_bn(dt, y, stats, out, arg, ymax, T, B, H, W, self.cout_p, self.pool_t)
+        else:
+            if fused_eval:
+                a = y
+            else:
+                a = torch.empty_like(y)
+                o.bn_act(dt, y, stats, a, rows, self.cout_p)
+            arg, out, To, Ho, Wo = None, a, T, H, W
+            if self.pool_t:
+                To, Ho, Wo = T // self.pool_t, H // 2, W // 2
+                out = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=dt, device=dev)
+                arg = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=torch.uint8, device=dev) if keep else None
+                o.pool(dt, a, out, arg, T, B, H, W, self.cout_p, self.pool_t)
+        saved = (x, y, a, arg, stats, (T, B, H, W), training, out, ymax) if keep else None
         return out, (To, Ho, Wo), saved
 
     @staticmethod
@@ -301,16 +343,20 @@ class _ConvBlock:
     def backward(self, dt, dout, saved):
         """dout: d/d(block output) -> (dx or None, dW, db, dgamma, dbeta)"""
         o = ops()
-        x, y, a, arg, stats, (T, B, H, W), training = saved
+        x, y, a, arg, stats, (T, B, H, W), training, pooled, ymax = saved
         dev = x.device
         esz = 2 if dt == torch.bfloat16 else 4
         rows = T * B * H * W
-        if self.pool_t:
-            da = torch.empty_like(a)
-            o.pool_bwd(dt, dout, arg, da, T, B, H, W, self.cout_p, self.pool_t)
+        if ymax is not None:
+            dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, self.cout_p,
+                                                   self.pool_t, dev, training)
         else:
-            da = dout
-        dy, dgamma, dbeta = o.bn_backward(dt, da, a, y, stats, self.gamma_p, rows, self.cout_p, dev, training)
+            if self.pool_t:
+                da = torch.empty_like(a)
+                o.pool_bwd(dt, dout, arg, da, T, B, H, W, self.cout_p, self.pool_t)
+            else:
+                da = dout
+            dy, dgamma, dbeta = o.bn_backward(dt, da, a, y, stats, self.gamma_p, rows, self.cout_p, dev, training)
         # conv bias gradient = column sums of dy.  No pass over dy is needed (it was 0.5 ms of the step): with
         # dy = ca (g - cb - xhat cc), ca = gamma invstd, the sum over positions is ca (sum g - M cb - cc sum xhat);
         # under batch statistics cb = sum g / M and sum xhat = 0: the gradient of a bias in front of a train-mode

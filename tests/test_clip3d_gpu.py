@@ -81,6 +81,107 @@ def test_maxpool3d_forward_backward(dt, pt, T, H):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pt,T,H", [(1, 3, 10), (2, 5, 9), (2, 4, 8)])
+def test_fused_bn_relu_maxpool3d_equals_separate_kernels(dt, pt, T, H):
+    """BatchNorm3d -> ReLU -> MaxPool3d of one conv block (/root/reference/3D models/models.py:26-47, the nn.Sequential of
+    Quadtree3DCNN's conv blocks) as one forward pass and one backward pass: the pooled map and argmax codes equal
+    qt_bn_act + qt_pool3d_max bit for bit; (dy, dgamma, dbeta) equal qt_pool3d_max_bwd + qt_bn_bwd_reduce / finalize / apply
+    (same per-element arithmetic; the channel sums differ only in summation order) and torch autograd in f32."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    B, C, W = 2, 16, H + 2
+    q = L.qt_dtype(dt)
+    st = L.stream_ptr()
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(B, C, T, H, W, generator=g).to(dt).float()
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    mean = y.mean((0, 2, 3, 4))
+    var = y.var((0, 2, 3, 4), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    To, Ho, Wo = T // pt, H // 2, W // 2
+    M, cells = T * B * H * W, To * B * Ho * Wo
+    yd = _to_tb(y).to(dev, dt)
+    sc, sh, mu, isd, gm = (v.to(dev).contiguous() for v in (scale, shift, mean, invstd, gamma))
+
+    # separate kernels
+    a = torch.empty_like(yd)
+    L.check(lib.qt_bn_act(q, L.ptr(yd), L.ptr(sc), L.ptr(sh), None, None, None, 1, L.ptr(a), ctypes.c_longlong(M), C, st), "act")
+    out0 = torch.empty(To, B, Ho, Wo, C, dtype=dt, device=dev)
+    arg0 = torch.empty(To, B, Ho, Wo, C, dtype=torch.uint8, device=dev)
+    L.check(lib.qt_pool3d_max(q, L.ptr(a), L.ptr(out0), L.ptr(arg0), T, B, H, W, C, pt, st), "pool")
+    # fused
+    out1 = torch.empty_like(out0)
+    arg1 = torch.empty_like(arg0)
+    ymax = torch.empty_like(out0)
+    L.check(lib.qt_pool3d_bn_relu_max(q, L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out1), L.ptr(arg1), L.ptr(ymax), T, B, H, W, C, pt,
+                                      st), "fused pool")
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1)
+    assert torch.equal(arg0, arg1)
+    # ymax is the raw conv output at the argmax position
+    yv = yd[: To * pt, :, : Ho * 2, : Wo * 2].reshape(To, pt, B, Ho, 2, Wo, 2, C).permute(0, 2, 3, 5, 7, 1, 4, 6).reshape(To, B, Ho, Wo, C, pt * 4)
+    assert torch.equal(ymax, torch.gather(yv, -1, arg1.long().unsqueeze(-1)).squeeze(-1))
+
+    dd = torch.randn(To, B, Ho, Wo, C, generator=g).to(dev, dt)
+
+    def finalize(part, rows):
+        dgb = torch.empty(2, C, device=dev)
+        coef = torch.empty(3, C, device=dev)
+        L.check(lib.qt_bn_bwd_finalize(L.ptr(part), rows, C, ctypes.c_longlong(M), L.ptr(gm), L.ptr(isd), L.ptr(dgb[0]), L.ptr(dgb[1]),
+                                       0, L.ptr(coef), st), "finalize")
+        return dgb, coef
+
+    # separate backward
+    da = torch.empty_like(yd)
+    L.check(lib.qt_pool3d_max_bwd(q, L.ptr(dd), L.ptr(arg0), L.ptr(da), T, B, H, W, C, pt, st), "pool bwd")
+    rows0 = lib.qt_bn_bwd_partial_rows(ctypes.c_longlong(M), C)
+    part0 = torch.empty(lib.qt_stats_capacity_rows(rows0), 2, C, device=dev)
+    L.check(lib.qt_bn_bwd_reduce(q, L.ptr(da), L.ptr(a), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(part0), ctypes.c_longlong(M), C, st),
+            "reduce")
+    dgb0, coef0 = finalize(part0, rows0)
+    dy0 = torch.empty_like(yd)
+    L.check(lib.qt_bn_bwd_apply(q, L.ptr(da), L.ptr(a), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef0), L.ptr(dy0), None,
+                                ctypes.c_longlong(M), C, st), "apply")
+    # fused backward
+    rows1 = lib.qt_bn_bwd_partial_rows(ctypes.c_longlong(cells), C)
+    part1 = torch.empty(lib.qt_stats_capacity_rows(rows1), 2, C, device=dev)
+    L.check(lib.qt_bn_bwd_reduce(q, L.ptr(dd), L.ptr(out1), L.ptr(ymax), L.ptr(mu), L.ptr(isd), L.ptr(part1), ctypes.c_longlong(cells),
+                                 C, st), "reduce (pooled side)")
+    dgb1, coef1 = finalize(part1, rows1)
+    dy1 = torch.full_like(yd, 7.0)
+    L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg1), L.ptr(out1), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef1),
+                                       L.ptr(dy1), T, B, H, W, C, pt, st), "fused apply")
+    torch.cuda.synchronize()
+    assert torch.allclose(dgb0, dgb1, rtol=1e-5, atol=1e-5)
+    tol = 2e-2 if dt == torch.bfloat16 else 1e-5
+    assert torch.allclose(dy0.float(), dy1.float(), rtol=tol, atol=tol)
+    # the same per-element arithmetic on the other path's coefficients is bit-identical
+    dy2 = torch.empty_like(yd)
+    L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg1), L.ptr(out1), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef0),
+                                       L.ptr(dy2), T, B, H, W, C, pt, st), "fused apply")
+    torch.cuda.synchronize()
+    assert torch.equal(dy0, dy2)
+
+    # torch autograd, f32, on the values the kernels saw
+    yt = y.clone().requires_grad_(True)
+    gt = gamma.clone().requires_grad_(True)
+    bt = beta.clone().requires_grad_(True)
+    ref = F.max_pool3d(torch.relu(F.batch_norm(yt, None, None, gt, bt, True, 0.0, 1e-5)), (pt, 2, 2), (pt, 2, 2))
+    ref.backward(dd.float().cpu().permute(1, 4, 0, 2, 3))
+    if dt == torch.float32:
+        assert torch.allclose(out1.cpu(), _to_tb(ref.detach()), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(dgb1[0].cpu(), gt.grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(dgb1[1].cpu(), bt.grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(dy1.cpu(), _to_tb(yt.grad), rtol=1e-4, atol=1e-5)
+    else:
+        assert rel_err(dy1.float().cpu(), _to_tb(yt.grad)) < 2e-2
+        assert rel_err(dgb1[0].cpu(), gt.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_bn_stats_pack_and_avgpool(dt):
     dev = _dev()
     L = pkg("_lib")
