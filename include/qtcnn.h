@@ -494,15 +494,27 @@ int qt_pool3d_max_bwd(int dtype, const void* dout, const unsigned char* argmax, 
  * activation map relu(bn(y)) is not materialised; y_at_max (nullable) keeps y at each pooled cell's argmax, so that the
  * BatchNorm-backward sums can be taken from the pooled side: qt_bn_bwd_reduce(g = d(loss)/d(pooled), mask = pooled,
  * y = y_at_max, M = pooled cells) followed by qt_bn_bwd_finalize with count = ALL positions of the map.  Values compared are
- * the activation rounded to `dtype`, i.e. exactly what qt_bn_act + qt_pool3d_max compare. */
+ * the activation rounded to `dtype`, i.e. exactly what qt_bn_act + qt_pool3d_max compare.  y rows are y_channels wide
+ * (<= C, a multiple of 8: qt_conv3d_first_fwd writes 32-channel rows while the next layer wants 64-channel K rows);
+ * out / argmax / y_at_max rows are C wide and zero in channels >= y_channels. */
 int qt_pool3d_bn_relu_max(int dtype, const void* y, const float* scale, const float* shift, void* out, unsigned char* argmax,
-                          void* y_at_max, int frames, int batch, int h, int w, int C, int pool_t, void* stream);
+                          void* y_at_max, int frames, int batch, int h, int w, int C, int y_channels, int pool_t, void* stream);
 /* ... and the backward of the three in one pass: dy = a (g - b - xhat c) with g = dout at the window's argmax where
  * pooled > 0, zero elsewhere (coef = qt_bn_bwd_finalize's [3][C]); replaces qt_pool3d_max_bwd + qt_bn_bwd_apply and the
- * full-size gradient map between them. */
+ * full-size gradient map between them.  dy rows are dy_channels wide (>= y_channels; zero beyond y_channels). */
 int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* argmax, const void* pooled, const void* y,
                            const float* mean, const float* invstd, const float* coef, void* dy, int frames, int batch, int h,
-                           int w, int C, int pool_t, void* stream);
+                           int w, int C, int y_channels, int dy_channels, int pool_t, void* stream);
+/* Round 3: the first Conv3d of the clip models (3 -> 32 channels, 3x3x3, pad 1; /root/reference/3dcnn/models.py:108)
+ * straight from the f32 clip [B][T][3][H][W]: y [T][B][H][W][32] (NO channel padding), bias-free accumulator.  w_packed is
+ * qt_pack_conv3d_block(first = 1)'s [>= 32][128] filter.  Either scale / shift (+ relu) of 32 channels (eval: folded
+ * BatchNorm3d), or stats: qt_conv3d_first_stats_rows(...) rows of [2][64] partial sums of y for qt_bn_finalize (channels
+ * 32..63 zero), or neither.  Replaces qt_pack_clip27 + a 1x1 qt_conv2d_igemm over 256-byte K rows (3.3 GB written and read
+ * back at 32 x 8 x 224 x 224).  QT_ERR_UNSUPPORTED (take the packed form) for f32, H % 4, W % 16, W > 256, a clip that is
+ * not 16-byte aligned, QTCNN_CONV3D_FIRST=0. */
+int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w);
+int qt_conv3d_first_fwd(int dtype, const float* clips, const void* w_packed, void* y, const float* scale, const float* shift,
+                        int relu, float* stats, int batch, int frames, int h, int w, void* stream);
 /* nn.AdaptiveAvgPool3d((1,1,1)) + flatten(1) into columns [col0, col0+C) of an f32 [B][ld] matrix, and its backward */
 int qt_avgpool_tb(int dtype, const void* x, float* dst, int frames, int batch, int hw, int C, int ld, int col0, void* stream);
 int qt_avgpool_tb_bwd(int dtype, const float* d, void* g, int frames, int batch, int hw, int C, int ld, int col0,

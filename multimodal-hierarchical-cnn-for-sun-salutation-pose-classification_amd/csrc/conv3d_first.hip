@@ -1,0 +1,266 @@
+// First Conv3d of the clip models (3 -> 32 channels, 3x3x3, pad 1) straight from the f32 clip, bf16 MFMA.
+//
+// Replaces nn.Conv3d(3, 32, kernel_size=(3,3,3), padding=(1,1,1)) of conv3d_block1
+// (/root/reference/3dcnn/models.py:108, reached from Quadtree3DCNN.forward, models.py:189-193, after the permute to
+// B,C,T,H,W) and its weight gradient (loss.backward(), /root/reference/3dcnn/train_3D_Quadtree_cnn_model.py).
+//
+// Rounds 1-3 packed the clip into one 128-wide K row per pixel (qt_pack_clip27: 27 taps x 3 channels, 256 B per pixel,
+// 3.3 GB for 32 clips x 8 frames of 224 x 224) and ran a 1x1 convolution over it: 1.8 ms to write the rows, 1.6 ms to read
+// them back, and the output padded to 64 channels.  Here a workgroup walks the frames of one (clip, 4-row slab): every input
+// frame slab is read once from the f32 clip (1.5x with the row halo), converted to bf16 and kept in LDS as [6 rows][W + 4
+// pixels][4 channels] for the three output frames that use it.  The im2col overlap is expressed by overlapping LDS reads:
+// the K-chunk of pixel w for (frame tap kt, row tap kh) is the 24 bytes at pixel w - 1 of row h + kh - 1 of frame t + kt - 1;
+// one MFMA k-step of 32 covers two (kt, kh) rows (4 pixels x 4 channels each, the filter is zero on the fourth pixel and
+// the fourth channel), five k-steps cover the nine rows.  The filter (10 fragments) lives in registers.  The output
+// channel of MFMA row 4q + r of block cb is 8q + 4cb + r, so a lane holds 8 consecutive channels of its pixel and a wave
+// writes one contiguous 1 KB run per 16 pixels: no transpose.  y is [T][B][H][W][32]: no channel padding.
+// Bound: the 0.8 GB output write (HBM); 10 MFMAs per 16 pixels are 50 us of matrix pipe for the whole clip batch.
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "qt_common.h"
+
+namespace {
+
+constexpr int C3_R = 4;          // output rows per slab (one per wave)
+constexpr int C3_SLABS = 5;      // four frame slabs in rotation + one that stays zero (frames outside the clip)
+
+struct C3Args {
+  const float* x;         // [B][T][3][H][W]
+  const bf16_t* w;        // [>= 32][128]: element ((kt*3 + kh)*3 + kw)*3 + c (qt_pack_conv3d_block, first = 1)
+  bf16_t* y;              // [T][B][H][W][32]
+  const float* scale;     // nullable: y = conv * scale + shift (+ ReLU)
+  const float* shift;
+  float* stats;           // [gridDim.x][2][64] or NULL (channels 32..63 written as zero)
+  int relu, B, T, H, W, items;
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const bf16_t x = (bf16_t)a, y = (bf16_t)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+template <bool AFF, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv3d_first_kernel(C3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int W = p.W, H = p.H, T = p.T;
+  const int rowb = (W + 4) * 8, slab = (C3_R + 2) * rowb;
+
+  for (int i = tid * 16; i < C3_SLABS * slab; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  // filter fragments (A operand): MFMA row li -> channel 8*(li >> 2) + 4*cb + (li & 3); k-group lg of k-step s: the tap row
+  // rr = 2s + (lg >> 1) = kt*3 + kh, pixels 2*(lg & 1) + {0, 1} of its four, 4 channel slots each
+  uint4 wf[5][2];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int ch = (li >> 2) * 8 + cb * 4 + (li & 3);
+      const int rr = 2 * s + (lg >> 1);
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dp = 2 * (lg & 1) + (j >> 2), c = j & 3;
+        const bool ok = rr < 9 && dp < 3 && c < 3;
+        const bf16_t v = ok ? p.w[(size_t)ch * 128 + (rr * 3 + dp) * 3 + c] : (bf16_t)0.f;
+        e[j] = __builtin_bit_cast(unsigned short, v);
+      }
+      wf[s][cb] = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                             e[6] | ((unsigned)e[7] << 16));
+    }
+
+  float sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = AFF ? p.scale[lg * 8 + j] : 1.f;
+    sh[j] = AFF ? p.shift[lg * 8 + j] : 0.f;
+    s1[j] = s2[j] = 0.f;
+  }
+
+  // staging: a frame slab is 6 rows x W/4 groups of four pixels; a thread owns at most two groups
+  const int quads = W >> 2, nslot = (C3_R + 2) * quads;
+  int sr[2], sq[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int sidx = tid + j * 256;
+    sr[j] = sidx / quads;
+    sq[j] = sidx - sr[j] * quads;
+  }
+  float4 pre[2][3];
+  const size_t plane = (size_t)H * W;
+  auto stage = [&](int b, int f, int h0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int hh = h0 - 1 + sr[j];
+      const bool ok = tid + j * 256 < nslot && (unsigned)hh < (unsigned)H;
+      const float* src = p.x + ((size_t)(b * T + f) * 3) * plane + (size_t)(ok ? hh : 0) * W + (ok ? sq[j] : 0) * 4;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        pre[j][c] = ok ? *reinterpret_cast<const float4*>(src + c * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](int f) {
+    unsigned char* base = smem + (f & 3) * slab;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (tid + j * 256 < nslot) {
+        uint2* dst = reinterpret_cast<uint2*>(base + sr[j] * rowb + (1 + sq[j] * 4) * 8);
+        dst[0] = make_uint2(pack_bf16x2(pre[j][0].x, pre[j][1].x), pack_bf16x2(pre[j][2].x, 0.f));
+        dst[1] = make_uint2(pack_bf16x2(pre[j][0].y, pre[j][1].y), pack_bf16x2(pre[j][2].y, 0.f));
+        dst[2] = make_uint2(pack_bf16x2(pre[j][0].z, pre[j][1].z), pack_bf16x2(pre[j][2].z, 0.f));
+        dst[3] = make_uint2(pack_bf16x2(pre[j][0].w, pre[j][1].w), pack_bf16x2(pre[j][2].w, 0.f));
+      }
+  };
+
+  const int slabs_per_img = H / C3_R, nblk = W >> 4;
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item / slabs_per_img, h0 = (item - b * slabs_per_img) * C3_R;
+    __syncthreads();                    // the previous item's last frames are done with their slabs
+    stage(b, 0, h0);
+    commit(0);
+    if (T > 1) stage(b, 1, h0);
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) commit(t + 1);
+      __syncthreads();                  // frame t + 1 is visible; every wave finished frame t - 1: slab (t + 2) & 3 is free
+      if (t + 2 < T) stage(b, t + 2, h0);
+
+      const unsigned char* a[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int rr = 2 * s + (lg >> 1);
+        const int kt = rr / 3, kh = rr - kt * 3;
+        const int f = t + kt - 1;
+        const int sl = (rr < 9 && (unsigned)f < (unsigned)T) ? (f & 3) : 4;
+        a[s] = smem + sl * slab + (wave + (rr < 9 ? kh : 0)) * rowb + (li + 2 * (lg & 1)) * 8;
+      }
+      bf16_t* yrow = p.y + ((((size_t)t * p.B + b) * H + h0 + wave) * W + li) * 32 + lg * 8;
+#pragma unroll 2
+      for (int blk = 0; blk < nblk; ++blk) {
+        uint4 xf[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          const uint2 lo = *reinterpret_cast<const uint2*>(a[s] + blk * 128);
+          const uint2 hi = *reinterpret_cast<const uint2*>(a[s] + blk * 128 + 8);
+          xf[s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        f32x4 acc[2];
+        acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s][cb]),
+                                                              __builtin_bit_cast(bf16x8, xf[s]), acc[cb], 0, 0, 0);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float acv = acc[j >> 2][j & 3];
+          if (STATS) {
+            s1[j] += acv;
+            s2[j] += acv * acv;
+          }
+          v[j] = acv;
+          if (AFF) {
+            v[j] = acv * sc[j] + sh[j];
+            if (p.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+        }
+        *reinterpret_cast<uint4*>(yrow + (size_t)blk * 16 * 32) =
+            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      }
+    }
+  }
+
+  if (STATS) {
+    // lanes of a 16-lane row hold different pixels of the same 8 channels; then the four waves through LDS, fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][32]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a1 = qt_row16_sum(s1[j]), a2 = qt_row16_sum(s2[j]);
+      if (li == 0) {
+        red[(wave * 2 + 0) * 32 + lg * 8 + j] = a1;
+        red[(wave * 2 + 1) * 32 + lg * 8 + j] = a2;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, ch = tid & 63;
+      float v = 0.f;
+      if (ch < 32) v = (red[(0 * 2 + which) * 32 + ch] + red[(1 * 2 + which) * 32 + ch]) +
+                       (red[(2 * 2 + which) * 32 + ch] + red[(3 * 2 + which) * 32 + ch]);
+      p.stats[((size_t)blockIdx.x * 2 + which) * 64 + ch] = v;
+    }
+  }
+}
+
+int c3_grid(int items) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+    }
+    return n;
+  }();
+  return items < 2 * cus ? items : 2 * cus;
+}
+
+bool c3_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("QTCNN_CONV3D_FIRST");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+bool c3_shape_ok(int dtype, const void* clips, int batch, int frames, int h, int w) {
+  return dtype == QT_BF16 && c3_enabled() && batch > 0 && frames > 0 && h >= C3_R && h % C3_R == 0 && w >= 16 && w % 16 == 0 &&
+         w <= 256 && ((uintptr_t)clips % 16) == 0;
+}
+
+}  // namespace
+
+// rows of BatchNorm partial sums qt_conv3d_first_fwd writes ([rows][2][64]), 0 = shape not covered
+extern "C" int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w) {
+  if (batch <= 0 || frames <= 0 || h < C3_R || h % C3_R || w < 16 || w % 16 || w > 256) return 0;
+  return c3_grid(batch * (h / C3_R));
+}
+
+extern "C" int qt_conv3d_first_fwd(int dtype, const float* clips, const void* w_packed, void* y, const float* scale,
+                                   const float* shift, int relu, float* stats, int batch, int frames, int h, int w,
+                                   void* stream) {
+  QT_CHECK_ARG(clips && w_packed && y && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_conv3d_first_fwd: bad argument");
+  QT_CHECK_ARG(!(scale && stats), "qt_conv3d_first_fwd: scale / shift and statistics are exclusive");
+  QT_CHECK_ARG(!scale || shift, "qt_conv3d_first_fwd: scale without shift");
+  if (!c3_shape_ok(dtype, clips, batch, frames, h, w)) {
+    qt_set_error("qt_conv3d_first_fwd: bf16, H %% 4 == 0, W %% 16 == 0, W <= 256 and a 16-byte aligned clip only "
+                 "(use qt_pack_clip27 + qt_conv2d_igemm)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  C3Args a;
+  a.x = clips; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)y; a.scale = scale; a.shift = shift; a.stats = stats;
+  a.relu = relu; a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
+  const int lds = C3_SLABS * (C3_R + 2) * (w + 4) * 8;
+  const dim3 grid(c3_grid(a.items)), blk(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = QT_OK;
+  if (scale) {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_first_kernel<true, false>, lds, done)) != QT_OK) return rc;
+    hipLaunchKernelGGL((conv3d_first_kernel<true, false>), grid, blk, lds, s, a);
+  } else if (stats) {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_first_kernel<false, true>, lds, done)) != QT_OK) return rc;
+    hipLaunchKernelGGL((conv3d_first_kernel<false, true>), grid, blk, lds, s, a);
+  } else {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_first_kernel<false, false>, lds, done)) != QT_OK) return rc;
+    hipLaunchKernelGGL((conv3d_first_kernel<false, false>), grid, blk, lds, s, a);
+  }
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

@@ -172,7 +172,7 @@ __global__ void pool3d_max_bwd_kernel(const T* __restrict__ dout, const unsigned
 template <typename T, int PT>
 __global__ void pool3d_bn_relu_max_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                           T* __restrict__ out, unsigned char* __restrict__ arg, T* __restrict__ ymax, int Tn, int B,
-                                          int H, int W, int C) {
+                                          int H, int W, int C, int Cy) {
   const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = C / 8;
   const long long n = (long long)To * B * Ho * Wo * G;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -183,6 +183,15 @@ __global__ void pool3d_bn_relu_max_kernel(const T* __restrict__ y, const float* 
     const int b = (int)(r % B);
     const int to = (int)(r / B);
     float sc[8], sh[8], best[8], braw[8];
+    const long long o = ((((long long)to * B + b) * Ho + ho) * Wo + wo) * C + g * 8;
+    if (g * 8 >= Cy) {   // channels the conv output does not have (y has Cy <= C per row): the pooled map is zero there
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[e] = 0.f;
+      QtVec8<T>::store(out + o, best);
+      if (arg) *reinterpret_cast<uint2*>(arg + o) = make_uint2(0u, 0u);
+      if (ymax) QtVec8<T>::store(ymax + o, best);
+      continue;
+    }
     QtVec8<float>::load(scale + g * 8, sc);
     QtVec8<float>::load(shift + g * 8, sh);
     unsigned char idx[8];
@@ -194,7 +203,7 @@ __global__ void pool3d_bn_relu_max_kernel(const T* __restrict__ y, const float* 
       for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
         for (int dw = 0; dw < 2; ++dw) {
-          const long long src = ((((long long)(to * PT + dt) * B + b) * H + ho * 2 + dh) * W + wo * 2 + dw) * C + g * 8;
+          const long long src = ((((long long)(to * PT + dt) * B + b) * H + ho * 2 + dh) * W + wo * 2 + dw) * Cy + g * 8;
           float v[8];
           QtVec8<T>::load(y + src, v);
 #pragma unroll
@@ -203,7 +212,6 @@ __global__ void pool3d_bn_relu_max_kernel(const T* __restrict__ y, const float* 
             if (a > best[e]) { best[e] = a; braw[e] = v[e]; idx[e] = (unsigned char)((dt * 2 + dh) * 2 + dw); }
           }
         }
-    const long long o = ((((long long)to * B + b) * Ho + ho) * Wo + wo) * C + g * 8;
     QtVec8<T>::store(out + o, best);
     if (arg) {
       uint2 pk;
@@ -223,12 +231,20 @@ template <typename T, int PT>
 __global__ void pool3d_bn_bwd_apply_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg,
                                            const T* __restrict__ pooled, const T* __restrict__ y, const float* __restrict__ mean,
                                            const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dy,
-                                           int Tn, int B, int H, int W, int C) {
-  const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = C / 8;
+                                           int Tn, int B, int H, int W, int C, int Cy, int Cd) {
+  const int To = Tn / PT, Ho = H / 2, Wo = W / 2, G = Cd / 8;
   const long long n = (long long)Tn * B * H * W * G;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int g = (int)(i % G);
     long long r = i / G;
+    const long long row = r;
+    if (g * 8 >= Cy) {   // dy rows are Cd wide, y rows Cy: the padding channels of dy are zero
+      float z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = 0.f;
+      QtVec8<T>::store(dy + row * Cd + g * 8, z);
+      continue;
+    }
     const int w = (int)(r % W); r /= W;
     const int h = (int)(r % H); r /= H;
     const int b = (int)(r % B);
@@ -250,7 +266,7 @@ __global__ void pool3d_bn_bwd_apply_kernel(const T* __restrict__ dout, const uns
         gv[e] = (a == me && pv[e] > 0.f) ? d[e] : 0.f;
       }
     }
-    QtVec8<T>::load(y + i * 8, yv);
+    QtVec8<T>::load(y + row * Cy + g * 8, yv);
     QtVec8<float>::load(mean + g * 8, mu);
     QtVec8<float>::load(invstd + g * 8, is);
     QtVec8<float>::load(coef + g * 8, ca);
@@ -259,7 +275,7 @@ __global__ void pool3d_bn_bwd_apply_kernel(const T* __restrict__ dout, const uns
     float o8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = ca[e] * (gv[e] - cb[e] - (yv[e] - mu[e]) * is[e] * cc[e]);
-    QtVec8<T>::store(dy + i * 8, o8);
+    QtVec8<T>::store(dy + row * Cd + g * 8, o8);
   }
 }
 
@@ -465,16 +481,17 @@ extern "C" int qt_pool3d_max_bwd(int dtype, const void* dout, const unsigned cha
 }
 
 extern "C" int qt_pool3d_bn_relu_max(int dtype, const void* y, const float* scale, const float* shift, void* out,
-                                     unsigned char* argmax, void* y_at_max, int frames, int batch, int h, int w, int C, int pool_t,
-                                     void* stream) {
+                                     unsigned char* argmax, void* y_at_max, int frames, int batch, int h, int w, int C,
+                                     int y_channels, int pool_t, void* stream) {
   QT_CHECK_ARG(y && scale && shift && out && frames > 0 && batch > 0 && h >= 2 && w >= 2 && C % 8 == 0,
                "qt_pool3d_bn_relu_max: bad argument");
+  QT_CHECK_ARG(y_channels > 0 && y_channels <= C && y_channels % 8 == 0, "qt_pool3d_bn_relu_max: y_channels=%d of C=%d", y_channels, C);
   QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pool3d_bn_relu_max: bad dtype %d", dtype);
   QT_CHECK_ARG((pool_t == 1 || pool_t == 2) && frames >= pool_t, "qt_pool3d_bn_relu_max: pool_t=%d", pool_t);
   const long long n = (long long)(frames / pool_t) * batch * (h / 2) * (w / 2) * (C / 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(n)), blk(256);
-#define QT_POOLF(TT, PT) hipLaunchKernelGGL((pool3d_bn_relu_max_kernel<TT, PT>), grid, blk, 0, s, (const TT*)y, scale, shift, (TT*)out, argmax, (TT*)y_at_max, frames, batch, h, w, C)
+#define QT_POOLF(TT, PT) hipLaunchKernelGGL((pool3d_bn_relu_max_kernel<TT, PT>), grid, blk, 0, s, (const TT*)y, scale, shift, (TT*)out, argmax, (TT*)y_at_max, frames, batch, h, w, C, y_channels)
   if (dtype == QT_F32) { if (pool_t == 1) QT_POOLF(float, 1); else QT_POOLF(float, 2); }
   else { if (pool_t == 1) QT_POOLF(bf16_t, 1); else QT_POOLF(bf16_t, 2); }
 #undef QT_POOLF
@@ -484,16 +501,18 @@ extern "C" int qt_pool3d_bn_relu_max(int dtype, const void* y, const float* scal
 
 extern "C" int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* argmax, const void* pooled, const void* y,
                                       const float* mean, const float* invstd, const float* coef, void* dy, int frames, int batch,
-                                      int h, int w, int C, int pool_t, void* stream) {
+                                      int h, int w, int C, int y_channels, int dy_channels, int pool_t, void* stream) {
   QT_CHECK_ARG(dout && argmax && pooled && y && mean && invstd && coef && dy && frames > 0 && batch > 0 && h >= 2 && w >= 2 &&
                    C % 8 == 0,
                "qt_pool3d_bn_bwd_apply: bad argument");
+  QT_CHECK_ARG(y_channels > 0 && y_channels <= C && y_channels % 8 == 0 && dy_channels >= y_channels && dy_channels % 8 == 0,
+               "qt_pool3d_bn_bwd_apply: y_channels=%d dy_channels=%d of C=%d", y_channels, dy_channels, C);
   QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_pool3d_bn_bwd_apply: bad dtype %d", dtype);
   QT_CHECK_ARG((pool_t == 1 || pool_t == 2) && frames >= pool_t, "qt_pool3d_bn_bwd_apply: pool_t=%d", pool_t);
-  const long long n = (long long)frames * batch * h * w * (C / 8);
+  const long long n = (long long)frames * batch * h * w * (dy_channels / 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(n)), blk(256);
-#define QT_POOLA(TT, PT) hipLaunchKernelGGL((pool3d_bn_bwd_apply_kernel<TT, PT>), grid, blk, 0, s, (const TT*)dout, argmax, (const TT*)pooled, (const TT*)y, mean, invstd, coef, (TT*)dy, frames, batch, h, w, C)
+#define QT_POOLA(TT, PT) hipLaunchKernelGGL((pool3d_bn_bwd_apply_kernel<TT, PT>), grid, blk, 0, s, (const TT*)dout, argmax, (const TT*)pooled, (const TT*)y, mean, invstd, coef, (TT*)dy, frames, batch, h, w, C, y_channels, dy_channels)
   if (dtype == QT_F32) { if (pool_t == 1) QT_POOLA(float, 1); else QT_POOLA(float, 2); }
   else { if (pool_t == 1) QT_POOLA(bf16_t, 1); else QT_POOLA(bf16_t, 2); }
 #undef QT_POOLA

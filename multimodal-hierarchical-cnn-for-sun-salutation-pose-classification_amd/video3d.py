@@ -163,16 +163,33 @@ class _Ops:
                                           None, _c.c_longlong(Mrows), C, _lib.stream_ptr()), "qt_bn_bwd_apply")
         return dy, dgb[0], dgb[1]
 
+    def pack_clip(self, dt, clip, B, T, H, W):
+        x = torch.empty(T * B * H * W, 128, dtype=dt, device=clip.device)
+        self.check(self.L.qt_pack_clip27(_lib.qt_dtype(dt), _ptr(clip), _ptr(x), B, T, H, W, _lib.stream_ptr()), "qt_pack_clip27")
+        return x
+
+    def conv3d_first(self, dt, clip, wf, y, part, B, T, H, W, flops, nbytes):
+        ev = None
+        if self.timed is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self.check(self.L.qt_conv3d_first_fwd(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), None, None, 0, _ptr(part), B, T, H, W,
+                                              _lib.stream_ptr()), "qt_conv3d_first_fwd")
+        if ev is not None:
+            ev[1].record()
+            self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_FWD)))
+
     def pool(self, dt, x, out, arg, T, B, H, W, C, pt):
         self.check(self.L.qt_pool3d_max(_lib.qt_dtype(dt), _ptr(x), _ptr(out), _ptr(arg), T, B, H, W, C, pt,
                                         _lib.stream_ptr()), "qt_pool3d_max")
 
-    def pool_bn(self, dt, y, stats, out, arg, ymax, T, B, H, W, C, pt):
-        """BatchNorm3d (scale / shift) + ReLU + MaxPool3d in one pass over the raw conv output (csrc/video3d.hip)"""
+    def pool_bn(self, dt, y, stats, out, arg, ymax, T, B, H, W, C, pt, cy=None):
+        """BatchNorm3d (scale / shift) + ReLU + MaxPool3d in one pass over the raw conv output (csrc/video3d.hip); y rows are
+        cy <= C channels wide"""
         self.check(self.L.qt_pool3d_bn_relu_max(_lib.qt_dtype(dt), _ptr(y), _ptr(stats[2]), _ptr(stats[3]), _ptr(out), _ptr(arg),
-                                                _ptr(ymax), T, B, H, W, C, pt, _lib.stream_ptr()), "qt_pool3d_bn_relu_max")
+                                                _ptr(ymax), T, B, H, W, C, cy or C, pt, _lib.stream_ptr()), "qt_pool3d_bn_relu_max")
 
-    def pool_bn_backward(self, dt, dout, arg, pooled, ymax, y, stats, gamma, T, B, H, W, C, pt, dev, batch_stats):
+    def pool_bn_backward(self, dt, dout, arg, pooled, ymax, y, stats, gamma, T, B, H, W, C, pt, dev, batch_stats, cy=None, cd=None):
         """d/d(pooled) -> (dy, dgamma, dbeta): the BatchNorm sums from the pooled side (every cell sends its gradient to one
         position), then max-pool backward + ReLU mask + BatchNorm backward in one pass; no full-size gradient map in between"""
         cells = (T // pt) * B * (H // 2) * (W // 2)
@@ -187,9 +204,10 @@ class _Ops:
         self.check(self.L.qt_bn_bwd_finalize(_ptr(part), rows, C, _c.c_longlong(Mrows if batch_stats else 0), _ptr(gamma),
                                              _ptr(stats[1]), _ptr(dgb[0]), _ptr(dgb[1]), 0, _ptr(coef), _lib.stream_ptr()),
                    "qt_bn_bwd_finalize")
-        dy = torch.empty_like(y)
+        cy, cd = cy or C, cd or cy or C
+        dy = torch.empty(Mrows, cd, dtype=dt, device=dev)
         self.check(self.L.qt_pool3d_bn_bwd_apply(q, _ptr(dout), _ptr(arg), _ptr(pooled), _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
-                                                 _ptr(coef), _ptr(dy), T, B, H, W, C, pt, _lib.stream_ptr()),
+                                                 _ptr(coef), _ptr(dy), T, B, H, W, C, cy, cd, pt, _lib.stream_ptr()),
                    "qt_pool3d_bn_bwd_apply")
         return dy, dgb[0], dgb[1]
 
@@ -279,9 +297,52 @@ class _ConvBlock:
         d.kt, d.frames = 3, T
         return d
 
+    def _raw_rows(self, dt, x, T, B, H, W):
+        """the first layer from the f32 clip itself (csrc/conv3d_first.hip): partial-sum rows, 0 = take the packed form"""
+        if not (self.first and FUSED_POOL and self.pool_t and dt == torch.bfloat16 and self.cin == 3 and self.cout == 32):
+            return 0
+        if x.data_ptr() % 16:
+            return 0
+        return ops().L.qt_conv3d_first_stats_rows(B, T, H, W) if os.environ.get("QTCNN_CONV3D_FIRST", "1") != "0" else 0
+
+    def _forward_raw(self, dt, clip, T, B, H, W, training, keep, prow):
+        """conv3d_block1 without the packed K rows: conv from the f32 clip (y: 32-channel rows, bias-free), then BatchNorm3d +
+        ReLU + MaxPool3d in one pass into the 64-channel rows the next layer reads"""
+        o, dev = ops(), clip.device
+        rows = T * B * H * W
+        y = torch.empty(rows, 32, dtype=dt, device=dev)
+        fl = 2.0 * rows * 27 * self.cin * self.cout
+        nb = 4.0 * rows * 3 + 2.0 * rows * 32
+        if training:
+            part = torch.empty(o.L.qt_stats_capacity_rows(prow), 2, self.cout_p, dtype=torch.float32, device=dev)
+            o.conv3d_first(dt, clip, self.wf, y, part, B, T, H, W, fl, nb)
+            stats = o.bn_finalize(part, prow, rows, self.cout_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p,
+                                  self.bn.num_batches_tracked, dev)
+            self.rmean_p.add_(self.bias_p, alpha=BN_MOMENTUM)
+            self.bn.running_mean.copy_(self.rmean_p[:self.cout])
+            self.bn.running_var.copy_(self.rvar_p[:self.cout])
+        else:
+            stats = o.bn_eval(self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, self.cout_p, dev)
+            # y is the bias-free accumulator: BatchNorm3d(y + bias) = y * scale + (shift + scale * bias), xhat = (y - (mean - bias)) invstd
+            stats[3].addcmul_(stats[2], self.bias_p)
+            stats[0].sub_(self.bias_p)
+            o.conv3d_first(dt, clip, self.wf, y, None, B, T, H, W, fl, nb)
+        To, Ho, Wo = T // self.pool_t, H // 2, W // 2
+        out = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=dt, device=dev)
+        arg = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=torch.uint8, device=dev) if keep else None
+        ymax = torch.empty_like(out) if keep else None
+        o.pool_bn(dt, y, stats, out, arg, ymax, T, B, H, W, self.cout_p, self.pool_t, cy=32)
+        saved = (clip, y, None, arg, stats, (T, B, H, W), training, out, ymax) if keep else None
+        return out, (To, Ho, Wo), saved
+
     def forward(self, dt, x, T, B, H, W, training, keep):
         o, dev = ops(), x.device
         rows = T * B * H * W
+        if self.first:   # x is the f32 clip [B][T][3][H][W]
+            prow = self._raw_rows(dt, x, T, B, H, W)
+            if prow > 0:
+                return self._forward_raw(dt, x, T, B, H, W, training, keep, prow)
+            x = o.pack_clip(dt, x, B, T, H, W)
         d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
         y = torch.empty(rows, self.cout_p, dtype=dt, device=dev)
         fused_eval = not training and not keep   # eval without backward: BatchNorm3d + ReLU in the conv epilogue, no second pass
@@ -347,7 +408,12 @@ class _ConvBlock:
         dev = x.device
         esz = 2 if dt == torch.bfloat16 else 4
         rows = T * B * H * W
-        if ymax is not None:
+        raw = self.first and x.dtype == torch.float32 and x.dim() == 5   # saved by _forward_raw: the clip itself, y 32 wide
+        if raw:
+            dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, self.cout_p,
+                                                   self.pool_t, dev, training, cy=32, cd=self.cout_p)
+            x = o.pack_clip(dt, x, B, T, H, W)
+        elif ymax is not None:
             dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, self.cout_p,
                                                    self.pool_t, dev, training)
         else:
@@ -647,8 +713,7 @@ class Quadtree3DCNN(_ClipModel):
         training = self.training
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
         blocks = self._conv_blocks()
-        x = torch.empty(T * B * H * W, 128, dtype=dt, device=dev)
-        o.check(o.L.qt_pack_clip27(_lib.qt_dtype(dt), _ptr(images), _ptr(x), B, T, H, W, _lib.stream_ptr()), "qt_pack_clip27")
+        x = images   # conv3d_block1 reads the f32 clip itself (or packs it: _ConvBlock.forward)
         saved_blocks = []
         t, h, w = T, H, W
         for blk in blocks:
@@ -755,8 +820,7 @@ class Ji3DCNN(_ClipModel):
         training = self.training
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
         blocks = self._conv_blocks()
-        x = torch.empty(T * B * H * W, 128, dtype=dt, device=dev)
-        o.check(o.L.qt_pack_clip27(_lib.qt_dtype(dt), _ptr(images), _ptr(x), B, T, H, W, _lib.stream_ptr()), "qt_pack_clip27")
+        x = images   # conv3d_block1 reads the f32 clip itself (or packs it: _ConvBlock.forward)
         saved_blocks = []
         t, h, w = T, H, W
         for blk in blocks:

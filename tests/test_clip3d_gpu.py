@@ -116,8 +116,8 @@ def test_fused_bn_relu_maxpool3d_equals_separate_kernels(dt, pt, T, H):
     out1 = torch.empty_like(out0)
     arg1 = torch.empty_like(arg0)
     ymax = torch.empty_like(out0)
-    L.check(lib.qt_pool3d_bn_relu_max(q, L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out1), L.ptr(arg1), L.ptr(ymax), T, B, H, W, C, pt,
-                                      st), "fused pool")
+    L.check(lib.qt_pool3d_bn_relu_max(q, L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out1), L.ptr(arg1), L.ptr(ymax), T, B, H, W, C, C,
+                                      pt, st), "fused pool")
     torch.cuda.synchronize()
     assert torch.equal(out0, out1)
     assert torch.equal(arg0, arg1)
@@ -153,7 +153,7 @@ def test_fused_bn_relu_maxpool3d_equals_separate_kernels(dt, pt, T, H):
     dgb1, coef1 = finalize(part1, rows1)
     dy1 = torch.full_like(yd, 7.0)
     L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg1), L.ptr(out1), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef1),
-                                       L.ptr(dy1), T, B, H, W, C, pt, st), "fused apply")
+                                       L.ptr(dy1), T, B, H, W, C, C, C, pt, st), "fused apply")
     torch.cuda.synchronize()
     assert torch.allclose(dgb0, dgb1, rtol=1e-5, atol=1e-5)
     tol = 2e-2 if dt == torch.bfloat16 else 1e-5
@@ -161,9 +161,27 @@ def test_fused_bn_relu_maxpool3d_equals_separate_kernels(dt, pt, T, H):
     # the same per-element arithmetic on the other path's coefficients is bit-identical
     dy2 = torch.empty_like(yd)
     L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg1), L.ptr(out1), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef0),
-                                       L.ptr(dy2), T, B, H, W, C, pt, st), "fused apply")
+                                       L.ptr(dy2), T, B, H, W, C, C, C, pt, st), "fused apply")
     torch.cuda.synchronize()
     assert torch.equal(dy0, dy2)
+
+    # y rows narrower than the pooled rows (the first layer's 32 channels feeding 64-channel K rows): same values in the
+    # first channels, zeros in the padding of pooled / argmax / y_at_max / dy
+    Cy = C // 2
+    yn = yd[..., :Cy].contiguous()
+    out3, arg3, ymax3 = torch.full_like(out0, 5.0), torch.full_like(arg0, 5), torch.full_like(out0, 5.0)
+    L.check(lib.qt_pool3d_bn_relu_max(q, L.ptr(yn), L.ptr(sc), L.ptr(sh), L.ptr(out3), L.ptr(arg3), L.ptr(ymax3), T, B, H, W, C, Cy,
+                                      pt, st), "fused pool, narrow y")
+    dy3 = torch.full_like(yd, 7.0)
+    L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg3), L.ptr(out3), L.ptr(yn), L.ptr(mu), L.ptr(isd), L.ptr(coef1),
+                                       L.ptr(dy3), T, B, H, W, C, Cy, C, pt, st), "fused apply, narrow y")
+    dy4 = torch.full_like(yn, 7.0)
+    L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg3), L.ptr(out3), L.ptr(yn), L.ptr(mu), L.ptr(isd), L.ptr(coef1),
+                                       L.ptr(dy4), T, B, H, W, C, Cy, Cy, pt, st), "fused apply, narrow y and dy")
+    torch.cuda.synchronize()
+    for full, narrow in ((out1, out3), (arg1, arg3), (ymax, ymax3), (dy1, dy3)):
+        assert torch.equal(full[..., :Cy], narrow[..., :Cy]) and (narrow[..., Cy:] == 0).all()
+    assert torch.equal(dy4, dy1[..., :Cy])
 
     # torch autograd, f32, on the values the kernels saw
     yt = y.clone().requires_grad_(True)
@@ -220,6 +238,56 @@ def test_bn_stats_pack_and_avgpool(dt):
     L.check(lib.qt_avgpool_tb_bwd(L.qt_dtype(dt), L.ptr(d.to(dev)), L.ptr(gx), T, B, HW, C, ld, col0, L.stream_ptr()), "avgpool_tb_bwd")
     want = (d[:, col0:col0 + C] / (T * HW)).view(1, B, 1, C).expand(T, B, HW, C)
     assert rel_err(gx.float().cpu(), want) <= (1e-6 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("cfg", [(2, 8, 16, 32), (3, 1, 8, 16), (1, 5, 12, 64), (2, 3, 4, 256)])
+def test_first_conv3d_from_the_f32_clip(cfg):
+    """conv3d_block1's nn.Conv3d(3, 32, 3x3x3, padding 1) (/root/reference/3dcnn/models.py:108) straight from the f32 clip
+    [B][T][3][H][W] (qt_conv3d_first_fwd): against torch CPU fp32 conv3d on the bf16-rounded clip and filter.  T = 1 (both
+    neighbour frames outside the clip), odd T, one 4-row slab per image, the widest row the kernel takes; BatchNorm3d partial
+    sums of the f32 accumulator; the folded scale / shift / ReLU form; shapes it does not cover are refused."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    B, T, H, W = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(91)
+    clip = torch.randn(B, T, 3, H, W, generator=g)
+    w = (torch.randn(32, 3, 3, 3, 3, generator=g) * (2.0 / 81) ** 0.5)
+    ref = F.conv3d(clip.to(dt).float().permute(0, 2, 1, 3, 4), w.to(dt).float(), None, 1, 1)    # [B][32][T][H][W]
+    ref_tb = ref.permute(2, 0, 3, 4, 1).contiguous()                                              # [T][B][H][W][32]
+    # the packed filter of qt_pack_conv3d_block(first = 1): [64][128], element ((kt*3 + kh)*3 + kw)*3 + c
+    wp = torch.zeros(64, 128)
+    wp[:32, :81] = w.permute(0, 2, 3, 4, 1).reshape(32, 81)
+    wp = wp.to(dev, dt)
+    cd = clip.to(dev)
+    rows = lib.qt_conv3d_first_stats_rows(B, T, H, W)
+    assert rows > 0
+    y = torch.full((T, B, H, W, 32), float("nan"), dtype=dt, device=dev)
+    part = torch.full((rows, 2, 64), float("nan"), device=dev)
+    L.check(lib.qt_conv3d_first_fwd(L.qt_dtype(dt), L.ptr(cd), L.ptr(wp), L.ptr(y), None, None, 0, L.ptr(part), B, T, H, W,
+                                    L.stream_ptr()), "qt_conv3d_first_fwd")
+    torch.cuda.synchronize()
+    assert rel_err(y.float().cpu(), ref_tb) <= 1e-2
+    sums = part.sum(0).cpu()
+    assert (sums[:, 32:] == 0).all()
+    rd = ref_tb.double().reshape(-1, 32)
+    assert rel_err(sums[0, :32], rd.sum(0)) <= 1e-4 and rel_err(sums[1, :32], (rd * rd).sum(0)) <= 1e-4
+    # plain (no statistics) is the same map; scale / shift / ReLU is applied to the f32 accumulator
+    y2 = torch.empty_like(y)
+    L.check(lib.qt_conv3d_first_fwd(L.qt_dtype(dt), L.ptr(cd), L.ptr(wp), L.ptr(y2), None, None, 0, None, B, T, H, W, L.stream_ptr()),
+            "plain")
+    sc = (torch.rand(32, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(32, generator=g) * 0.3).to(dev)
+    y3 = torch.empty_like(y)
+    L.check(lib.qt_conv3d_first_fwd(L.qt_dtype(dt), L.ptr(cd), L.ptr(wp), L.ptr(y3), L.ptr(sc), L.ptr(sh), 1, None, B, T, H, W,
+                                    L.stream_ptr()), "affine")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    assert rel_err(y3.float().cpu(), torch.relu(ref_tb * sc.cpu() + sh.cpu())) <= 1e-2
+    # not covered: f32, a width that is not a multiple of 16, a height that is not a multiple of 4
+    assert lib.qt_conv3d_first_fwd(L.QT_F32, L.ptr(cd), L.ptr(wp), L.ptr(y), None, None, 0, None, B, T, H, W, L.stream_ptr()) == -3
+    assert lib.qt_conv3d_first_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_first_stats_rows(B, T, H + 2, W) == 0
 
 
 CASES = [("q3_t8", 2, 8, 112, "quadtree_3d_fusion", 31), ("q3_t5", 2, 5, 64, "quadtree_3d_fusion", 31),
