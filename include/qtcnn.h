@@ -513,6 +513,14 @@ int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* arg
  * back at 32 x 8 x 224 x 224).  QT_ERR_UNSUPPORTED (take the packed form) for f32, H % 4, W % 16, W > 256, a clip that is
  * not 16-byte aligned, QTCNN_CONV3D_FIRST=0. */
 int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w);
+/* ... and its weight gradient from the f32 clip and dy [T][B][H][W][32] (32-channel rows, what qt_pool3d_bn_bwd_apply
+ * writes with dy_channels = 32): dweight [32][3][3][3][3] f32 in nn.Conv3d's own layout, every element written; partial
+ * filters per workgroup in `workspace` (qt_conv3d_first_wgrad_workspace_bytes, 0 = shape not covered: W % 32, else as
+ * qt_conv3d_first_fwd) added in a fixed order: deterministic.  Replaces qt_pack_clip27 + qt_conv2d_wgrad +
+ * qt_unpack_conv3d_wgrad. */
+size_t qt_conv3d_first_wgrad_workspace_bytes(int batch, int frames, int h, int w);
+int qt_conv3d_first_wgrad(int dtype, const float* clips, const void* dy, float* dweight, void* workspace,
+                          size_t workspace_bytes, int batch, int frames, int h, int w, void* stream);
 int qt_conv3d_first_fwd(int dtype, const float* clips, const void* w_packed, void* y, const float* scale, const float* shift,
                         int relu, float* stats, int batch, int frames, int h, int w, void* stream);
 /* nn.AdaptiveAvgPool3d((1,1,1)) + flatten(1) into columns [col0, col0+C) of an f32 [B][ld] matrix, and its backward */

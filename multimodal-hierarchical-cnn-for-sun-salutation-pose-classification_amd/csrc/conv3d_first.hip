@@ -197,6 +197,196 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(C3Args p) {
   }
 }
 
+// ---- weight gradient of the same layer from the f32 clip and d(loss)/dy [T][B][H][W][32] ---------------------------------
+//   dW[ch][kt][kh][kw][c] = sum over positions of dy[pos][ch] * x[t + kt - 1][c][h + kh - 1][w + kw - 1]
+// The contraction runs over positions (MFMA k = 32 consecutive pixels of a row).  Same walk and the same bf16 frame slabs as the
+// forward; a wave owns one of the slab's four rows and streams its dy row through a private LDS ring by LDS-DMA (2 KB =
+// 32 positions per chunk, two chunks ahead, counted vmcnt waits, no barrier).  Both operands are position-major in LDS and
+// come out k-major through ds_read_b64_tr_b16: dy as 16 channels x 32 positions, the clip as (4 window pixels x 4 channel
+// slots) x 32 positions per tap row -- the window of position w starts at staged pixel w, so the im2col overlap is again
+// only an address (lane (row, pp) reads the 8 bytes of pixel w0 + row + pp).  18 accumulator tiles per wave:
+// 2 channel blocks x 9 tap rows, 22 transposing reads per 18 MFMAs.  Every workgroup writes its partial filter
+// [32][9][16]; c3_wgrad_sum_kernel adds them in a fixed order straight into the reference's [32][3][3][3][3] layout:
+// deterministic, no atomics, no unpack launch.
+constexpr int C3W_D = 2;             // dy chunks in flight ahead of the one being multiplied
+constexpr int C3W_NCH = C3W_D + 1;   // ring slots per wave
+constexpr int C3W_PART = 32 * 9 * 16;
+
+struct C3WArgs {
+  const float* x;         // [B][T][3][H][W]
+  const bf16_t* dy;       // [T][B][H][W][32]
+  float* part;            // [gridDim.x][32][9][16]
+  int B, T, H, W, items;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_first_wgrad_kernel(C3WArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int lrow = 4 * lg + (li >> 2), pp = li & 3;
+  const int W = p.W, H = p.H, T = p.T;
+  const int rowb = (W + 4) * 8, slab = (C3_R + 2) * rowb;
+  const unsigned smem_base = lds_addr_of(smem);
+  const unsigned ring = smem_base + C3_SLABS * slab + wave * (C3W_NCH * 2048);
+
+  for (int i = tid * 16; i < C3_SLABS * slab; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) acc[cb][rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int quads = W >> 2, nslot = (C3_R + 2) * quads;
+  int sr[2], sq[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int sidx = tid + j * 256;
+    sr[j] = sidx / quads;
+    sq[j] = sidx - sr[j] * quads;
+  }
+  float4 pre[2][3];
+  const size_t plane = (size_t)H * W;
+  auto stage = [&](int b, int f, int h0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int hh = h0 - 1 + sr[j];
+      const bool ok = tid + j * 256 < nslot && (unsigned)hh < (unsigned)H;
+      const float* src = p.x + ((size_t)(b * T + f) * 3) * plane + (size_t)(ok ? hh : 0) * W + (ok ? sq[j] : 0) * 4;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        pre[j][c] = ok ? *reinterpret_cast<const float4*>(src + c * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](int f) {
+    unsigned char* base = smem + (f & 3) * slab;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (tid + j * 256 < nslot) {
+        uint2* dst = reinterpret_cast<uint2*>(base + sr[j] * rowb + (1 + sq[j] * 4) * 8);
+        dst[0] = make_uint2(pack_bf16x2(pre[j][0].x, pre[j][1].x), pack_bf16x2(pre[j][2].x, 0.f));
+        dst[1] = make_uint2(pack_bf16x2(pre[j][0].y, pre[j][1].y), pack_bf16x2(pre[j][2].y, 0.f));
+        dst[2] = make_uint2(pack_bf16x2(pre[j][0].z, pre[j][1].z), pack_bf16x2(pre[j][2].z, 0.f));
+        dst[3] = make_uint2(pack_bf16x2(pre[j][0].w, pre[j][1].w), pack_bf16x2(pre[j][2].w, 0.f));
+      }
+  };
+
+  // the wave's stream of dy chunks: (item, frame, chunk of 32 pixels of row h0 + wave), issued C3W_D ahead of use
+  const int slabs_per_img = H / C3_R, nck = W >> 5;
+  int is_item = blockIdx.x, is_t = 0, is_c = 0;   // next chunk to issue
+  int n_issued = 0, n_used = 0;
+  auto issue = [&]() {
+    if (is_item >= p.items) return;
+    const int b = is_item / slabs_per_img, h0 = (is_item - b * slabs_per_img) * C3_R;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(
+        p.dy + ((((size_t)is_t * p.B + b) * H + h0 + wave) * W + is_c * 32) * 32);
+    const unsigned dst = ring + (unsigned)(n_issued % C3W_NCH) * 2048u;
+    glds16(src + lane * 16, dst);
+    glds16(src + 1024 + lane * 16, dst + 1024);
+    ++n_issued;
+    if (++is_c == nck) {
+      is_c = 0;
+      if (++is_t == T) {
+        is_t = 0;
+        is_item += gridDim.x;
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < C3W_D; ++d) issue();
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item / slabs_per_img, h0 = (item - b * slabs_per_img) * C3_R;
+    __syncthreads();
+    stage(b, 0, h0);
+    commit(0);
+    if (T > 1) stage(b, 1, h0);
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) commit(t + 1);
+      __syncthreads();
+      if (t + 2 < T) stage(b, t + 2, h0);
+
+      unsigned xa[9];   // tap row rr: pixel (lrow + pp) of row wave + kh of frame t + kt - 1 (the zero slab outside the clip)
+#pragma unroll
+      for (int rr = 0; rr < 9; ++rr) {
+        const int kt = rr / 3, kh = rr - kt * 3;
+        const int f = t + kt - 1;
+        const int sl = (unsigned)f < (unsigned)T ? (f & 3) : 4;
+        xa[rr] = smem_base + sl * slab + (wave + kh) * rowb + (lrow + pp) * 8;
+      }
+      for (int c = 0; c < nck; ++c) {
+        issue();
+        const int ahead = n_issued - n_used - 1;   // chunks issued after the one about to be read
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned da = ring + (unsigned)(n_used % C3W_NCH) * 2048u + lrow * 64 + pp * 8;
+        ++n_used;
+        uint4 fa[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(da + cb * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(da + cb * 32 + 1024));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fa[cb] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(xa[rr] + c * 256));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(xa[rr] + c * 256 + 128));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          const uint4 fb = make_uint4(l2.x, l2.y, h2.x, h2.y);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc[cb][rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[cb]),
+                                                                  __builtin_bit_cast(bf16x8, fb), acc[cb][rr], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // the four waves' filters through LDS in a fixed order; lane: channels 16 cb + 4 lg + r, column li of tap row rr
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);   // [4][C3W_PART]
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * C3W_PART + ((cb * 16 + lg * 4 + r) * 9 + rr) * 16 + li] = acc[cb][rr][r];
+  __syncthreads();
+  for (int i = tid; i < C3W_PART; i += 256)
+    p.part[(size_t)blockIdx.x * C3W_PART + i] = (red[i] + red[C3W_PART + i]) + (red[2 * C3W_PART + i] + red[3 * C3W_PART + i]);
+}
+
+// dW [32][3 c][3 kt][3 kh][3 kw] (nn.Conv3d weight layout) = sum over the workgroups' partial filters, ascending order
+__global__ __launch_bounds__(256) void c3_wgrad_sum_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int o = blockIdx.x * 32 + col;     // (ch, c, kt, kh, kw)
+  float s = 0.f;
+  if (o < 32 * 81) {
+    const int ch = o / 81, rem = o - ch * 81;
+    const int c = rem / 27, tap = rem - c * 27;      // tap = (kt*3 + kh)*3 + kw
+    const int rr = tap / 3, kw = tap - rr * 3;
+    const float* src = part + (ch * 9 + rr) * 16 + kw * 4 + c;
+    const int per = (nparts + 7) / 8;
+    const int beg = sg * per, end = min(nparts, beg + per);
+#pragma unroll 8
+    for (int k = beg; k < end; ++k) s += src[(size_t)k * C3W_PART];
+  }
+  red[sg][col] = s;
+  __syncthreads();
+  if (sg == 0 && o < 32 * 81) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][col];
+    dw[o] = t;
+  }
+}
+
 int c3_grid(int items) {
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -223,6 +413,39 @@ bool c3_shape_ok(int dtype, const void* clips, int batch, int frames, int h, int
 }
 
 }  // namespace
+
+extern "C" size_t qt_conv3d_first_wgrad_workspace_bytes(int batch, int frames, int h, int w) {
+  if (!c3_enabled() || batch <= 0 || frames <= 0 || h < C3_R || h % C3_R || w < 32 || w % 32 || w > 256) return 0;
+  return (size_t)c3_grid(batch * (h / C3_R)) * C3W_PART * sizeof(float);
+}
+
+extern "C" int qt_conv3d_first_wgrad(int dtype, const float* clips, const void* dy, float* dweight, void* workspace,
+                                     size_t workspace_bytes, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(clips && dy && dweight && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_conv3d_first_wgrad: bad argument");
+  const size_t need = qt_conv3d_first_wgrad_workspace_bytes(batch, frames, h, w);
+  if (dtype != QT_BF16 || need == 0 || ((uintptr_t)clips % 16) != 0 || ((uintptr_t)dy % 16) != 0) {
+    qt_set_error("qt_conv3d_first_wgrad: bf16, H %% 4 == 0, W %% 32 == 0, W <= 256, 16-byte aligned operands only "
+                 "(use qt_pack_clip27 + qt_conv2d_wgrad)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  QT_CHECK_ARG(workspace && workspace_bytes >= need, "qt_conv3d_first_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
+               need);
+  C3WArgs a;
+  a.x = clips; a.dy = (const bf16_t*)dy; a.part = (float*)workspace;
+  a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
+  const int grid = c3_grid(a.items);
+  int lds = C3_SLABS * (C3_R + 2) * (w + 4) * 8 + 4 * C3W_NCH * 2048;
+  if (lds < 4 * C3W_PART * 4) lds = 4 * C3W_PART * 4;   // the four waves' filters at the end
+  static std::atomic<unsigned long long> done{0};
+  int rc = qt_raise_lds_limit((const void*)conv3d_first_wgrad_kernel, lds, done);
+  if (rc != QT_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(conv3d_first_wgrad_kernel, dim3(grid), dim3(256), lds, s, a);
+  QT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(c3_wgrad_sum_kernel, dim3((32 * 81 + 31) / 32), dim3(256), 0, s, (const float*)workspace, dweight, grid);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
 
 // rows of BatchNorm partial sums qt_conv3d_first_fwd writes ([rows][2][64]), 0 = shape not covered
 extern "C" int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w) {

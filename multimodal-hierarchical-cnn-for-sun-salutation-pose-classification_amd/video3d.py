@@ -409,10 +409,14 @@ class _ConvBlock:
         esz = 2 if dt == torch.bfloat16 else 4
         rows = T * B * H * W
         raw = self.first and x.dtype == torch.float32 and x.dim() == 5   # saved by _forward_raw: the clip itself, y 32 wide
+        raw_ws = 0
         if raw:
+            o.L.qt_conv3d_first_wgrad_workspace_bytes.restype = _c.c_size_t
+            raw_ws = int(o.L.qt_conv3d_first_wgrad_workspace_bytes(B, T, H, W))
             dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, self.cout_p,
-                                                   self.pool_t, dev, training, cy=32, cd=self.cout_p)
-            x = o.pack_clip(dt, x, B, T, H, W)
+                                                   self.pool_t, dev, training, cy=32, cd=32 if raw_ws else self.cout_p)
+            if not raw_ws:   # (a width the raw weight-gradient kernel does not take: the packed rows after all)
+                x = o.pack_clip(dt, x, B, T, H, W)
         elif ymax is not None:
             dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, self.cout_p,
                                                    self.pool_t, dev, training)
@@ -434,6 +438,11 @@ class _ConvBlock:
             db = self.gamma_p.detach().float() * stats[1] * dbeta
         dW = torch.empty_like(self.conv.weight)
         dx = None
+        if raw_ws:
+            ws = torch.empty(raw_ws, dtype=torch.uint8, device=dev)
+            o.check(o.L.qt_conv3d_first_wgrad(_lib.qt_dtype(dt), _ptr(x), _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(raw_ws), B, T, H, W,
+                                              _lib.stream_ptr()), "qt_conv3d_first_wgrad")
+            return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
         if self.first:
             d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
             dw = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)

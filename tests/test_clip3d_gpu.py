@@ -285,6 +285,26 @@ def test_first_conv3d_from_the_f32_clip(cfg):
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
     assert rel_err(y3.float().cpu(), torch.relu(ref_tb * sc.cpu() + sh.cpu())) <= 1e-2
+    # weight gradient from the clip and a 32-channel-row gradient map, in nn.Conv3d's layout; deterministic
+    lib.qt_conv3d_first_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nws = int(lib.qt_conv3d_first_wgrad_workspace_bytes(B, T, H, W))
+    assert (nws > 0) == (W % 32 == 0)
+    if nws:
+        dyt = torch.randn(T, B, H, W, 32, generator=g).to(dt)
+        xr = clip.to(dt).float().permute(0, 2, 1, 3, 4).contiguous()
+        wr = w.to(dt).float().requires_grad_(True)
+        F.conv3d(xr, wr, None, 1, 1).backward(dyt.float().permute(1, 4, 0, 2, 3))
+        dyd = dyt.to(dev)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        outs = []
+        for _ in range(2):
+            dw = torch.full((32, 3, 3, 3, 3), float("nan"), device=dev)
+            L.check(lib.qt_conv3d_first_wgrad(L.qt_dtype(dt), L.ptr(cd), L.ptr(dyd), L.ptr(dw), L.ptr(ws), ctypes.c_size_t(nws), B, T, H,
+                                              W, L.stream_ptr()), "qt_conv3d_first_wgrad")
+            torch.cuda.synchronize()
+            outs.append(dw.cpu())
+        assert rel_err(outs[0], wr.grad) <= 2e-4        # products of bf16 values are exact in f32: only the summation order differs
+        assert torch.equal(outs[0], outs[1])
     # not covered: f32, a width that is not a multiple of 16, a height that is not a multiple of 4
     assert lib.qt_conv3d_first_fwd(L.QT_F32, L.ptr(cd), L.ptr(wp), L.ptr(y), None, None, 0, None, B, T, H, W, L.stream_ptr()) == -3
     assert lib.qt_conv3d_first_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_first_stats_rows(B, T, H + 2, W) == 0
