@@ -495,8 +495,8 @@ def main():
                         "steps_profiled": args.profile_steps, "by_kernel": per}
 
     if eng is None and args.model == "quadtree3d" and args.profile_steps > 0:
-        # no plan behind the clip models: the Conv3d launches (qt_conv2d_igemm with 27 taps, forward + data gradient) are
-        # timed per launch with HIP events on their stream in extra steps (video3d.py::_Ops.igemm)
+        # no plan behind the clip models: the Conv3d launches (qt_conv2d_igemm with 27 taps, forward + data gradient; block 1's
+        # qt_conv3d_first_fwd) are timed per launch with HIP events on their stream in extra steps (video3d.py::_Ops.igemm)
         v3d = importlib.import_module(PKG + ".video3d")
         v3d.ops().timed = []
         for _ in range(args.profile_steps):
@@ -509,7 +509,7 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             per = {}
-            for mode, nm in ((0, "forward Conv3d launches (conv_igemm_kernel, 27 taps; block 1: 1x1 over packed K rows)"),
+            for mode, nm in ((0, "forward Conv3d launches (conv_igemm_kernel, 27 taps; block 1: conv3d_first_kernel from the f32 clip)"),
                              (1, "data-gradient Conv3d launches (conv_igemm_kernel, 27 taps)")):
                 sel = [r for r in recs if r[4] == mode]
                 if sel:
@@ -517,7 +517,7 @@ def main():
                     per[nm] = {"launches_per_step": len(sel) // args.profile_steps, "avg_us": round(1e3 * msk / len(sel), 1),
                                "tflops": round(sum(r[2] for r in sel) / (msk * 1e-3) / 1e12, 1),
                                "algorithmic_mb_per_launch": round(sum(r[3] for r in sel) / len(sel) / 1e6, 1)}
-            roofline = {"kernel": "Conv3d launches of the step (one 27-tap implicit GEMM per convolution and direction)",
+            roofline = {"kernel": "Conv3d launches of the step (one 27-tap implicit GEMM per convolution and direction; block 1 from the f32 clip)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": None, "traffic_source": "no PMC pass collected for this model",
                         "algorithmic_bytes_per_launch": round(tot_by / len(recs)), "avg_launch_us": round(1e3 * tot_ms / len(recs), 1),
