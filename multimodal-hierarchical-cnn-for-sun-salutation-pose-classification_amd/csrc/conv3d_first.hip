@@ -40,8 +40,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-template <bool AFF, bool STATS>
+// POOL (eval, needs AFF): MaxPool3d((1,2,2)) of relu(conv * scale + shift) in registers -- a wave owns a row PAIR of the slab
+// and every second block of 16 pixels; vertical maximum between its two accumulator sets, horizontal between neighbour lanes
+// (DPP); only the pooled map [T][B][H/2][W/2][64] is written (channels 32..63 zero: the rows block 2 reads), y never exists.
+template <bool AFF, bool STATS, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(C3Args p) {
+  static_assert(!POOL || (AFF && !STATS), "the pooled form is the eval form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,6 +139,46 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(C3Args p) {
         const int f = t + kt - 1;
         const int sl = (rr < 9 && (unsigned)f < (unsigned)T) ? (f & 3) : 4;
         a[s] = smem + sl * slab + (wave + (rr < 9 ? kh : 0)) * rowb + (li + 2 * (lg & 1)) * 8;
+      }
+      if (POOL) {
+        const int pr = wave & 1;   // row pair of the slab; blocks (wave >> 1), (wave >> 1) + 2, ...
+        // the addresses above are for slab row `wave`: move them to row 2 * pr
+        const int back = (wave - 2 * pr) * rowb;
+        bf16_t* orow = p.y + ((((size_t)t * p.B + b) * (H >> 1) + (h0 >> 1) + pr) * (W >> 1) + (li >> 1)) * 64 +
+                       ((li & 1) ? 32 : 0) + lg * 8;
+        for (int blk = wave >> 1; blk < nblk; blk += 2) {
+          f32x4 acc[2][2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            uint4 xf[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const unsigned char* q = a[s] - back + r * rowb + blk * 128;
+              const uint2 lo = *reinterpret_cast<const uint2*>(q);
+              const uint2 hi = *reinterpret_cast<const uint2*>(q + 8);
+              xf[s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            acc[r][0] = acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb)
+                acc[r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s][cb]),
+                                                                     __builtin_bit_cast(bf16x8, xf[s]), acc[r][cb], 0, 0, 0);
+          }
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v0 = fmaxf(acc[0][j >> 2][j & 3] * sc[j] + sh[j], 0.f);
+            const float v1 = fmaxf(acc[1][j >> 2][j & 3] * sc[j] + sh[j], 0.f);
+            const float m = fmaxf(v0, v1);
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xb1, 0xf, 0xf, false));
+            v[j] = (li & 1) ? 0.f : fmaxf(m, o);   // odd lanes write the zero half of their left neighbour's pooled row
+          }
+          *reinterpret_cast<uint4*>(orow + (size_t)blk * 8 * 64) =
+              make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+        continue;
       }
       bf16_t* yrow = p.y + ((((size_t)t * p.B + b) * H + h0 + wave) * W + li) * 32 + lg * 8;
 #pragma unroll 2
@@ -443,6 +487,29 @@ extern "C" int qt_conv3d_first_wgrad(int dtype, const float* clips, const void* 
   hipLaunchKernelGGL(conv3d_first_wgrad_kernel, dim3(grid), dim3(256), lds, s, a);
   QT_CHECK_LAUNCH();
   hipLaunchKernelGGL(c3_wgrad_sum_kernel, dim3((32 * 81 + 31) / 32), dim3(256), 0, s, (const float*)workspace, dweight, grid);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+// Eval forward of conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv bias folded
+// into shift) + ReLU + MaxPool3d((1,2,2)); pooled [T][B][H/2][W/2][64], channels 32..63 zero.  Shapes as qt_conv3d_first_fwd.
+extern "C" int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const void* w_packed, void* pooled, const float* scale,
+                                        const float* shift, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(clips && w_packed && pooled && scale && shift && batch > 0 && frames > 0 && h > 0 && w > 0,
+               "qt_conv3d_first_fwd_pool: bad argument");
+  if (!c3_shape_ok(dtype, clips, batch, frames, h, w)) {
+    qt_set_error("qt_conv3d_first_fwd_pool: bf16, H %% 4 == 0, W %% 16 == 0, W <= 256 and a 16-byte aligned clip only "
+                 "(use qt_conv3d_first_fwd / qt_pack_clip27 + qt_conv2d_igemm, then qt_pool3d_max)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  C3Args a;
+  a.x = clips; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)pooled; a.scale = scale; a.shift = shift; a.stats = nullptr;
+  a.relu = 1; a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
+  const int lds = C3_SLABS * (C3_R + 2) * (w + 4) * 8;
+  static std::atomic<unsigned long long> done{0};
+  if (int rc = qt_raise_lds_limit((const void*)conv3d_first_kernel<true, false, true>, lds, done)) return rc;
+  hipLaunchKernelGGL((conv3d_first_kernel<true, false, true>), dim3(c3_grid(a.items)), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), a);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

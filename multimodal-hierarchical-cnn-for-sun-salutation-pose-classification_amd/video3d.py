@@ -168,13 +168,17 @@ class _Ops:
         self.check(self.L.qt_pack_clip27(_lib.qt_dtype(dt), _ptr(clip), _ptr(x), B, T, H, W, _lib.stream_ptr()), "qt_pack_clip27")
         return x
 
-    def conv3d_first(self, dt, clip, wf, y, part, B, T, H, W, flops, nbytes):
+    def conv3d_first(self, dt, clip, wf, y, part, B, T, H, W, flops, nbytes, pooled=None):
         ev = None
         if self.timed is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        self.check(self.L.qt_conv3d_first_fwd(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), None, None, 0, _ptr(part), B, T, H, W,
-                                              _lib.stream_ptr()), "qt_conv3d_first_fwd")
+        if pooled is not None:   # y is the pooled map; pooled = the folded BatchNorm3d's (.., .., scale, shift)
+            self.check(self.L.qt_conv3d_first_fwd_pool(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), _ptr(pooled[2]), _ptr(pooled[3]),
+                                                       B, T, H, W, _lib.stream_ptr()), "qt_conv3d_first_fwd_pool")
+        else:
+            self.check(self.L.qt_conv3d_first_fwd(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), None, None, 0, _ptr(part), B, T, H, W,
+                                                  _lib.stream_ptr()), "qt_conv3d_first_fwd")
         if ev is not None:
             ev[1].record()
             self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_FWD)))
@@ -310,7 +314,7 @@ class _ConvBlock:
         ReLU + MaxPool3d in one pass into the 64-channel rows the next layer reads"""
         o, dev = ops(), clip.device
         rows = T * B * H * W
-        y = torch.empty(rows, 32, dtype=dt, device=dev)
+        y = torch.empty(rows, 32, dtype=dt, device=dev) if (training or keep or self.pool_t != 1) else None
         fl = 2.0 * rows * 27 * self.cin * self.cout
         nb = 4.0 * rows * 3 + 2.0 * rows * 32
         if training:
@@ -326,6 +330,10 @@ class _ConvBlock:
             # y is the bias-free accumulator: BatchNorm3d(y + bias) = y * scale + (shift + scale * bias), xhat = (y - (mean - bias)) invstd
             stats[3].addcmul_(stats[2], self.bias_p)
             stats[0].sub_(self.bias_p)
+            if not keep and self.pool_t == 1:   # eval without backward: the whole block in one launch, y never exists
+                out = torch.empty(T * B * (H // 2) * (W // 2), self.cout_p, dtype=dt, device=dev)
+                o.conv3d_first(dt, clip, self.wf, out, None, B, T, H, W, fl, 4.0 * rows * 3 + 2.0 * out.numel(), pooled=stats)
+                return out, (T, H // 2, W // 2), None
             o.conv3d_first(dt, clip, self.wf, y, None, B, T, H, W, fl, nb)
         To, Ho, Wo = T // self.pool_t, H // 2, W // 2
         out = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=dt, device=dev)
@@ -572,6 +580,9 @@ class _ClipModel(nn.Module):
     def _run(self, image_sequence, numerical_sequence):
         self._check_hooks()
         params = [p for p in self.parameters()]
+        # needs_input_grad reports requires_grad even under torch.no_grad(): without this an eval forward under no_grad kept
+        # every activation and never took the fused eval kernels
+        self._grad_mode = torch.is_grad_enabled()
         return _ClipFunction.apply(self, image_sequence, numerical_sequence, *params)
 
 
@@ -579,7 +590,7 @@ class _ClipFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, images, numerical, *params):
         # (grad mode is off inside Function.forward; `needs_input_grad` tells whether a backward may follow)
-        keep = any(ctx.needs_input_grad[3:])
+        keep = owner._grad_mode and any(ctx.needs_input_grad[3:])
         with torch.cuda.device(images.device):
             logits = owner._forward_impl(images, numerical, keep)
         ctx.owner = owner
