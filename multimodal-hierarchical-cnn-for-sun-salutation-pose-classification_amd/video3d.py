@@ -243,6 +243,34 @@ class _Ops:
 # pass backward (csrc/video3d.hip); 0: qt_bn_act + qt_pool3d_max / qt_pool3d_max_bwd + qt_bn_bwd_reduce + qt_bn_bwd_apply
 FUSED_POOL = os.environ.get("QTCNN_POOL3D_FUSED", "1") != "0"
 
+# QTCNN_LSTM_SIDE_STREAM (default 1): Quadtree3DCNN's LSTM branch (a dozen latency-bound launches of 32 workgroups, 0.3 ms
+# forward and 0.25 ms backward in a row) runs on a second stream beside the conv blocks, which it does not depend on
+LSTM_SIDE = os.environ.get("QTCNN_LSTM_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+
+
+class _Side:
+    """fork / join of a per-device second stream around a branch; tensors made there and used on the main stream are
+    recorded on it (the caching allocator's pools are per stream)"""
+
+    def __init__(self, dev):
+        self.main = torch.cuda.current_stream(dev)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device())
+        if key not in _side_streams:
+            _side_streams[key] = torch.cuda.Stream(device=dev)
+        self.side = _side_streams[key]
+
+    def fork(self):
+        self.side.wait_stream(self.main)
+        return torch.cuda.stream(self.side)
+
+    def join(self, *tensors):
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
+
+
 _ops = None
 
 
@@ -733,6 +761,18 @@ class Quadtree3DCNN(_ClipModel):
         training = self.training
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
         blocks = self._conv_blocks()
+        fusion = self.mode == 'quadtree_3d_fusion'
+        lstm = last = side = None
+        if fusion:   # the numerical branch first: on the second stream it runs under the conv blocks
+            lstm = _Lstm(self.numerical_lstm)
+            side = _Side(dev) if LSTM_SIDE else None
+            if side is not None:
+                with side.fork():
+                    hout = lstm.forward(numerical.view(B * T, -1), B, T, training, seed)
+                    last = hout.view(B, T, lstm.H)[:, -1, :].contiguous()
+            else:
+                hout = lstm.forward(numerical.view(B * T, -1), B, T, training, seed)
+                last = hout.view(B, T, lstm.H)[:, -1, :].contiguous()
         x = images   # conv3d_block1 reads the f32 clip itself (or packs it: _ConvBlock.forward)
         saved_blocks = []
         t, h, w = T, H, W
@@ -741,18 +781,15 @@ class Quadtree3DCNN(_ClipModel):
             x, (t, h, w), sv = blk.forward(dt, x, t, B, h, w, training, keep)
             saved_blocks.append(sv)
         F_img = self.cnn_3d_feature_dim
-        fusion = self.mode == 'quadtree_3d_fusion'
         ld = self.final_classifier_input_dim
         fused = torch.empty(B, ld, dtype=torch.float32, device=dev)
         o.check(o.L.qt_avgpool_tb(_lib.qt_dtype(dt), _ptr(x), _ptr(fused), t, B, h * w, blocks[-1].cout_p, ld, 0,
                                   _lib.stream_ptr()), "qt_avgpool_tb")
         p = self.dropout_rate if training else 0.0
-        lstm = last = None
         if fusion:
-            lstm = _Lstm(self.numerical_lstm)
-            hout = lstm.forward(numerical.view(B * T, -1), B, T, training, seed)
+            if side is not None:
+                side.join(last)
             Hn = lstm.H
-            last = hout.view(B, T, Hn)[:, -1, :].contiguous()
             _Head.linear_fwd(last, Hn, 0, self.numerical_projection[0], B, fused, ld, F_img, 1)
             if p > 0:
                 o.dropout(fused, B, self.numerical_final_dim, ld, F_img, seed + 1, p)
@@ -787,10 +824,17 @@ class Quadtree3DCNN(_ClipModel):
             dlast = torch.empty(B, Hn, dtype=torch.float32, device=dev)
             g["numerical_projection.0.weight"], g["numerical_projection.0.bias"] = _Head.linear_bwd(
                 dproj, Fn, 0, last, Hn, 0, self.numerical_projection[0], B, True, dlast, Hn, 0)
-            lg = lstm.backward(dlast, B, T)
+            side = _Side(dev) if LSTM_SIDE else None
+            if side is not None:   # (joined after the image branch's backward)
+                with side.fork():
+                    lg = lstm.backward(dlast, B, T)
+            else:
+                lg = lstm.backward(dlast, B, T)
             for k in range(lstm.layers):
                 for j, nm in enumerate(("weight_ih", "weight_hh", "bias_ih", "bias_hh")):
                     g[f"numerical_lstm.{nm}_l{k}"] = lg[4 * k + j]
+        else:
+            side = None
         # image branch
         C_last = blocks[-1].cout_p
         dout = torch.empty(t * B * h * w, C_last, dtype=dt, device=dev)
@@ -800,6 +844,8 @@ class Quadtree3DCNN(_ClipModel):
         for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), reversed(names)):
             dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
             g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
+        if side is not None:
+            side.join(*lg)
         self._saved = None
         return [g.get(n) for n, _ in self.named_parameters()]
 
