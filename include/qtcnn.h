@@ -513,6 +513,15 @@ int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* arg
  * back at 32 x 8 x 224 x 224).  QT_ERR_UNSUPPORTED (take the packed form) for f32, H % 4, W % 16, W > 256, a clip that is
  * not 16-byte aligned, QTCNN_CONV3D_FIRST=0. */
 int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w);
+/* Round 3: the clip models' second Conv3d (32 -> 64 channels, 3x3x3, pad 1; /root/reference/3dcnn/models.py:115) with the
+ * input frame slabs resident in LDS: x [T][B][H][W][x_channels] (channels 0..31 read: the 64-channel-padded pooled map of
+ * block 1, or 32-channel rows), w_packed = qt_pack_conv3d_block's [64][27][64], y [T][B][H][W][64].  Bias-free accumulator
+ * with either scale / shift (+ relu) of 64 channels, or stats = qt_conv3d_c32_stats_rows(...) rows of [2][64] partial sums
+ * for qt_bn_finalize, or neither.  Same result as qt_conv2d_igemm with kt = 3 on the same operands (other summation order).
+ * QT_ERR_UNSUPPORTED (take qt_conv2d_igemm) for f32, odd H, W % 16, W > 128, misaligned operands, QTCNN_CONV3D_SLAB=0. */
+int qt_conv3d_c32_stats_rows(int batch, int frames, int h, int w);
+int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const void* w_packed, void* y, const float* scale,
+                      const float* shift, int relu, float* stats, int batch, int frames, int h, int w, void* stream);
 /* Eval forward of the whole conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv
  * bias folded into shift) + ReLU + MaxPool3d((1,2,2)) in registers; pooled [T][B][H/2][W/2][64] with channels 32..63 zero (the
  * K rows block 2 reads); the conv map never reaches memory.  Same values as qt_conv3d_first_fwd(scale, shift, relu) followed by

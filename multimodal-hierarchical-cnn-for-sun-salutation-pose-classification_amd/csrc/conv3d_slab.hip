@@ -1,0 +1,237 @@
+// Conv3d(32 -> 64, 3x3x3, pad 1) of the clip models' second block with the input frame slabs resident in LDS, bf16 MFMA.
+//
+// Replaces nn.Conv3d(32, 64, kernel_size=(3,3,3), padding=(1,1,1)) of conv3d_block2 (/root/reference/3dcnn/models.py:115,
+// reached from Quadtree3DCNN.forward, models.py:189-193) in the forward pass.
+//
+// The 27-tap implicit GEMM (conv_igemm.hip, qt_conv_desc.kt = 3) fetches every 128-byte K row 27 times through L2 --
+// 11 GB per launch at 32 clips x 8 frames of 112 x 112, 7.9 TB/s of L2 -> LDS, 1.44 ms -- and half of each row is the
+// zero padding 32 -> 64 channels.  Here a workgroup of 8 waves walks the frames of one (clip, 2-row slab):
+//   * a frame slab = 4 rows x (W + 2) pixels x the 32 REAL channels (64 B per pixel) arrives by LDS-DMA straight from the
+//     time-major NHWC map (first half of its 128-byte rows), once per slab (2x with the row halo), into a ring of four
+//     (frames t - 1, t, t + 1 in use, frame t + 2 landing under the MFMAs of frame t), ONE barrier per frame;
+//   * a tap (kt, kh, kw) is a byte offset into the ring: the B fragment of 16 pixels is one ds_read_b128 per lane;
+//   * wave (n, half) owns output channels 16 n .. 16 n + 15 and every second block of 16 pixels; its 27 filter fragments
+//     (108 VGPRs) stay in registers for the whole walk, so the K loop is one LDS read + one MFMA per tap, two pixel blocks
+//     interleaved; frames outside the clip are skipped (no MFMA work on padding frames);
+//   * epilogue: bias-free accumulator + BatchNorm3d partial sums (train) or scale / shift / ReLU (eval), 8-byte stores.
+// Bound: LDS reads (one 1 KB fragment read per MFMA, 4 SIMDs share 128 B/clk: at most 50 % of the matrix pipe).
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "qt_common.h"
+
+namespace {
+
+constexpr int S3_R = 2;        // output rows per slab
+constexpr int S3_RING = 4;     // frames t - 1, t, t + 1 under the MFMAs + frame t + 2 landing
+
+struct S3Args {
+  const bf16_t* x;        // [T][B][H][W][xc], channels 0..31 read
+  const bf16_t* w;        // [64][27][64]: element tap * 64 + c (qt_pack_conv3d_block), c < 32 read
+  bf16_t* y;              // [T][B][H][W][64]
+  const float* scale;     // nullable: y = conv * scale + shift (+ ReLU)
+  const float* shift;
+  float* stats;           // [gridDim.x][2][64] or NULL
+  int relu, B, T, H, W, xc, items;
+};
+
+template <bool AFF, bool STATS>
+__global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nb = wave & 3, half = wave >> 2;
+  const int W = p.W, H = p.H, T = p.T;
+  const int rowb = (W + 2) * 64, slab = (S3_R + 2) * rowb;
+  const unsigned smem_base = lds_addr_of(smem);
+
+  for (int i = tid * 16; i < S3_RING * slab; i += 512 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  // filter fragments (A operand): row li = output channel 16 nb + li, k-group lg = input channels 8 lg .. 8 lg + 7 of the tap
+  uint4 wf[27];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+    wf[tap] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(nb * 16 + li) * 27 + tap) * 64 + lg * 8);
+
+  float sc[4], sh[4], s1[4], s2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ch = nb * 16 + lg * 4 + r;
+    sc[r] = AFF ? p.scale[ch] : 1.f;
+    sh[r] = AFF ? p.shift[ch] : 0.f;
+    s1[r] = s2[r] = 0.f;
+  }
+
+  const int nbw = W >> 4;                    // blocks of 16 pixels per row
+  const int ndma = (S3_R + 2) * nbw;         // 1 KB DMA instructions per frame slab
+  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(qt_zero_page) + (lane & 7) * 16;
+  // frame f of (clip b, rows h0 - 1 .. h0 + S3_R) -> ring slot f % 4; instruction j = (slab row, block of 16 pixels)
+  auto dma_frame = [&](int b, int f, int h0) {
+    const unsigned dst0 = smem_base + (unsigned)(f % S3_RING) * slab + 64;   // pixel 0 of a slab row is the left halo
+    for (int j = wave; j < ndma; j += 8) {
+      const int r = j / nbw, blk = j - r * nbw;
+      const int hh = h0 - 1 + r;
+      const unsigned char* src =
+          (unsigned)hh < (unsigned)H
+              ? reinterpret_cast<const unsigned char*>(p.x + ((((size_t)f * p.B + b) * H + hh) * W + blk * 16 + (lane >> 2)) * p.xc) +
+                    (lane & 3) * 16
+              : zero_src;
+      glds16(src, dst0 + (unsigned)r * rowb + (unsigned)blk * 1024);
+    }
+  };
+
+  const int slabs_per_img = H / S3_R, nmb = S3_R * nbw;
+  __syncthreads();   // the zero fill (halo columns) is complete before any DMA lands
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item / slabs_per_img, h0 = (item - b * slabs_per_img) * S3_R;
+    // (every wave passed the barrier after the previous item's last frame: the ring is free)
+    dma_frame(b, 0, h0);
+    if (T > 1) dma_frame(b, 1, h0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      if (t + 2 < T) dma_frame(b, t + 2, h0);   // into the slot of frame t - 2, which every wave finished before the last barrier
+
+      const int kt_lo = t == 0 ? 1 : 0, kt_hi = t + 1 < T ? 2 : 1;
+      for (int mb = half; mb < nmb; mb += 4) {   // two pixel blocks (mb, mb + 2) interleaved
+        const int mb1 = mb + 2;
+        const bool two = mb1 < nmb;
+        const int r0 = mb / nbw, c0 = mb - r0 * nbw;
+        const int r1 = two ? mb1 / nbw : r0, c1 = two ? mb1 - r1 * nbw : c0;
+        const unsigned char* a0 = smem + r0 * rowb + (c0 * 16 + li) * 64 + lg * 16;
+        const unsigned char* a1 = smem + r1 * rowb + (c1 * 16 + li) * 64 + lg * 16;
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {   // (unrolled: the filter fragments are registers; frames outside the clip: a uniform skip)
+          if (kt < kt_lo || kt > kt_hi) continue;
+          const int so = ((t + kt + S3_RING - 1) % S3_RING) * slab;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int off = so + kh * rowb + kw * 64;
+              const uint4 x0 = *reinterpret_cast<const uint4*>(a0 + off);
+              const uint4 x1 = *reinterpret_cast<const uint4*>(a1 + off);
+              const uint4 wk = wf[(kt * 3 + kh) * 3 + kw];
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk), __builtin_bit_cast(bf16x8, x0), acc0, 0,
+                                                             0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk), __builtin_bit_cast(bf16x8, x1), acc1, 0,
+                                                             0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+          const f32x4 acc = u ? acc1 : acc0;
+          const int rr = u ? r1 : r0, cc = u ? c1 : c0;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = acc[r];
+            if (STATS) {
+              s1[r] += a;
+              s2[r] += a * a;
+            }
+            v[r] = a;
+            if (AFF) {
+              v[r] = a * sc[r] + sh[r];
+              if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(p.y + ((((size_t)t * p.B + b) * H + h0 + rr) * W + cc * 16 + li) * 64 + nb * 16 + lg * 4) = o;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of frame t + 2 has landed
+      __syncthreads();                                     // ... everyone's has, and everyone is done with output frame t
+    }
+  }
+
+  if (STATS) {
+    // 16 lanes of a row hold 16 pixels of the same 4 channels; the two waves of a channel block through LDS, fixed order
+    float* red = reinterpret_cast<float*>(smem);   // [2 halves][2][64]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a1 = qt_row16_sum(s1[r]), a2 = qt_row16_sum(s2[r]);
+      if (li == 0) {
+        red[(half * 2 + 0) * 64 + nb * 16 + lg * 4 + r] = a1;
+        red[(half * 2 + 1) * 64 + nb * 16 + lg * 4 + r] = a2;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, ch = tid & 63;
+      p.stats[((size_t)blockIdx.x * 2 + which) * 64 + ch] = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch];
+    }
+  }
+}
+
+int s3_grid(int items) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+    }
+    return n;
+  }();
+  return items < cus ? items : cus;
+}
+
+bool s3_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("QTCNN_CONV3D_SLAB");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+bool s3_shape_ok(int batch, int frames, int h, int w) {
+  return s3_enabled() && batch > 0 && frames > 0 && h >= S3_R && h % S3_R == 0 && w >= 16 && w % 16 == 0 && w <= 128;
+}
+
+}  // namespace
+
+// rows of BatchNorm partial sums qt_conv3d_c32_fwd writes ([rows][2][64]); 0 = shape not covered (take qt_conv2d_igemm)
+extern "C" int qt_conv3d_c32_stats_rows(int batch, int frames, int h, int w) {
+  return s3_shape_ok(batch, frames, h, w) ? s3_grid(batch * (h / S3_R)) : 0;
+}
+
+extern "C" int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const void* w_packed, void* y, const float* scale,
+                                 const float* shift, int relu, float* stats, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(x && w_packed && y && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_conv3d_c32_fwd: bad argument");
+  QT_CHECK_ARG(x_channels >= 32 && x_channels % 8 == 0, "qt_conv3d_c32_fwd: x rows of %d channels", x_channels);
+  QT_CHECK_ARG(!(scale && stats), "qt_conv3d_c32_fwd: scale / shift and statistics are exclusive");
+  QT_CHECK_ARG(!scale || shift, "qt_conv3d_c32_fwd: scale without shift");
+  if (dtype != QT_BF16 || !s3_shape_ok(batch, frames, h, w) || ((uintptr_t)x % 16) != 0 || ((uintptr_t)w_packed % 16) != 0) {
+    qt_set_error("qt_conv3d_c32_fwd: bf16, H %% 2 == 0, W %% 16 == 0, W <= 128, 16-byte aligned operands only (use qt_conv2d_igemm "
+                 "with kt = 3)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  S3Args a;
+  a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)y; a.scale = scale; a.shift = shift; a.stats = stats;
+  a.relu = relu; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = x_channels; a.items = batch * (h / S3_R);
+  int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
+  if (lds < 2 * 2 * 64 * 4) lds = 2 * 2 * 64 * 4;
+  const dim3 grid(s3_grid(a.items)), blk(512);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = QT_OK;
+  if (scale) {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<true, false>, lds, done)) != QT_OK) return rc;
+    hipLaunchKernelGGL((conv3d_c32_kernel<true, false>), grid, blk, lds, s, a);
+  } else if (stats) {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, true>, lds, done)) != QT_OK) return rc;
+    hipLaunchKernelGGL((conv3d_c32_kernel<false, true>), grid, blk, lds, s, a);
+  } else {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, false>, lds, done)) != QT_OK) return rc;
+    hipLaunchKernelGGL((conv3d_c32_kernel<false, false>), grid, blk, lds, s, a);
+  }
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}

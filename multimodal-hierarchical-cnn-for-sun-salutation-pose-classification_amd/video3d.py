@@ -183,6 +183,17 @@ class _Ops:
             ev[1].record()
             self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_FWD)))
 
+    def conv3d_c32(self, dt, x, xc, wf, y, B, T, H, W, scale=None, shift=None, relu=0, stats=None, flops=0.0, nbytes=0.0):
+        ev = None
+        if self.timed is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self.check(self.L.qt_conv3d_c32_fwd(_lib.qt_dtype(dt), _ptr(x), xc, _ptr(wf), _ptr(y), _ptr(scale), _ptr(shift), relu, _ptr(stats),
+                                            B, T, H, W, _lib.stream_ptr()), "qt_conv3d_c32_fwd")
+        if ev is not None:
+            ev[1].record()
+            self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_FWD)))
+
     def pool(self, dt, x, out, arg, T, B, H, W, C, pt):
         self.check(self.L.qt_pool3d_max(_lib.qt_dtype(dt), _ptr(x), _ptr(out), _ptr(arg), T, B, H, W, C, pt,
                                         _lib.stream_ptr()), "qt_pool3d_max")
@@ -246,6 +257,8 @@ FUSED_POOL = os.environ.get("QTCNN_POOL3D_FUSED", "1") != "0"
 # QTCNN_LSTM_SIDE_STREAM (default 1): Quadtree3DCNN's LSTM branch (a dozen latency-bound launches of 32 workgroups, 0.3 ms
 # forward and 0.25 ms backward in a row) runs on a second stream beside the conv blocks, which it does not depend on
 LSTM_SIDE = os.environ.get("QTCNN_LSTM_SIDE_STREAM", "1") != "0"
+# QTCNN_CONV3D_SLAB (default 1): conv3d_block2's forward on the slab-resident kernel (csrc/conv3d_slab.hip); 0: 27-tap implicit GEMM
+SLAB_C32 = os.environ.get("QTCNN_CONV3D_SLAB", "1") != "0"
 _side_streams = {}
 
 
@@ -386,13 +399,27 @@ class _ConvBlock:
         fl = 2.0 * rows * 27 * self.cin * self.cout            # algorithmic: the Conv3d as the reference computes it
         nb = esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p)
         tk = dict(flops=fl, nbytes=nb)
+        # conv3d_block2 (32 -> 64 channels) with its frame slabs resident in LDS (csrc/conv3d_slab.hip) where the shape fits:
+        # slab = its partial-sum rows, 0 = the 27-tap implicit GEMM
+        slab = 0
+        if (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
+                and x.data_ptr() % 16 == 0):
+            slab = o.L.qt_conv3d_c32_stats_rows(B, T, H, W)
+        if slab:
+            tk = dict(flops=fl, nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
+
+            def conv(**kw):
+                o.conv3d_c32(dt, x, self.cin_p, self.wf, y, B, T, H, W, **kw, **tk)
+        else:
+            def conv(**kw):
+                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), **kw, **tk)
         if training:
-            prow = o.L.qt_conv2d_stats_rows(_c.byref(d))
+            prow = slab or o.L.qt_conv2d_stats_rows(_c.byref(d))
             part = torch.empty(o.L.qt_stats_capacity_rows(prow), 2, self.cout_p, dtype=torch.float32, device=dev)
             # Under batch statistics BatchNorm3d(conv + bias) = BatchNorm3d(conv): a per-channel constant moves the mean with it.
             # y holds the bias-free accumulator and the epilogue's statistics are of exactly that value; the bias only enters
             # the running mean the reference tracks (mean of conv + bias), added below.
-            o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), stats=part, **tk)
+            conv(stats=part)
             stats = o.bn_finalize(part, prow, rows, self.cout_p, self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p,
                                   self.bn.num_batches_tracked, dev)
             self.rmean_p.add_(self.bias_p, alpha=BN_MOMENTUM)
@@ -402,9 +429,11 @@ class _ConvBlock:
             stats = o.bn_eval(self.gamma_p, self.beta_p, self.rmean_p, self.rvar_p, self.cout_p, dev)
             if fused_eval:   # relu(scale * (conv + bias) + shift)
                 shift = torch.addcmul(stats[3], stats[2], self.bias_p)
-                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), scale=stats[2], shift=shift, relu=1, **tk)
+                conv(scale=stats[2], shift=shift, relu=1)
+            elif slab:   # (its epilogue has no shift-only form: conv * 1 + bias)
+                conv(scale=torch.ones_like(self.bias_p), shift=self.bias_p)
             else:
-                o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), shift=self.bias_p, **tk)
+                conv(shift=self.bias_p)
         ymax = None
         if self.pool_t and not fused_eval and FUSED_POOL:
             # BatchNorm3d + ReLU + MaxPool3d in one pass: relu(bn(y)) is read by nothing but the pool (the next block takes the

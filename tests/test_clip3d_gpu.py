@@ -318,6 +318,54 @@ def test_first_conv3d_from_the_f32_clip(cfg):
     assert lib.qt_conv3d_first_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_first_stats_rows(B, T, H + 2, W) == 0
 
 
+@pytest.mark.parametrize("cfg", [(2, 8, 16, 32, 64), (3, 1, 8, 16, 64), (1, 5, 12, 64, 32), (2, 3, 4, 112, 64), (1, 2, 8, 128, 64)])
+def test_second_conv3d_with_frame_slabs_in_lds(cfg):
+    """conv3d_block2's nn.Conv3d(32, 64, 3x3x3, padding 1) (/root/reference/3dcnn/models.py:115) on the slab-resident kernel
+    (qt_conv3d_c32_fwd): against torch CPU fp32 conv3d on the bf16-rounded operands.  T = 1, odd T, T = 2 (ring of three
+    with two frames), one slab per image, the widest rows it takes, 32- and 64-channel input rows (the padding channels are
+    never read: they hold garbage here); BatchNorm3d partial sums; the scale / shift / ReLU form; refused shapes."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    B, T, H, W, xc = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, 32, T, H, W, generator=g).to(dt).float()
+    w = (torch.randn(64, 32, 3, 3, 3, generator=g) * (2.0 / (32 * 27)) ** 0.5).to(dt).float()
+    ref = F.conv3d(x, w, None, 1, 1).permute(2, 0, 3, 4, 1).contiguous()            # [T][B][H][W][64]
+    xd = torch.full((T, B, H, W, xc), 3.0, dtype=dt)                                  # garbage in the padding channels
+    xd[..., :32] = x.permute(2, 0, 3, 4, 1).to(dt)
+    xd = xd.to(dev)
+    wp = torch.full((64, 27, 64), 3.0, dtype=dt)                                      # [O][tap][I padded]: garbage in the padding
+    wp[:, :, :32] = w.permute(0, 2, 3, 4, 1).reshape(64, 27, 32).to(dt)
+    wp = wp.to(dev)
+    rows = lib.qt_conv3d_c32_stats_rows(B, T, H, W)
+    assert rows > 0
+    y = torch.full((T, B, H, W, 64), float("nan"), dtype=dt, device=dev)
+    part = torch.full((rows, 2, 64), float("nan"), device=dev)
+    L.check(lib.qt_conv3d_c32_fwd(L.qt_dtype(dt), L.ptr(xd), xc, L.ptr(wp), L.ptr(y), None, None, 0, L.ptr(part), B, T, H, W,
+                                  L.stream_ptr()), "qt_conv3d_c32_fwd")
+    torch.cuda.synchronize()
+    assert rel_err(y.float().cpu(), ref) <= 1e-2
+    sums = part.sum(0).cpu()
+    rd = ref.double().reshape(-1, 64)
+    assert rel_err(sums[0], rd.sum(0)) <= 1e-4 and rel_err(sums[1], (rd * rd).sum(0)) <= 1e-4
+    y2 = torch.empty_like(y)
+    L.check(lib.qt_conv3d_c32_fwd(L.qt_dtype(dt), L.ptr(xd), xc, L.ptr(wp), L.ptr(y2), None, None, 0, None, B, T, H, W,
+                                  L.stream_ptr()), "plain")
+    sc = (torch.rand(64, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(64, generator=g) * 0.3).to(dev)
+    y3 = torch.empty_like(y)
+    L.check(lib.qt_conv3d_c32_fwd(L.qt_dtype(dt), L.ptr(xd), xc, L.ptr(wp), L.ptr(y3), L.ptr(sc), L.ptr(sh), 1, None, B, T, H, W,
+                                  L.stream_ptr()), "affine")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    assert rel_err(y3.float().cpu(), torch.relu(ref * sc.cpu() + sh.cpu())) <= 1e-2
+    assert lib.qt_conv3d_c32_fwd(L.QT_F32, L.ptr(xd), xc, L.ptr(wp), L.ptr(y), None, None, 0, None, B, T, H, W, L.stream_ptr()) == -3
+    assert lib.qt_conv3d_c32_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_c32_stats_rows(B, T, H + 1, W) == 0
+    assert lib.qt_conv3d_c32_stats_rows(B, T, H, 144) == 0
+
+
 CASES = [("q3_t8", 2, 8, 112, "quadtree_3d_fusion", 31), ("q3_t5", 2, 5, 64, "quadtree_3d_fusion", 31),
          ("q3_img_t8", 2, 8, 64, "quadtree_3d_image_only", 31), ("ji_t4", 2, 4, 64, None, 32)]
 
