@@ -522,6 +522,13 @@ int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w);
 int qt_conv3d_c32_stats_rows(int batch, int frames, int h, int w);
 int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const void* w_packed, void* y, const float* scale,
                       const float* shift, int relu, float* stats, int batch, int frames, int h, int w, void* stream);
+/* ... and its data gradient: dx [T][B][H][W][64] (channels 0..31 = d(loss)/d(input), 32..63 zero) from dy
+ * [T][B][H][W][64] and qt_pack_conv3d_block's data-gradient filter [64][27][64] ([input channel][tap][output channel]): the
+ * same slab walk over dy with the flipped filter, as two launches over dy's channel halves joined through an f32 scratch
+ * (qt_conv3d_c32_dgrad_scratch_bytes; 0 = shape not covered, take qt_conv2d_igemm in QT_CONV_DGRAD mode). */
+size_t qt_conv3d_c32_dgrad_scratch_bytes(int batch, int frames, int h, int w);
+int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, void* scratch, size_t scratch_bytes,
+                        int batch, int frames, int h, int w, void* stream);
 /* Eval forward of the whole conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv
  * bias folded into shift) + ReLU + MaxPool3d((1,2,2)) in registers; pooled [T][B][H/2][W/2][64] with channels 32..63 zero (the
  * K rows block 2 reads); the conv map never reaches memory.  Same values as qt_conv3d_first_fwd(scale, shift, relu) followed by

@@ -32,16 +32,24 @@ struct S3Args {
   const float* scale;     // nullable: y = conv * scale + shift (+ ReLU)
   const float* shift;
   float* stats;           // [gridDim.x][2][64] or NULL
+  float* scratch;         // data gradient: f32 [T][B][H][W][32] partial sums between its two passes
   int relu, B, T, H, W, xc, items;
+  int coff;               // first of the 32 channels of x (and of the filter's K rows) this launch reads
 };
 
-template <bool AFF, bool STATS>
+// NB = 16-channel output blocks (4: the forward's 64 channels; 2: the data gradient's 32 input channels, waves (block, quarter
+// of the pixel blocks)).  FLIP: tap (kt, kh, kw) multiplies filter tap 26 - index (the data gradient is the same walk over dy
+// with the flipped filter [I][27][O]).  OUT: 0 = bf16 rows of 64 (NB * 16 channels written); 1 = f32 partial sums to
+// scratch; 2 = scratch + accumulator -> bf16 rows of 64, channels 32..63 zero.  The data gradient contracts over 64 channels =
+// two launches of 32 (coff 0 / 32: an LDS ring of 64-channel slabs would need 233 KB), joined through the f32 scratch.
+template <bool AFF, bool STATS, int NB = 4, bool FLIP = false, int OUT = 0>
 __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int nb = wave & 3, half = wave >> 2;
+  constexpr int PARTS = 8 / NB;              // waves that share a channel block split the pixel blocks
+  const int nb = wave % NB, half = wave / NB;
   const int W = p.W, H = p.H, T = p.T;
   const int rowb = (W + 2) * 64, slab = (S3_R + 2) * rowb;
   const unsigned smem_base = lds_addr_of(smem);
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
   uint4 wf[27];
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap)
-    wf[tap] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(nb * 16 + li) * 27 + tap) * 64 + lg * 8);
+    wf[tap] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(nb * 16 + li) * 27 + (FLIP ? 26 - tap : tap)) * 64 + p.coff + lg * 8);
 
   float sc[4], sh[4], s1[4], s2[4];
 #pragma unroll
@@ -74,7 +82,8 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
       const int hh = h0 - 1 + r;
       const unsigned char* src =
           (unsigned)hh < (unsigned)H
-              ? reinterpret_cast<const unsigned char*>(p.x + ((((size_t)f * p.B + b) * H + hh) * W + blk * 16 + (lane >> 2)) * p.xc) +
+              ? reinterpret_cast<const unsigned char*>(p.x + ((((size_t)f * p.B + b) * H + hh) * W + blk * 16 + (lane >> 2)) * p.xc +
+                                                       p.coff) +
                     (lane & 3) * 16
               : zero_src;
       glds16(src, dst0 + (unsigned)r * rowb + (unsigned)blk * 1024);
@@ -94,8 +103,8 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
       if (t + 2 < T) dma_frame(b, t + 2, h0);   // into the slot of frame t - 2, which every wave finished before the last barrier
 
       const int kt_lo = t == 0 ? 1 : 0, kt_hi = t + 1 < T ? 2 : 1;
-      for (int mb = half; mb < nmb; mb += 4) {   // two pixel blocks (mb, mb + 2) interleaved
-        const int mb1 = mb + 2;
+      for (int mb = half; mb < nmb; mb += 2 * PARTS) {   // two pixel blocks (mb, mb + PARTS) interleaved
+        const int mb1 = mb + PARTS;
         const bool two = mb1 < nmb;
         const int r0 = mb / nbw, c0 = mb - r0 * nbw;
         const int r1 = two ? mb1 / nbw : r0, c1 = two ? mb1 - r1 * nbw : c0;
@@ -139,10 +148,20 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
               if (p.relu) v[r] = fmaxf(v[r], 0.f);
             }
           }
+          const size_t pos = (((size_t)t * p.B + b) * H + h0 + rr) * W + cc * 16 + li;
+          if (OUT == 1) {
+            *reinterpret_cast<float4*>(p.scratch + pos * 32 + nb * 16 + lg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            continue;
+          }
+          if (OUT == 2) {
+            const float4 q = *reinterpret_cast<const float4*>(p.scratch + pos * 32 + nb * 16 + lg * 4);
+            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+          }
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          *reinterpret_cast<bf16x4*>(p.y + ((((size_t)t * p.B + b) * H + h0 + rr) * W + cc * 16 + li) * 64 + nb * 16 + lg * 4) = o;
+          *reinterpret_cast<bf16x4*>(p.y + pos * 64 + nb * 16 + lg * 4) = o;
+          if (OUT == 2) *reinterpret_cast<uint2*>(p.y + pos * 64 + 32 + nb * 16 + lg * 4) = make_uint2(0u, 0u);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of frame t + 2 has landed
@@ -151,6 +170,7 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
   }
 
   if (STATS) {
+    static_assert(!STATS || NB == 4, "statistics: the forward form");
     // 16 lanes of a row hold 16 pixels of the same 4 channels; the two waves of a channel block through LDS, fixed order
     float* red = reinterpret_cast<float*>(smem);   // [2 halves][2][64]
 #pragma unroll
@@ -214,6 +234,7 @@ extern "C" int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const
   S3Args a;
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)y; a.scale = scale; a.shift = shift; a.stats = stats;
   a.relu = relu; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = x_channels; a.items = batch * (h / S3_R);
+  a.scratch = nullptr; a.coff = 0;
   int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
   if (lds < 2 * 2 * 64 * 4) lds = 2 * 2 * 64 * 4;
   const dim3 grid(s3_grid(a.items)), blk(512);
@@ -233,5 +254,48 @@ extern "C" int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const
     hipLaunchKernelGGL((conv3d_c32_kernel<false, false>), grid, blk, lds, s, a);
   }
   QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
+// Data gradient of the same layer: dx [T][B][H][W][64] (channels 0..31 = d(loss)/d(input), 32..63 zero) from
+// dy [T][B][H][W][64] and qt_pack_conv3d_block's data-gradient filter [64][27][64] ([input channel][tap][output channel]).
+// Two launches of the slab kernel over dy's channels 0..31 / 32..63 joined through `scratch` (f32 [positions][32]).
+extern "C" size_t qt_conv3d_c32_dgrad_scratch_bytes(int batch, int frames, int h, int w) {
+  return s3_shape_ok(batch, frames, h, w) ? (size_t)frames * batch * h * w * 32 * sizeof(float) : 0;
+}
+
+extern "C" int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, void* scratch,
+                                   size_t scratch_bytes, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(dy && w_dgrad_packed && dx && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_conv3d_c32_dgrad: bad argument");
+  const size_t need = qt_conv3d_c32_dgrad_scratch_bytes(batch, frames, h, w);
+  if (dtype != QT_BF16 || need == 0 || ((uintptr_t)dy % 16) != 0 || ((uintptr_t)w_dgrad_packed % 16) != 0 || ((uintptr_t)dx % 16) != 0) {
+    qt_set_error("qt_conv3d_c32_dgrad: bf16, even H, W %% 16 == 0, W <= 128, 16-byte aligned operands only (use qt_conv2d_igemm "
+                 "with kt = 3, mode QT_CONV_DGRAD)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  QT_CHECK_ARG(scratch && scratch_bytes >= need && ((uintptr_t)scratch % 16) == 0,
+               "qt_conv3d_c32_dgrad: scratch of %zu bytes, %zu needed", scratch_bytes, need);
+  S3Args a;
+  a.x = (const bf16_t*)dy; a.w = (const bf16_t*)w_dgrad_packed; a.y = (bf16_t*)dx; a.scale = nullptr; a.shift = nullptr;
+  a.stats = nullptr; a.scratch = (float*)scratch;
+  a.relu = 0; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = 64; a.items = batch * (h / S3_R);
+  const int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
+  const dim3 grid(s3_grid(a.items)), blk(512);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = QT_OK;
+  {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, false, 2, true, 1>, lds, done)) != QT_OK) return rc;
+    a.coff = 0;
+    hipLaunchKernelGGL((conv3d_c32_kernel<false, false, 2, true, 1>), grid, blk, lds, s, a);
+    QT_CHECK_LAUNCH();
+  }
+  {
+    static std::atomic<unsigned long long> done{0};
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, false, 2, true, 2>, lds, done)) != QT_OK) return rc;
+    a.coff = 32;
+    hipLaunchKernelGGL((conv3d_c32_kernel<false, false, 2, true, 2>), grid, blk, lds, s, a);
+    QT_CHECK_LAUNCH();
+  }
   return QT_OK;
 }

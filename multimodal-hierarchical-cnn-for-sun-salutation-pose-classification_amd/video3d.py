@@ -194,6 +194,17 @@ class _Ops:
             ev[1].record()
             self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_FWD)))
 
+    def conv3d_c32_dgrad(self, dt, dy, wd, dx, scr, nscr, B, T, H, W, flops=0.0, nbytes=0.0):
+        ev = None
+        if self.timed is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self.check(self.L.qt_conv3d_c32_dgrad(_lib.qt_dtype(dt), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(scr), _c.c_size_t(nscr), B, T, H, W,
+                                              _lib.stream_ptr()), "qt_conv3d_c32_dgrad")
+        if ev is not None:
+            ev[1].record()
+            self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_DGRAD)))
+
     def pool(self, dt, x, out, arg, T, B, H, W, C, pt):
         self.check(self.L.qt_pool3d_max(_lib.qt_dtype(dt), _ptr(x), _ptr(out), _ptr(arg), T, B, H, W, C, pt,
                                         _lib.stream_ptr()), "qt_pool3d_max")
@@ -524,11 +535,21 @@ class _ConvBlock:
                     continue
                 d2 = o_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
                 o.wgrad(d2, _ptr(dy, dlo * frame_out), _ptr(x, slo * frame_in), dw[kt])
-            # data gradient: one 27-tap launch
+            # data gradient: one 27-tap launch; conv3d_block2's on the slab-resident kernel (two passes over dy's channel halves)
             dd = self._desc(dt, _lib.QT_CONV_DGRAD, T, B, H, W)
             dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
-            o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx), flops=2.0 * rows * 27 * self.cin * self.cout,
-                    nbytes=esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p))
+            nscr = 0
+            if (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
+                    and dy.data_ptr() % 16 == 0):
+                o.L.qt_conv3d_c32_dgrad_scratch_bytes.restype = _c.c_size_t
+                nscr = int(o.L.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
+            if nscr:
+                scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
+                o.conv3d_c32_dgrad(dt, dy, self.wd, dx, scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
+                                   nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
+            else:
+                o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx), flops=2.0 * rows * 27 * self.cin * self.cout,
+                        nbytes=esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p))
         o.check(o.L.qt_unpack_conv3d_wgrad(_ptr(dw), _ptr(dW), self.cout, self.cin, self.cout_p, self.cin_p,
                                            1 if self.first else 0, _lib.stream_ptr()), "qt_unpack_conv3d_wgrad")
         return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()

@@ -361,6 +361,23 @@ def test_second_conv3d_with_frame_slabs_in_lds(cfg):
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
     assert rel_err(y3.float().cpu(), torch.relu(ref * sc.cpu() + sh.cpu())) <= 1e-2
+    # the data gradient: the same walk over dy with the flipped filter [I][27][O], two passes joined through an f32 scratch
+    dyt = torch.randn(T, B, H, W, 64, generator=g).to(dt)
+    xr = x.clone().requires_grad_(True)
+    F.conv3d(xr, w, None, 1, 1).backward(dyt.float().permute(1, 4, 0, 2, 3))
+    wdp = torch.full((64, 27, 64), 3.0, dtype=dt)                                     # rows 32..63 (padding input channels): garbage
+    wdp[:32] = w.permute(1, 2, 3, 4, 0).reshape(32, 27, 64).to(dt)
+    wdp = wdp.to(dev)
+    lib.qt_conv3d_c32_dgrad_scratch_bytes.restype = ctypes.c_size_t
+    nscr = int(lib.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
+    assert nscr == T * B * H * W * 32 * 4
+    scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
+    dx = torch.full((T, B, H, W, 64), float("nan"), dtype=dt, device=dev)
+    L.check(lib.qt_conv3d_c32_dgrad(L.qt_dtype(dt), L.ptr(dyt.to(dev)), L.ptr(wdp), L.ptr(dx), L.ptr(scr), ctypes.c_size_t(nscr), B, T,
+                                    H, W, L.stream_ptr()), "qt_conv3d_c32_dgrad")
+    torch.cuda.synchronize()
+    assert rel_err(dx[..., :32].float().cpu(), xr.grad.permute(2, 0, 3, 4, 1)) <= 1e-2
+    assert (dx[..., 32:] == 0).all()
     assert lib.qt_conv3d_c32_fwd(L.QT_F32, L.ptr(xd), xc, L.ptr(wp), L.ptr(y), None, None, 0, None, B, T, H, W, L.stream_ptr()) == -3
     assert lib.qt_conv3d_c32_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_c32_stats_rows(B, T, H + 1, W) == 0
     assert lib.qt_conv3d_c32_stats_rows(B, T, H, 144) == 0
