@@ -509,15 +509,15 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             per = {}
-            for mode, nm in ((0, "forward Conv3d launches (conv_igemm_kernel, 27 taps; block 1: conv3d_first_kernel from the f32 clip)"),
-                             (1, "data-gradient Conv3d launches (conv_igemm_kernel, 27 taps)")):
+            for mode, nm in ((0, "forward Conv3d launches (block 1: conv3d_first_kernel from the f32 clip; block 2: conv3d_c32_kernel, slab-resident; blocks 3-5: conv_igemm_kernel, 27 taps)"),
+                             (1, "data-gradient Conv3d launches (block 2: conv3d_c32_kernel, slab-resident, two passes; blocks 3-5: conv_igemm_kernel, 27 taps)")):
                 sel = [r for r in recs if r[4] == mode]
                 if sel:
                     msk = sum(a.elapsed_time(b) for a, b, _, _, _ in sel)
                     per[nm] = {"launches_per_step": len(sel) // args.profile_steps, "avg_us": round(1e3 * msk / len(sel), 1),
                                "tflops": round(sum(r[2] for r in sel) / (msk * 1e-3) / 1e12, 1),
                                "algorithmic_mb_per_launch": round(sum(r[3] for r in sel) / len(sel) / 1e6, 1)}
-            roofline = {"kernel": "Conv3d launches of the step (one 27-tap implicit GEMM per convolution and direction; block 1 from the f32 clip)",
+            roofline = {"kernel": "Conv3d launches of the step (blocks 3-5: one 27-tap implicit GEMM per convolution and direction; block 1 from the f32 clip; block 2 slab-resident)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": None, "traffic_source": "no PMC pass collected for this model",
                         "algorithmic_bytes_per_launch": round(tot_by / len(recs)), "avg_launch_us": round(1e3 * tot_ms / len(recs), 1),
