@@ -529,6 +529,13 @@ int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const void* w_pa
 size_t qt_conv3d_c32_dgrad_scratch_bytes(int batch, int frames, int h, int w);
 int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, void* scratch, size_t scratch_bytes,
                         int batch, int frames, int h, int w, void* stream);
+/* ... and its weight gradient: dweight [64][32][3][3][3] f32 in nn.Conv3d's layout (every element written) from x (channels
+ * 0..31 of x_channels-wide rows) and dy [T][B][H][W][64]; the contraction runs over positions with both operands read
+ * through transposing LDS reads; per-workgroup partial filters in `workspace` (qt_conv3d_c32_wgrad_workspace_bytes; 0 = shape
+ * not covered, take qt_conv2d_wgrad per frame tap) added in a fixed order: deterministic. */
+size_t qt_conv3d_c32_wgrad_workspace_bytes(int batch, int frames, int h, int w);
+int qt_conv3d_c32_wgrad(int dtype, const void* x, int x_channels, const void* dy, float* dweight, void* workspace,
+                        size_t workspace_bytes, int batch, int frames, int h, int w, void* stream);
 /* Eval forward of the whole conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv
  * bias folded into shift) + ReLU + MaxPool3d((1,2,2)) in registers; pooled [T][B][H/2][W/2][64] with channels 32..63 zero (the
  * K rows block 2 reads); the conv map never reaches memory.  Same values as qt_conv3d_first_fwd(scale, shift, relu) followed by

@@ -189,6 +189,170 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
   }
 }
 
+// ---- weight gradient of the same layer ------------------------------------------------------------------------------------
+//   dW[co][ci][kt][kh][kw] = sum over positions of dy[pos][co] * x[pos + tap][ci]
+// Same walk, the same ring of 32-channel x slabs.  The contraction runs over positions: MFMA k = a chunk of 32 consecutive
+// positions of the 2-row tile.  dy chunks (32 positions x 64 channels = 4 KB, contiguous in memory) stream through a shared
+// ring of six by LDS-DMA, three ahead, one barrier per chunk.  Both operands are position-major in LDS and come out k-major
+// through ds_read_b64_tr_b16 at per-lane addresses: dy as 16 output channels x 32 positions, x as 16 input channels x 32
+// positions at the tap's byte offset.  Wave (cb, ib) owns output channels 16 cb.., input channels 16 ib.. of ALL 27 taps:
+// 27 accumulator tiles (108 VGPRs), 56 transposing reads per 27 MFMAs -- LDS-read bound like the forward.  Partial filters
+// per workgroup, added in a fixed order straight into nn.Conv3d's [64][32][3][3][3] layout: deterministic, no atomics.
+// Measured 548 us at 32 clips x 8 frames of 112 x 112 (three launches of the tile kernel over 64-channel-padded rows: 720).
+// (Swapping the two 32-byte halves of a slab pixel on every second group of four pixels -- positions 4 apart are 256 B
+// apart -- measured 633 us: the extra per-tap address arithmetic costs more than any bank conflict it removes.)
+constexpr int S3W_NCH = 6, S3W_D = 3;
+constexpr int S3W_PART = 64 * 27 * 32;
+
+struct S3WArgs {
+  const bf16_t* x;        // [T][B][H][W][xc], channels 0..31
+  const bf16_t* dy;       // [T][B][H][W][64]
+  float* part;            // [gridDim.x][64][27][32]
+  int B, T, H, W, xc, items;
+};
+
+__global__ __launch_bounds__(512) void conv3d_c32_wgrad_kernel(S3WArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int lrow = 4 * lg + (li >> 2), pp = li & 3;
+  const int cb = wave & 3, ib = wave >> 2;
+  const int W = p.W, H = p.H, T = p.T;
+  const int rowb = (W + 2) * 64, slab = (S3_R + 2) * rowb;
+  const unsigned smem_base = lds_addr_of(smem);
+  const unsigned dyring = smem_base + S3_RING * slab;
+
+  for (int i = tid * 16; i < S3_RING * slab; i += 512 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) acc[tap] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nbw = W >> 4, ndma = (S3_R + 2) * nbw;
+  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(qt_zero_page) + (lane & 7) * 16;
+  auto dma_frame = [&](int b, int f, int h0) {
+    const unsigned dst0 = smem_base + (unsigned)(f % S3_RING) * slab + 64;
+    for (int j = wave; j < ndma; j += 8) {
+      const int r = j / nbw, blk = j - r * nbw;
+      const int hh = h0 - 1 + r;
+      const unsigned char* src =
+          (unsigned)hh < (unsigned)H
+              ? reinterpret_cast<const unsigned char*>(p.x + ((((size_t)f * p.B + b) * H + hh) * W + blk * 16 + (lane >> 2)) * p.xc) +
+                    (lane & 3) * 16
+              : zero_src;
+      glds16(src, dst0 + (unsigned)r * rowb + (unsigned)blk * 1024);
+    }
+  };
+
+  // dy chunk stream: (item, frame, chunk of 32 positions of the 2 x W tile); waves 0..3 move one KB each per chunk
+  const int slabs_per_img = H / S3_R, nck = (S3_R * W) >> 5;
+  int is_item = blockIdx.x, is_t = 0, is_c = 0, n_issued = 0, n_used = 0;
+  auto issue = [&]() {
+    if (is_item >= p.items) return;
+    if (wave < 4) {
+      const int b = is_item / slabs_per_img, h0 = (is_item - b * slabs_per_img) * S3_R;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(
+          p.dy + ((((size_t)is_t * p.B + b) * H + h0) * W + is_c * 32) * 64);
+      glds16(src + wave * 1024 + lane * 16, dyring + (unsigned)(n_issued % S3W_NCH) * 4096u + (unsigned)wave * 1024u);
+    }
+    ++n_issued;
+    if (++is_c == nck) {
+      is_c = 0;
+      if (++is_t == T) {
+        is_t = 0;
+        is_item += gridDim.x;
+      }
+    }
+  };
+
+  __syncthreads();   // the zero fill is complete before any DMA lands
+#pragma unroll
+  for (int d = 0; d < S3W_D; ++d) issue();
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item / slabs_per_img, h0 = (item - b * slabs_per_img) * S3_R;
+    dma_frame(b, 0, h0);
+    if (T > 1) dma_frame(b, 1, h0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      if (t + 2 < T) dma_frame(b, t + 2, h0);
+      const int kt_lo = t == 0 ? 1 : 0, kt_hi = t + 1 < T ? 2 : 1;
+      for (int c = 0; c < nck; ++c) {
+        issue();   // chunk n_used + S3W_D into the slot of chunk n_used - 3, which every wave finished before the last barrier
+        // positions lrow and lrow + 16 of the chunk -> (row, column) of the tile
+        const int p0 = c * 32 + lrow, p1 = p0 + 16;
+        const int r0 = p0 >= W ? 1 : 0, r1 = p1 >= W ? 1 : 0;      // (S3_R == 2)
+        const unsigned xo0 = (unsigned)(r0 * rowb + (p0 - r0 * W) * 64 + ib * 32 + pp * 8);
+        const unsigned xo1 = (unsigned)(r1 * rowb + (p1 - r1 * W) * 64 + ib * 32 + pp * 8);
+        const unsigned da = dyring + (unsigned)(n_used % S3W_NCH) * 4096u + lrow * 128 + cb * 32 + pp * 8;
+        ++n_used;
+        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)da);
+        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(da + 16 * 128));
+        const uint2 al = __builtin_bit_cast(uint2, alo), ah = __builtin_bit_cast(uint2, ahi);
+        const uint4 fa = make_uint4(al.x, al.y, ah.x, ah.y);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          if (kt < kt_lo || kt > kt_hi) continue;
+          const unsigned so = smem_base + (unsigned)(((t + kt + S3_RING - 1) % S3_RING) * slab);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const unsigned off = so + kh * rowb + kw * 64;
+              const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(off + xo0));
+              const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS_AS s16x4*)(size_t)(off + xo1));
+              const uint2 bl = __builtin_bit_cast(uint2, blo), bh = __builtin_bit_cast(uint2, bhi);
+              const uint4 fb = make_uint4(bl.x, bl.y, bh.x, bh.y);
+              acc[(kt * 3 + kh) * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[(kt * 3 + kh) * 3 + kw], 0, 0, 0);
+            }
+        }
+        // chunk n_used (next) was issued three iterations ago: at most this wave's two younger dy instructions (and whatever
+        // x slab instructions it issued since) may still be in flight; at a frame's end everything has to have landed
+        const int younger = n_issued - n_used - 1;   // dy chunks issued after the next one to be read
+        if (c + 1 < nck && younger >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (c + 1 < nck && younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+  }
+
+  // lane: output channels 16 cb + 4 lg + r, input channel 16 ib + li of every tap
+  float* out = p.part + (size_t)blockIdx.x * S3W_PART;
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[((cb * 16 + lg * 4 + r) * 27 + tap) * 32 + ib * 16 + li] = acc[tap][r];
+}
+
+// dW [64][32 ci][27 taps] (nn.Conv3d weight layout [co][ci][kt][kh][kw]) = sum over the workgroups' partial filters, ascending
+__global__ __launch_bounds__(256) void s3_wgrad_sum_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int o = blockIdx.x * 32 + col;     // (co, ci, tap)
+  float s = 0.f;
+  if (o < 64 * 32 * 27) {
+    const int co = o / (32 * 27), rem = o - co * (32 * 27);
+    const int ci = rem / 27, tap = rem - ci * 27;
+    const float* src = part + (co * 27 + tap) * 32 + ci;
+    const int per = (nparts + 7) / 8;
+    const int beg = sg * per, end = min(nparts, beg + per);
+#pragma unroll 8
+    for (int k = beg; k < end; ++k) s += src[(size_t)k * S3W_PART];
+  }
+  red[sg][col] = s;
+  __syncthreads();
+  if (sg == 0 && o < 64 * 32 * 27) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][col];
+    dw[o] = t;
+  }
+}
+
 int s3_grid(int items) {
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -297,5 +461,37 @@ extern "C" int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgra
     hipLaunchKernelGGL((conv3d_c32_kernel<false, false, 2, true, 2>), grid, blk, lds, s, a);
     QT_CHECK_LAUNCH();
   }
+  return QT_OK;
+}
+
+// Weight gradient of the same layer: dweight [64][32][3][3][3] f32 (nn.Conv3d's layout, every element written) from
+// x [T][B][H][W][x_channels] (channels 0..31) and dy [T][B][H][W][64]; per-workgroup partial filters in `workspace`.
+extern "C" size_t qt_conv3d_c32_wgrad_workspace_bytes(int batch, int frames, int h, int w) {
+  return s3_shape_ok(batch, frames, h, w) ? (size_t)s3_grid(batch * (h / S3_R)) * S3W_PART * sizeof(float) : 0;
+}
+
+extern "C" int qt_conv3d_c32_wgrad(int dtype, const void* x, int x_channels, const void* dy, float* dweight, void* workspace,
+                                   size_t workspace_bytes, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(x && dy && dweight && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_conv3d_c32_wgrad: bad argument");
+  QT_CHECK_ARG(x_channels >= 32 && x_channels % 8 == 0, "qt_conv3d_c32_wgrad: x rows of %d channels", x_channels);
+  const size_t need = qt_conv3d_c32_wgrad_workspace_bytes(batch, frames, h, w);
+  if (dtype != QT_BF16 || need == 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)dy % 16) != 0) {
+    qt_set_error("qt_conv3d_c32_wgrad: bf16, even H, W %% 16 == 0, W <= 128, 16-byte aligned operands only (use qt_conv2d_wgrad per "
+                 "frame tap)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  QT_CHECK_ARG(workspace && workspace_bytes >= need, "qt_conv3d_c32_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+  S3WArgs a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.part = (float*)workspace;
+  a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = x_channels; a.items = batch * (h / S3_R);
+  const int grid = s3_grid(a.items);
+  const int lds = S3_RING * (S3_R + 2) * (w + 2) * 64 + S3W_NCH * 4096;
+  static std::atomic<unsigned long long> done{0};
+  if (int rc = qt_raise_lds_limit((const void*)conv3d_c32_wgrad_kernel, lds, done)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(conv3d_c32_wgrad_kernel, dim3(grid), dim3(512), lds, s, a);
+  QT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(s3_wgrad_sum_kernel, dim3((64 * 32 * 27 + 31) / 32), dim3(256), 0, s, (const float*)workspace, dweight, grid);
+  QT_CHECK_LAUNCH();
   return QT_OK;
 }

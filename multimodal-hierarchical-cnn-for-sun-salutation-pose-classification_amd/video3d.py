@@ -353,6 +353,12 @@ class _ConvBlock:
         d.kt, d.frames = 3, T
         return d
 
+    @staticmethod
+    def _slab_wgrad_bytes(B, T, H, W):
+        L = ops().L
+        L.qt_conv3d_c32_wgrad_workspace_bytes.restype = _c.c_size_t
+        return int(L.qt_conv3d_c32_wgrad_workspace_bytes(B, T, H, W))
+
     def _raw_rows(self, dt, x, T, B, H, W):
         """the first layer from the f32 clip itself (csrc/conv3d_first.hip): partial-sum rows, 0 = take the packed form"""
         if not (self.first and FUSED_POOL and self.pool_t and dt == torch.bfloat16 and self.cin == 3 and self.cout == 32):
@@ -523,6 +529,20 @@ class _ConvBlock:
             d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
             dw = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
             o.wgrad(d, _ptr(dy), _ptr(x), dw)
+        elif (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
+              and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and self._slab_wgrad_bytes(B, T, H, W)):
+            # conv3d_block2: weight gradient and data gradient on the slab-resident kernels (csrc/conv3d_slab.hip)
+            nws = self._slab_wgrad_bytes(B, T, H, W)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            o.check(o.L.qt_conv3d_c32_wgrad(_lib.qt_dtype(dt), _ptr(x), self.cin_p, _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(nws), B, T, H,
+                                            W, _lib.stream_ptr()), "qt_conv3d_c32_wgrad")
+            o.L.qt_conv3d_c32_dgrad_scratch_bytes.restype = _c.c_size_t
+            nscr = int(o.L.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
+            scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
+            dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
+            o.conv3d_c32_dgrad(dt, dy, self.wd, dx, scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
+                               nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
+            return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
         else:
             # weight gradient: one launch per frame tap over the contiguous range of frames the tap connects (the contraction
             # runs over pixels: f32 sums, nothing accumulates through an activation map); with a workspace the bf16 build takes

@@ -378,6 +378,23 @@ def test_second_conv3d_with_frame_slabs_in_lds(cfg):
     torch.cuda.synchronize()
     assert rel_err(dx[..., :32].float().cpu(), xr.grad.permute(2, 0, 3, 4, 1)) <= 1e-2
     assert (dx[..., 32:] == 0).all()
+    # the weight gradient: contraction over positions, nn.Conv3d's layout, deterministic
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(x, wr, None, 1, 1).backward(dyt.float().permute(1, 4, 0, 2, 3))
+    lib.qt_conv3d_c32_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nws = int(lib.qt_conv3d_c32_wgrad_workspace_bytes(B, T, H, W))
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    dyd = dyt.to(dev)
+    outs = []
+    for _ in range(2):
+        dwt = torch.full((64, 32, 3, 3, 3), float("nan"), device=dev)
+        L.check(lib.qt_conv3d_c32_wgrad(L.qt_dtype(dt), L.ptr(xd), xc, L.ptr(dyd), L.ptr(dwt), L.ptr(ws), ctypes.c_size_t(nws), B, T, H, W,
+                                        L.stream_ptr()), "qt_conv3d_c32_wgrad")
+        torch.cuda.synchronize()
+        outs.append(dwt.cpu())
+    assert rel_err(outs[0], wr.grad) <= 2e-4       # products of bf16 values are exact in f32: only the summation order differs
+    assert torch.equal(outs[0], outs[1])
     assert lib.qt_conv3d_c32_fwd(L.QT_F32, L.ptr(xd), xc, L.ptr(wp), L.ptr(y), None, None, 0, None, B, T, H, W, L.stream_ptr()) == -3
     assert lib.qt_conv3d_c32_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_c32_stats_rows(B, T, H + 1, W) == 0
     assert lib.qt_conv3d_c32_stats_rows(B, T, H, 144) == 0
