@@ -21,6 +21,15 @@ from . import _lib
 from .engine import AdamDesc, AdamItem
 
 
+# Parameter updates made through raw pointers (qt_adam_multi) do not bump torch's version counters: consumers that cache
+# packed copies of parameters (video3d._ConvBlock.pack) compare this counter as well.
+_raw_updates = 0
+
+
+def raw_update_count():
+    return _raw_updates
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, model=None):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
@@ -86,4 +95,6 @@ class FusedAdam(torch.optim.Optimizer):
                     with torch.cuda.device(rest[0][0].device):
                         _lib.check(L.qt_adam_multi(items, len(rest), ctypes.byref(desc), _lib.stream_ptr()),
                                    "qt_adam_multi")
+                    global _raw_updates
+                    _raw_updates += 1
         return loss

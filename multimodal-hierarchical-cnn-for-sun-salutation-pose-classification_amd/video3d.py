@@ -26,6 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import modules as M
+from . import optim as _optim
 from ._lib import QtError
 from .engine import default_compute_dtype
 
@@ -268,6 +269,8 @@ FUSED_POOL = os.environ.get("QTCNN_POOL3D_FUSED", "1") != "0"
 # QTCNN_LSTM_SIDE_STREAM (default 1): Quadtree3DCNN's LSTM branch (a dozen latency-bound launches of 32 workgroups, 0.3 ms
 # forward and 0.25 ms backward in a row) runs on a second stream beside the conv blocks, which it does not depend on
 LSTM_SIDE = os.environ.get("QTCNN_LSTM_SIDE_STREAM", "1") != "0"
+# QTCNN_PACK_CACHE (default 1): the clip models re-pack a conv block's filter / BatchNorm vectors only when one of them changed
+PACK_CACHE = os.environ.get("QTCNN_PACK_CACHE", "1") != "0"
 # QTCNN_CONV3D_SLAB (default 1): conv3d_block2's forward on the slab-resident kernel (csrc/conv3d_slab.hip); 0: 27-tap implicit GEMM
 SLAB_C32 = os.environ.get("QTCNN_CONV3D_SLAB", "1") != "0"
 _side_streams = {}
@@ -325,9 +328,19 @@ class _ConvBlock:
         self._buf_key = None
 
     # -- operand packing: ONE launch per forward (weights may have changed: fused optimizers do not bump _version) --
-    def pack(self, dt, need_dgrad):
+    def pack(self, dt, need_dgrad, epoch=0):
         o, dev = ops(), self.conv.weight.device
         key = (dt, dev, bool(need_dgrad))
+        # nothing to do when neither the parameters nor the running statistics changed since the last pack (an eval loop:
+        # five launches per forward, 8 % of Quadtree3DCNN's eval forward).  torch bumps a tensor's version on every in-place
+        # op; FusedAdam's raw-pointer updates are counted by optim.raw_update_count(); torch's fused optimizers bump nothing, so
+        # `epoch` (the model's count of backward passes) invalidates the copies whenever gradients were produced -- the rule of
+        # engine.Engine.pack_weights
+        tens = (self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+        ver = tuple((t._version, t.data_ptr()) for t in tens) + (_optim.raw_update_count(), epoch)
+        if PACK_CACHE and self._buf_key == key and getattr(self, "_packed_ver", None) == ver:
+            return
+        self._packed_ver = ver
         if self._buf_key != key:
             nf = self.cout_p * 128 if self.first else self.cout_p * 27 * self.cin_p
             self.wf = torch.empty(nf, dtype=dt, device=dev)
@@ -675,6 +688,14 @@ class _ClipModel(nn.Module):
                 raise QtError(f"hook registered on submodule {name!r}: the clip models run as one fused autograd node and "
                               "serve no submodule hooks (hooks on the model itself work); they would never fire")
 
+    def _cached_blocks(self, specs):
+        """the conv blocks' executors (packed filter buffers) live as long as their modules do"""
+        key = tuple((id(c), id(b), p, f) for c, b, p, f in specs)
+        if self.__dict__.get("_blocks_key") != key:
+            self.__dict__["_blocks"] = [_ConvBlock(c, b, p, f) for c, b, p, f in specs]
+            self.__dict__["_blocks_key"] = key
+        return self.__dict__["_blocks"]
+
     def _run(self, image_sequence, numerical_sequence):
         self._check_hooks()
         params = [p for p in self.parameters()]
@@ -814,7 +835,7 @@ class Quadtree3DCNN(_ClipModel):
     def _conv_blocks(self):
         seqs = (self.conv3d_block1, self.conv3d_block2, self.conv3d_block3, self.conv3d_block4_new, self.conv3d_final_features)
         pools = (1, 2, 2, 1, 0)
-        return [_ConvBlock(s[0], s[1], p, i == 0) for i, (s, p) in enumerate(zip(seqs, pools))]
+        return self._cached_blocks([(s[0], s[1], p, i == 0) for i, (s, p) in enumerate(zip(seqs, pools))])
 
     def forward(self, image_sequence_input, numerical_sequence_input):
         fusion = self.mode == 'quadtree_3d_fusion'
@@ -847,7 +868,7 @@ class Quadtree3DCNN(_ClipModel):
         saved_blocks = []
         t, h, w = T, H, W
         for blk in blocks:
-            blk.pack(dt, keep)
+            blk.pack(dt, keep, self.__dict__.get("_bwd_count", 0))
             x, (t, h, w), sv = blk.forward(dt, x, t, B, h, w, training, keep)
             saved_blocks.append(sv)
         F_img = self.cnn_3d_feature_dim
@@ -874,6 +895,7 @@ class Quadtree3DCNN(_ClipModel):
         return logits
 
     def _backward_impl(self, dlogits):
+        self.__dict__["_bwd_count"] = self.__dict__.get("_bwd_count", 0) + 1   # gradients exist: packed weights may go stale
         o, dt = ops(), self.compute_dtype
         blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, last, p = self._saved
         dev = dlogits.device
@@ -942,8 +964,7 @@ class Ji3DCNN(_ClipModel):
 
     def _conv_blocks(self):
         vs = self.visual_stream
-        return [_ConvBlock(vs[0][0], vs[0][1], 1, True), _ConvBlock(vs[2][0], vs[2][1], 2, False),
-                _ConvBlock(vs[4][0], vs[4][1], 0, False)]
+        return self._cached_blocks([(vs[0][0], vs[0][1], 1, True), (vs[2][0], vs[2][1], 2, False), (vs[4][0], vs[4][1], 0, False)])
 
     def forward(self, image_sequence, numerical_sequence):
         numerical_sequence = numerical_sequence.to(image_sequence.device)
@@ -960,7 +981,7 @@ class Ji3DCNN(_ClipModel):
         saved_blocks = []
         t, h, w = T, H, W
         for blk in blocks:
-            blk.pack(dt, keep)
+            blk.pack(dt, keep, self.__dict__.get("_bwd_count", 0))
             x, (t, h, w), sv = blk.forward(dt, x, t, B, h, w, training, keep)
             saved_blocks.append(sv)
         ld = 128 + 64
@@ -982,6 +1003,7 @@ class Ji3DCNN(_ClipModel):
         return logits
 
     def _backward_impl(self, dlogits):
+        self.__dict__["_bwd_count"] = self.__dict__.get("_bwd_count", 0) + 1   # gradients exist: packed weights may go stale
         o, dt = ops(), self.compute_dtype
         blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, p = self._saved
         dev = dlogits.device

@@ -578,6 +578,46 @@ def test_dropout_train_mode_and_eval_backward_and_errors():
     assert torch.equal(a, b)
 
 
+def test_packed_operands_follow_the_parameters(monkeypatch):
+    """The conv blocks re-pack their filter / BatchNorm vectors only when one of them changed (video3d._ConvBlock.pack): an
+    in-place edit through torch, a step of the package's FusedAdam (raw pointers: optim.raw_update_count) and a step of
+    torch's fused Adam (bumps nothing: invalidated by the backward that produced its gradients) must all reach the next
+    forward -- logits equal to those of a forward that re-packs unconditionally."""
+    dev = _dev()
+    P = pkg()
+    v3d = pkg("video3d")
+    B, T, HW = 2, 4, 32
+    x, f, y = (t.to(dev) for t in _inputs(B, T, HW, 9))
+    m = _build("quadtree_3d_fusion", T, torch.bfloat16).to(dev)
+
+    def eval_logits(cache):
+        monkeypatch.setattr(v3d, "PACK_CACHE", cache)
+        m.eval()
+        with torch.no_grad():
+            return m(x, f).clone()
+
+    a0 = eval_logits(True)
+    assert torch.equal(a0, eval_logits(True)) and torch.equal(a0, eval_logits(False))
+    w = m.conv3d_block2[0].weight
+    with torch.no_grad():
+        w.mul_(0.5)
+    a1 = eval_logits(True)
+    assert not torch.equal(a1, a0) and torch.equal(a1, eval_logits(False))
+    with torch.no_grad():
+        w.mul_(2.0)                                        # (exact: back to the first weights)
+    assert torch.equal(eval_logits(True), a0)
+    for make in (lambda ps: P.FusedAdam(ps, lr=1e-2), lambda ps: torch.optim.Adam(ps, lr=1e-2, fused=True)):
+        opt = make(list(m.parameters()))
+        before = eval_logits(True)
+        monkeypatch.setattr(v3d, "PACK_CACHE", True)
+        m.train()
+        opt.zero_grad(set_to_none=True)
+        F.cross_entropy(m(x, f), y).backward()
+        opt.step()
+        after = eval_logits(True)
+        assert not torch.equal(after, before) and torch.equal(after, eval_logits(False))
+
+
 class _sibling_models:
     def __init__(self, sub):
         self.dir = os.path.join(ROOT, PKG, sub)
