@@ -366,6 +366,11 @@ class _ConvBlock:
         d.kt, d.frames = 3, T
         return d
 
+    def _vec_grad(self, v):
+        """a per-channel gradient vector without its padding channels; no copy launch when there is no padding (every block
+        but the first: three launches per block and step)"""
+        return v if v.shape[0] == self.cout and v.is_contiguous() else v[:self.cout].clone()
+
     @staticmethod
     def _slab_wgrad_bytes(B, T, H, W):
         L = ops().L
@@ -537,7 +542,7 @@ class _ConvBlock:
             ws = torch.empty(raw_ws, dtype=torch.uint8, device=dev)
             o.check(o.L.qt_conv3d_first_wgrad(_lib.qt_dtype(dt), _ptr(x), _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(raw_ws), B, T, H, W,
                                               _lib.stream_ptr()), "qt_conv3d_first_wgrad")
-            return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
+            return dx, dW, self._vec_grad(db), self._vec_grad(dgamma), self._vec_grad(dbeta)
         if self.first:
             d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
             dw = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
@@ -555,7 +560,7 @@ class _ConvBlock:
             dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
             o.conv3d_c32_dgrad(dt, dy, self.wd, dx, scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
                                nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
-            return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
+            return dx, dW, self._vec_grad(db), self._vec_grad(dgamma), self._vec_grad(dbeta)
         else:
             # weight gradient: one launch per frame tap over the contiguous range of frames the tap connects (the contraction
             # runs over pixels: f32 sums, nothing accumulates through an activation map); with a workspace the bf16 build takes
@@ -585,7 +590,7 @@ class _ConvBlock:
                         nbytes=esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p))
         o.check(o.L.qt_unpack_conv3d_wgrad(_ptr(dw), _ptr(dW), self.cout, self.cin, self.cout_p, self.cin_p,
                                            1 if self.first else 0, _lib.stream_ptr()), "qt_unpack_conv3d_wgrad")
-        return dx, dW, db[:self.cout].clone(), dgamma[:self.cout].clone(), dbeta[:self.cout].clone()
+        return dx, dW, self._vec_grad(db), self._vec_grad(dgamma), self._vec_grad(dbeta)
 
 
 def o_desc(dt, mode, images, h, w, k_per_tap, n_out, k, pad):
