@@ -8,7 +8,8 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-profile}
-CMD="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0"
+# QT_PROFILE_ARGS: extra bench.py arguments (e.g. "--model quadtree3d"); default = the headline QuadtreeCNN train step
+CMD="python3 $R/bench.py ${QT_PROFILE_ARGS} --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
