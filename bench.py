@@ -32,6 +32,7 @@ import ctypes
 import importlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -47,6 +48,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
 # kernel families (scripts/summarize_profiles.py) behind roofline.achieved: forward + data-gradient conv launches
 ROOFLINE_FAMILIES = ("conv_igemm_kernel", "conv_pt_kernel", "conv_s2_kernel", "conv_l1_ring_kernel", "conv_stem_kernel",
                      "conv_stem_pool_kernel", "linear_splitk_kernel")
+ROOFLINE_FAMILIES_3D = ("conv_igemm_kernel", "conv3d_first_kernel", "conv3d_c32_kernel")
 
 
 def kernel_sources_sha1():
@@ -62,22 +64,123 @@ def kernel_sources_sha1():
     return h.hexdigest()
 
 
-def pmc_summary(pattern):
-    """Newest committed profiles/<pattern> collected on EXACTLY the kernel sources of this tree, else (None, reason).
+SUMMARY_KEYS = {   # what a reader below indexes; a summary without them is skipped, never indexed (round 3: KeyError 'families')
+    "traffic": ("kernel_sources_sha1", "families"),
+    "mfma_busy": ("kernel_sources_sha1", "train", "eval"),
+}
+
+
+def summary_identity(rec, path):
+    """(kind, model, batch, dtype) of a committed PMC summary.  Summaries written since round 4 carry all four fields;
+    older ones are identified by file name / command string (the only other model ever summarised is quadtree3d)."""
+    base = os.path.basename(path)
+    kind = rec.get("kind") or ("mfma_busy" if base.endswith("_mfma_busy.json") else
+                               "traffic" if base.endswith("_traffic.json") else None)
+    model = rec.get("model")
+    if model is None:
+        m = re.search(r"--model\s+(\w+)", str(rec.get("command", "")))
+        model = m.group(1) if m else ("quadtree3d" if "quadtree3d" in base else "quadtree")
+    return kind, model, int(rec.get("batch", 256)), rec.get("dtype", "bf16")
+
+
+def summary_problems(rec, kind):
+    """Reasons a summary of `kind` cannot be consumed by this file ([] = usable)."""
+    bad = ["missing key %r" % k for k in SUMMARY_KEYS[kind] if k not in rec]
+    if kind == "traffic" and isinstance(rec.get("families"), dict):
+        for fam, v in rec["families"].items():
+            if not isinstance(v, dict) or not all(isinstance(v.get(k), (int, float)) for k in
+                                                  ("hbm_bytes_per_launch", "launches_profiled")):
+                bad.append("family %r lacks hbm_bytes_per_launch / launches_profiled" % fam)
+    elif kind == "traffic":
+        bad.append("'families' is not a mapping")
+    if kind == "mfma_busy":
+        for mode in ("train", "eval"):
+            if not isinstance(rec.get(mode), dict) or not all(k in rec[mode] for k in
+                                                              ("mfma_busy_cycles_per_step", "executed_over_algorithmic")):
+                bad.append("%r lacks mfma_busy_cycles_per_step / executed_over_algorithmic" % mode)
+    return bad
+
+
+def pmc_summary(kind, model="quadtree", batch=256, dtype="bf16"):
+    """The committed profiles/*.json PMC summary of `kind` ("traffic" | "mfma_busy") for exactly this model / batch / dtype,
+    collected on EXACTLY the kernel sources of this tree and carrying the keys the readers use -- else (None, reason).
     PMC counters cannot be collected inside bench.py (rocprofv3 wraps the process), so the numbers are read from the
-    committed summary of the same command -- but never from one that predates a kernel change."""
+    committed summary of the same command, but never from one that predates a kernel change, belongs to another model or
+    has another shape.  Candidates are ordered by NAME (rNN_ prefix), newest round first: file times are checkout times.
+    Never raises."""
     import glob
-    cur = kernel_sources_sha1()
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime, reverse=True)
-    for f in cands:
-        try:
-            rec = json.load(open(f))
-        except Exception:
-            continue
-        if rec.get("kernel_sources_sha1") == cur:
+    try:
+        cur = kernel_sources_sha1()
+        skipped = []
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.json")), key=os.path.basename, reverse=True):
+            try:
+                rec = json.load(open(f))
+            except Exception:
+                continue
+            if not isinstance(rec, dict) or "kernel_sources_sha1" not in rec:
+                continue
+            if summary_identity(rec, f) != (kind, model, batch, dtype) or rec["kernel_sources_sha1"] != cur:
+                continue
+            bad = summary_problems(rec, kind)
+            if bad:
+                skipped.append("%s: %s" % (os.path.basename(f), "; ".join(bad[:3])))
+                continue
             return rec, os.path.relpath(f, ROOT)
-    return None, ("no committed PMC summary matches the current kernel sources (sha1 %s): re-collect with "
-                  "scripts/collect_profiles.sh" % cur[:12])
+        return None, ("no committed %s summary of %s (batch %d, %s) matches the current kernel sources (sha1 %s): re-collect "
+                      "with scripts/collect_profiles.sh%s" % (kind, model, batch, dtype, cur[:12],
+                                                              "; skipped " + " | ".join(skipped) if skipped else ""))
+    except Exception as e:   # a broken profiles/ directory must never take the measurement down
+        return None, "profiles/ unreadable: %r" % (e,)
+
+
+def guarded(what, fn, *a, **kw):
+    """Enrichment of the JSON line from side files / extra steps: the measurement is already taken when these run, so a
+    failure becomes {"error": ...} on the line instead of a crash before the line is printed (the rule cpu_baseline has
+    followed since round 1)."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:
+        print("bench.py: %s failed: %r" % (what, e), file=sys.stderr)
+        return {"error": "%s: %r" % (what, e)}
+
+
+def roofline_traffic(model, batch, dtype, families):
+    """(HBM bytes per launch over the kernel `families` behind roofline.achieved, source string) from the committed
+    FETCH_SIZE / WRITE_SIZE summary of the same command; (None, reason) if there is none for this tree."""
+    try:
+        rec, src = pmc_summary("traffic", model, batch, dtype)
+        if rec is None:
+            return None, src
+        fams = rec["families"]
+        sel = [fams[k] for k in families if k in fams and fams[k].get("launches_profiled", 0)]
+        n = sum(v["launches_profiled"] for v in sel)
+        traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in sel) / n) if n else None
+        return traffic, src + " (kernel sources sha1 " + rec["kernel_sources_sha1"][:12] + ")"
+    except Exception as e:
+        return None, "traffic summary unusable: %r" % (e,)
+
+
+def step_hbm(model, batch, dtype, s_per_step):
+    """Whole-step HBM bytes by counter against THIS run's step time."""
+    rec, src = pmc_summary("traffic", model, batch, dtype)
+    if rec is None:
+        return {"bytes_per_step": None, "note": src}
+    steps_prof = float(rec.get("steps_profiled", 5))
+    per_step = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in rec["families"].values()) / steps_prof
+    return {"bytes_per_step": int(per_step), "achieved_tb_s": round(per_step / s_per_step / 1e12, 2),
+            "peak_tb_s": 8.0, "source": src, "kernel_sources_sha1": rec["kernel_sources_sha1"][:12]}
+
+
+def step_mfma_busy(model, batch, dtype, mode, s_per_step):
+    """Matrix-pipe busy cycles by counter against THIS run's step time."""
+    rec, src = pmc_summary("mfma_busy", model, batch, dtype)
+    if rec is None:
+        return {"utilisation": None, "note": src}
+    r = rec[mode]
+    return {"busy_simd_cycles_per_step": r["mfma_busy_cycles_per_step"],
+            "executed_over_algorithmic_flop": r["executed_over_algorithmic"],
+            "utilisation": round(r["mfma_busy_cycles_per_step"] / (1024 * s_per_step * 2.4e9), 4),
+            "source": src + " (SQ_VALU_MFMA_BUSY_CYCLES)", "kernel_sources_sha1": rec["kernel_sources_sha1"][:12]}
 
 
 def parse():
@@ -468,17 +571,7 @@ def main():
         if nig:
             ach = (fl[0] + fl[1]) / ((ms[0] + ms[1]) * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            traffic, traffic_src = None, None
-            rec, src = pmc_summary("*_traffic.json")
-            if rec is not None:  # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE passes of the same command)
-                fams = rec["families"]
-                n = sum(fams[k].get("launches_profiled", 0) for k in ROOFLINE_FAMILIES if k in fams)
-                if n:
-                    traffic = round(sum(fams[k]["hbm_bytes_per_launch"] * fams[k]["launches_profiled"]
-                                        for k in ROOFLINE_FAMILIES if k in fams) / n)
-                traffic_src = src + " (kernel sources sha1 " + rec["kernel_sources_sha1"][:12] + ")"
-            else:
-                traffic_src = src
+            traffic, traffic_src = roofline_traffic(args.model, args.batch, args.dtype, ROOFLINE_FAMILIES)
             roofline = {"kernel": "forward + data-gradient conv launches (conv_pt_kernel for the 3x3 stride-1 layers of "
                                   "layer2-4; conv_l1_ring_kernel for the 56x56 64->64 layers; conv_s2_kernel for the stride-2 "
                                   "transitions forward, conv_igemm_kernel for their data gradients; conv_stem_kernel for conv1)",
@@ -517,9 +610,10 @@ def main():
                     per[nm] = {"launches_per_step": len(sel) // args.profile_steps, "avg_us": round(1e3 * msk / len(sel), 1),
                                "tflops": round(sum(r[2] for r in sel) / (msk * 1e-3) / 1e12, 1),
                                "algorithmic_mb_per_launch": round(sum(r[3] for r in sel) / len(sel) / 1e6, 1)}
+            traffic, traffic_src = roofline_traffic(args.model, args.batch, args.dtype, ROOFLINE_FAMILIES_3D)
             roofline = {"kernel": "Conv3d launches of the step (blocks 3-5: one 27-tap implicit GEMM per convolution and direction; block 1 from the f32 clip; block 2 slab-resident)",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": None, "traffic_source": "no PMC pass collected for this model",
+                        "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": round(tot_by / len(recs)), "avg_launch_us": round(1e3 * tot_ms / len(recs), 1),
                         "gflop_per_launch": round(tot_fl / len(recs) / 1e9, 3), "steps_profiled": args.profile_steps,
                         "by_kernel": per}
@@ -529,26 +623,11 @@ def main():
     # collected on exactly these kernel sources (otherwise null + the reason)
     hbm = mfma_pmc = None
     headline = args.batch == 256 and args.dtype == "bf16" and args.model == "quadtree" and not args.freeze_backbone
-    if headline and not args.forward_only:
-        rec, src = pmc_summary("*_traffic.json")
-        if rec is not None:
-            fams = rec["families"]
-            steps_prof = float(rec.get("steps_profiled", 5))
-            per_step = sum(v.get("hbm_bytes_per_launch", 0) * v.get("launches_profiled", 0) for v in fams.values()) / steps_prof
-            hbm = {"bytes_per_step": int(per_step), "achieved_tb_s": round(per_step / (elapsed / args.steps) / 1e12, 2),
-                   "peak_tb_s": 8.0, "source": src, "kernel_sources_sha1": rec["kernel_sources_sha1"][:12]}
-        else:
-            hbm = {"bytes_per_step": None, "note": src}
+    if (headline or args.model == "quadtree3d") and not args.forward_only and not args.freeze_backbone:
+        hbm = guarded("hbm summary", step_hbm, args.model, args.batch, args.dtype, elapsed / args.steps)
     if headline:
-        rec, src = pmc_summary("*_mfma_busy.json")
-        if rec is not None:
-            r = rec["eval" if args.forward_only else "train"]
-            mfma_pmc = {"busy_simd_cycles_per_step": r["mfma_busy_cycles_per_step"],
-                        "executed_over_algorithmic_flop": r["executed_over_algorithmic"],
-                        "utilisation": round(r["mfma_busy_cycles_per_step"] / (1024 * (elapsed / args.steps) * 2.4e9), 4),
-                        "source": src + " (SQ_VALU_MFMA_BUSY_CYCLES)", "kernel_sources_sha1": rec["kernel_sources_sha1"][:12]}
-        else:
-            mfma_pmc = {"utilisation": None, "note": src}
+        mfma_pmc = guarded("mfma_busy summary", step_mfma_busy, args.model, args.batch, args.dtype,
+                           "eval" if args.forward_only else "train", elapsed / args.steps)
 
     # ---- the north-star quantity on the same line: eval-mode forward of the same model, timed after the train step ----
     forward = None

@@ -18,4 +18,11 @@ export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}q3 -o q3 -- python3 bench.py --model quadtree3d --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0 > gpurun_out/${R}q3.log 2>&1 || exit 1
 export QTCNN_SIDE_STREAM=0
 timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}ser -o ser -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0 > gpurun_out/${R}ser.log 2>&1 || exit 1
+unset QTCNN_SIDE_STREAM
+# LAST: the exact command the driver runs, on the tree as it stands.  Summarise + commit the profiles, then run
+#   gpurun -- 'python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/final_bench.json'
+# once more on the committed tree and commit NOTHING that bench.py reads after it (tests/test_bench_gpu.py runs the same
+# command; tests/test_bench_cpu.py checks every committed summary against the reader).
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_driver_command.json || exit 1
+python -c "import json,sys; r=json.load(open('gpurun_out/${R}_driver_command.json')); assert r['roofline'] and r['cpu_baseline'] and r['forward'], r" || exit 1
 echo done

@@ -20,7 +20,7 @@ algorithmic = {"train": 11.0792e9 * 256, "eval": 3.7718e9 * 256}
 FAMS = ("conv_igemm", "conv_pt", "conv_s2", "stem_wgrad_rows", "conv_wgrad_tile", "conv_wgrad_patch", "conv_wgrad", "conv_l1_ring", "conv_stem", "linear_splitk")
 sys.path.insert(0, root)
 import bench  # noqa: E402
-out = {"kernel_sources_sha1": bench.kernel_sources_sha1(), "counter": "SQ_VALU_MFMA_BUSY_CYCLES (rocprofv3 --pmc, one pass, --kernel-trace only)", "batch": 256, "dtype": "bf16",
+out = {"kind": "mfma_busy", "model": "quadtree", "kernel_sources_sha1": bench.kernel_sources_sha1(), "counter": "SQ_VALU_MFMA_BUSY_CYCLES (rocprofv3 --pmc, one pass, --kernel-trace only)", "batch": 256, "dtype": "bf16",
        "simds": 1024, "clock_ghz_for_utilisation": 2.4, "busy_cycles_per_mfma_16x16x32": 16}
 for mode in ("train", "eval"):
     f = glob.glob(os.path.join(root, "gpurun_out", name, mode, "*", "*_counter_collection.csv"))[0]

@@ -14,11 +14,19 @@ import sys
 
 name = sys.argv[1] if len(sys.argv) > 1 else "profile"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+# optional: the model the passes were collected on (QT_PROFILE_ARGS="--model quadtree3d" -> `quadtree3d`), its batch and dtype;
+# bench.py::pmc_summary matches a summary on (kind, model, batch, dtype, kernel sources)
+model = sys.argv[3] if len(sys.argv) > 3 else "quadtree"
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+dtype = sys.argv[5] if len(sys.argv) > 5 else "bf16"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", name)
 
 
 def family(kernel):
+    if model != "quadtree":   # other models: the kernel's own name without template arguments
+        k = kernel.split("(")[0].split("<")[0].split()[-1] if kernel.strip() else "other"
+        return k.split("::")[-1]
     for key in ("conv_igemm_kernel", "conv_pt_kernel", "conv_s2_kernel", "stem_bn_bwd_apply2x2", "stem_wgrad_rows", "conv_wgrad_tile_kernel", "conv_wgrad_patch_kernel", "conv_wgrad_kernel", "conv_l1_ring_kernel",
                 "conv_stem_kernel", "conv_patch_kernel", "wgrad_partial_sum", "bn_bwd_apply", "bn_bwd_reduce",
                 "bn_act", "stem_pool_bwd", "stem_bn_bwd_sums", "stem_pool", "pack_weights_batched",
@@ -42,7 +50,8 @@ def pmc(sub, counter):
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(stats)))
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
-with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w") as out:
+stem = tag if model == "quadtree" else f"{tag}_{model}"
+with open(os.path.join(root, "profiles", f"{stem}_kernel_stats.csv"), "w") as out:
     out.write(open(stats).read())
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 summary = {}
@@ -62,8 +71,10 @@ for fam, (ns, calls) in dur.items():
     summary[fam]["calls"] = calls
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_sources_sha1: ties the summary to the kernel sources it was collected on)
-json.dump({"command": "bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0 (B=256, bf16, 1 GPU)",
+json.dump({"kind": "traffic", "model": model, "batch": batch, "dtype": dtype,
+           "command": "bench.py%s --steps 3 --warmup 2 --no-cpu-baseline --no-forward-leg --profile-steps 0 (B=%d, %s, 1 GPU)"
+                      % ("" if model == "quadtree" else " --model " + model, batch, dtype),
            "kernel_sources_sha1": bench.kernel_sources_sha1(), "steps_profiled": 5,
            "corrections": "read = FETCH_SIZE*1024*2 (gfx950 half-count of wide coalesced reads), write = WRITE_SIZE*1024",
-           "families": summary}, open(os.path.join(root, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
+           "families": summary}, open(os.path.join(root, "profiles", f"{stem}_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
