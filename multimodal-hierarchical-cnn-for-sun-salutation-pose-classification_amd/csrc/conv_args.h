@@ -37,7 +37,9 @@ struct ConvArgs {
   int dst_merge_res0;       // residual only for class (0,0)
   int dst_merge;            // C > 0: N = 4*C, the four parity classes of a stride-2 data gradient in one launch (qtcnn.h)
   FastDiv div_ohw, div_ow;
-  unsigned long long* prof;   // PROFILING AID (qt_set_igemm_prof): [workgroup][4] s_memrealtime stamps (10 ns), NULL normally
+#ifdef QT_KERNEL_PROF
+  unsigned long long* prof;   // experiment build only (qt_set_igemm_prof): [workgroup][4] s_memrealtime stamps (10 ns)
+#endif
   // Conv3d as ONE implicit GEMM (round 3): KT > 1 frame taps on time-major clips [T][Bf][H][W][C] -- tap (kt, kh, kw) of
   // output image n = t * Bf + b reads image n + (kt - KT/2) * Bf (data gradient: n - (kt - KT/2) * Bf), valid while that
   // frame exists; ntaps = KT * KH * KW <= 32.  KT <= 1: plain 2-D.

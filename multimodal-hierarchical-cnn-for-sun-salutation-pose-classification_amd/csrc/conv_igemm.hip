@@ -54,9 +54,15 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
 
+  // phase stamps exist only in an experiment build (-DQT_KERNEL_PROF, scripts/prof_build.sh): the production kernel carries
+  // no profiling pointer it could write through
+#ifdef QT_KERNEL_PROF
   auto stamp = [&](int i) {
     if (p.prof && tid == 0) p.prof[(long long)blockIdx.x * 4 + i] = wall_clock64();
   };
+#else
+  auto stamp = [](int) {};
+#endif
   stamp(0);   // entry
   const int bid = qt_xcd_remap(blockIdx.x, p.gridM * p.gridN);
   const int mt = bid / p.gridN, nt = bid - mt * p.gridN;
@@ -695,8 +701,10 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   return d->dst_merge > 0 ? rows * (d->n_out / d->dst_merge) : rows;  // merged parity classes: one row per class
 }
 
+#ifdef QT_KERNEL_PROF   // experiment build only (scripts/prof_build.sh): [workgroup][4] stamps; the caller owns the buffer
 unsigned long long* g_igemm_prof = nullptr;
-extern "C" void qt_set_igemm_prof(unsigned long long* buf) { g_igemm_prof = buf; }   // profiling aid, not in the header
+extern "C" void qt_set_igemm_prof(unsigned long long* buf) { g_igemm_prof = buf; }
+#endif
 
 extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   QT_CHECK_ARG(d && io, "qt_conv2d_igemm: null descriptor");
@@ -745,7 +753,9 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.src = io->src; a.wgt = io->weight; a.dst = io->dst;
   a.scale = io->scale; a.shift = io->shift;
   a.residual = io->residual; a.relu_mask = io->relu_mask; a.relu_mask_bits = io->relu_mask_bits;
+#ifdef QT_KERNEL_PROF
   a.prof = g_igemm_prof;
+#endif
   a.stats_partial = io->stats_partial;
   for (int k = 0; k < 2; ++k) {
     a.bn_y[k] = io->bwd_bn[k].y; a.bn_mean[k] = io->bwd_bn[k].mean; a.bn_invstd[k] = io->bwd_bn[k].invstd;

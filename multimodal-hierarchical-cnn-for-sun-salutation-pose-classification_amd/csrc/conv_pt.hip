@@ -56,7 +56,9 @@ struct PtArgs {
   int PW, PP, npos, npass;      // patch: row pitch W+2, positions per sub-image (R+2)*(W+2), G*PP, passes of 64 rows
   int tpi, tiles_m, batch;      // pixel tiles per image (GEO_ROWS), pixel tiles in all, images
   int items, ipw;               // (channel tile, pixel tile) items in all / per workgroup (persistent walk)
-  unsigned long long* prof;     // PROFILING AID (QTCNN_PT_PROF): [workgroup][32] s_memrealtime stamps (10 ns), NULL normally
+#ifdef QT_KERNEL_PROF
+  unsigned long long* prof;     // experiment build only (qt_set_pt_prof): [workgroup][32] s_memrealtime stamps (10 ns)
+#endif
   int stagger;                  // start delay of workgroup class k = (blockIdx / 8) % 4: k * stagger * 1024 cycles (0: none)
   int nchunks;                  // 128-byte channel chunks of the source
   unsigned src_bytes, wgt_bytes; // extents of the two operands (buffer resources: range-checked DMA)
@@ -202,7 +204,9 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   // K-tile stream never stops at an item boundary (the next item's first patch and weight tiles are requested during
   // the last chunk of the current one) and the epilogue runs from the accumulators between two K-tiles.  Consecutive
   // logical workgroup ids share an XCD (its L2): a weight slice and neighbouring pixel tiles per XCD.
+#ifdef QT_KERNEL_PROF
   if (q.prof && threadIdx.x == 0) q.prof[(long long)blockIdx.x * 32 + 31] = wall_clock64();   // kernel entry
+#endif
   const int wg = qt_xcd_remap(blockIdx.x, gridDim.x);
   // (the 256-channel tile has no register room for the walk's state next to its epilogue: one item per workgroup there --
   // which is what 256 images give its 14x14 stage anyway; the loop below then runs once and its state dies in the epilogue)
@@ -344,11 +348,15 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   for (int s = 0; s < D; ++s) dma_weights(rs_wgt, (unsigned)cur_nt * wtile_bytes + (unsigned)s * tap_bytes, s);   // (D < 9: all in chunk 0)
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RW * (D - 1)) : "memory");   // (lgkmcnt: the vectors above)
   if (grp == 1) asm volatile("s_barrier" ::: "memory");
+#ifdef QT_KERNEL_PROF
   int prof_i = 0;
   auto stamp = [&]() {
     if (q.prof && tid == 0 && prof_i < 32) q.prof[(long long)blockIdx.x * 32 + prof_i] = wall_clock64();
     ++prof_i;
   };
+#else
+  auto stamp = []() {};
+#endif
   stamp();   // 0: prologue done
 
   T* __restrict__ dst = static_cast<T*>(p.dst);
@@ -738,7 +746,9 @@ inline int pt_bn(const ConvArgs& a) { return (a.N % 256 == 0 && a.OH == 14) ? 25
 // persistent grid: one workgroup per CU (qt_set_pt_conv_max_workgroups caps it: tests walk several items per workgroup
 // at small batches; QTCNN_PT_PERSIST=0: one item per workgroup as in round 2, same-box A/B)
 int g_pt_max_wgs_fwd = 0;
+#ifdef QT_KERNEL_PROF
 unsigned long long* g_pt_prof = nullptr;
+#endif
 int g_pt_stagger[2] = {-1, -1};   // forward, backward
 inline int pt_stagger(bool bwd) {
   if (g_pt_stagger[0] < 0) {
@@ -775,7 +785,9 @@ int launch(PtArgs q, hipStream_t stream) {
   q.items = q.tiles_m * q.c.gridN;
   q.ipw = (BN == 128 && !KS) ? qt_cdiv(q.items, pt_workgroups()) : 1;
   q.stagger = (q.ipw >= 2 || pt_stagger(DGRAD || NTAPS == 4) < 0) ? pt_stagger(DGRAD || NTAPS == 4) : 0;   // (< 0: experiment builds)
+#ifdef QT_KERNEL_PROF
   q.prof = g_pt_prof;
+#endif
   hipLaunchKernelGGL(kern, dim3(qt_cdiv(q.items, q.ipw)), dim3(kNT), lds, stream, q);
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -859,7 +871,9 @@ inline int pt_enabled() {
 
 extern "C" void qt_set_pt_conv(int mode) { g_pt_enabled = mode < 0 ? 1 : mode; }
 extern "C" void qt_set_pt_conv_max_workgroups(int n) { g_pt_max_wgs_fwd = n > 0 ? n : 0; }
-extern "C" void qt_set_pt_prof(unsigned long long* buf) { g_pt_prof = buf; }   // profiling aid, not in the header
+#ifdef QT_KERNEL_PROF
+extern "C" void qt_set_pt_prof(unsigned long long* buf) { g_pt_prof = buf; }   // experiment build only, not in the header
+#endif
 
 // images the kernel walks (quadrant modes: four 7x7 region images per map) and the quadrant mode, -1: not covered
 static int pt_images(const ConvArgs& a, bool dgrad, int* quad) {

@@ -1,7 +1,8 @@
 """Drop-in for /root/reference/3dcnn/models.py (`from models import get_model`).
 
 Quadtree3DCNN (:96-214) with the reference's constructor and `get_model` signature (:493-522); the Conv3d stack runs on
-the MFMA implicit-GEMM kernels (three 2-D launches per 3x3x3 convolution over time-major clips, <pkg>/video3d.py).
+the MFMA kernels over time-major clips, one launch per 3x3x3 convolution and direction (27-tap implicit GEMM; block 1 from the
+f32 clip, block 2 slab-resident: <pkg>/video3d.py).
 The 2-D models this file also carries in the reference (StandardResNetCNN :34-92, QuadtreeCNN :381-490) are the ones of
 the resnet/ drop-in.  ResNet3DVideo / HybridQuadtree3DCNN (:220-375) wrap torchvision's r3d_18 with KINETICS400 weights
 (a remote fetch, SURVEY.md section 2 row 11: out of scope): they raise NotImplementedError.

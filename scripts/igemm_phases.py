@@ -1,5 +1,6 @@
 """Developer aid: where the generic implicit-GEMM tile spends its time on the stride-2 data gradients of the backward chain
-(s_memrealtime stamps per workgroup: qt_set_igemm_prof)."""
+(s_memrealtime stamps per workgroup: qt_set_igemm_prof).
+Needs the experiment build: bash scripts/prof_build.sh, then QTCNN_LIB_PATH=<pkg>/libqtcnn_prof.so (the production library has no stamps)."""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
-"""Developer aid: where a conv_pt launch spends its time (s_memrealtime stamps per workgroup: qt_set_pt_prof)."""
+"""Developer aid: where a conv_pt launch spends its time (s_memrealtime stamps per workgroup: qt_set_pt_prof).
+Needs the experiment build: bash scripts/prof_build.sh, then QTCNN_LIB_PATH=<pkg>/libqtcnn_prof.so (the production library has no stamps)."""
 import ctypes, os, sys
 sys.argv = [sys.argv[0], "none"]
 import importlib.util
