@@ -99,6 +99,11 @@ typedef struct qt_conv_desc {
    * accumulation over all kt * kh * kw taps, the epilogue (bias, residual, BatchNorm3d statistics) sees the finished value.
    * DGRAD mirrors it.  Needs stride 1 and no region / strided-destination mode; 0 or 1 = plain 2-D. */
   int kt, frames;
+  /* With dst_merge: 1 = a FIFTH tap slot (weight rows then hold 5 slots of k_per_tap) that reads qt_conv_io.extra_src -- a
+   * second gradient map of the same geometry as src -- at the window's first pixel (r, c) and only reaches class (0,0): the
+   * data gradient of the block's 1x1 / stride-2 downsample (torchvision BasicBlock.downsample) accumulated in
+   * the same launch as conv1's, instead of a launch of its own whose output the merged launch then re-reads as a residual. */
+  int dst_merge_extra;
 } qt_conv_desc;
 
 typedef struct qt_conv_io {
@@ -125,6 +130,7 @@ typedef struct qt_conv_io {
    * relu_mask; read at the destination row like relu_mask (strided / merged destinations included).  n_out % 8 == 0.
    * 1/16 of the bytes of a bf16 mask: the mask is the second-largest epilogue operand of a data-gradient launch. */
   const unsigned char* relu_mask_bits;
+  const void* extra_src;  /* qt_conv_desc.dst_merge_extra: [batch][in_h][in_w][k_per_tap] with src's strides, or NULL */
 } qt_conv_io;
 
 /* 3x3 stride-1 convs with the input patch resident in LDS (csrc/conv_patch.hip) instead of the
@@ -206,7 +212,8 @@ int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, flo
 size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* desc);
 int qt_conv2d_wgrad_ws(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* workspace,
                        size_t workspace_bytes, void* stream);
-/* The shapes with a workspace (bf16 3x3 stride 1): the gradient is WRITTEN (not accumulated) in the
+/* The shapes with a workspace (bf16: 3x3 stride 1; and the stride-2 pair of a ResNet transition block, 3x3 / 2 pad 1 and
+ * 1x1 / 2 on an even-sized map, csrc/conv_wgrad_s2.hip): the gradient is WRITTEN (not accumulated) in the
  * reference's OIHW layout by the kernel that sums the partial filters -- no [O][kh][kw][I] scratch,
  * no zero fill, no qt_unpack_conv_wgrad.  QT_ERR_UNSUPPORTED for every other shape. */
 int qt_conv2d_wgrad_oihw(const qt_conv_desc* desc, const void* dy, const void* x, float* grad_oihw, void* workspace,
@@ -220,6 +227,10 @@ void qt_set_wgrad_patch_min_width(int min_width);
  * buffered in LDS, fragment reads two taps ahead of the MFMAs, source offsets from a table in LDS; default),
  * 0 / 2 = the round-1 ring kernel with one / two wave groups.  <0 = default; env QTCNN_WP_VARIANT. */
 void qt_set_wgrad_patch_variant(int variant);
+/* bf16 weight gradients of the stride-2 convolutions (3x3 / 2 pad 1, 1x1 / 2 pad 0, even map, channels % 64 == 0) on the
+ * four parity planes of the input, tile-resident, all taps per workgroup, deterministic (csrc/conv_wgrad_s2.hip):
+ * 1 = on (default), 0 = the generic kernel with float atomics, <0 = default.  Env QTCNN_WGRAD_S2. */
+void qt_set_wgrad_s2(int on);
 
 /* ------------------------------------------------------------------------
  * Layout packing (HBM-bound).
@@ -246,7 +257,11 @@ typedef struct qt_pack_item {
   const float* w_oihw;
   void* w_fwd;   /* nullable */
   void* w_dgrad; /* nullable */
-  int O, I, k, stride2_dgrad;
+  int O, I, k, stride2_dgrad;   /* stride2_dgrad: 0 stride 1; 1 parity classes (qt_pack_dgrad_s2); 2 merged, 4 slots
+                                   (qt_pack_dgrad_s2_merged); 3 merged, FIVE slots per row (slot 4 belongs to the downsample);
+                                   4 (k = 1): w_dgrad is that five-slot operand of the block's conv1 -- this item fills slot 4
+                                   of the class-(0,0) rows: element ((i*5 + 4)*O + o) = w[o][i] (rows of the other classes
+                                   keep the zeros qt_plan_init_workspace wrote) */
 } qt_pack_item;
 int qt_pack_weights_batched(int dtype, const qt_pack_item* items, int n, void* stream);
 /* Adam with L2-in-gradient weight decay, torch.optim.Adam semantics without amsgrad / maximize

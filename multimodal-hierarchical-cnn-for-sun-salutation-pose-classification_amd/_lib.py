@@ -39,6 +39,7 @@ class ConvDesc(ctypes.Structure):
         ("dst_off_h", ctypes.c_int), ("dst_off_w", ctypes.c_int),
         ("dst_merge", ctypes.c_int), ("dst_merge_res0", ctypes.c_int),
         ("kt", ctypes.c_int), ("frames", ctypes.c_int),
+        ("dst_merge_extra", ctypes.c_int),   # with dst_merge: a fifth tap slot read from ConvIO.extra_src (class (0,0) only)
     ]
 
 
@@ -54,6 +55,7 @@ class ConvIO(ctypes.Structure):
         ("bn1_y", ctypes.c_void_p), ("bn1_mean", ctypes.c_void_p), ("bn1_invstd", ctypes.c_void_p),
         ("bn1_partial", ctypes.c_void_p),
         ("relu_mask_bits", ctypes.c_void_p),   # [M][n_out/8] bytes: the ReLU mask as one bit per element (or NULL)
+        ("extra_src", ctypes.c_void_p),        # second gradient map of the fifth tap slot (dst_merge_extra) or NULL
     ]
 
 

@@ -36,6 +36,8 @@ struct ConvArgs {
   int dst_sub, dst_h, dst_w, dst_oh, dst_ow;
   int dst_merge_res0;       // residual only for class (0,0)
   int dst_merge;            // C > 0: N = 4*C, the four parity classes of a stride-2 data gradient in one launch (qtcnn.h)
+  long long extra_off;      // dst_merge with FIVE tap slots (ntaps == 5): elements from src to the second gradient map that
+                            // slot 4 reads at the window's first pixel (the downsample's gradient; class (0,0) only)
   FastDiv div_ohw, div_ow;
 #ifdef QT_KERNEL_PROF
   unsigned long long* prof;   // experiment build only (qt_set_igemm_prof): [workgroup][4] s_memrealtime stamps (10 ns)

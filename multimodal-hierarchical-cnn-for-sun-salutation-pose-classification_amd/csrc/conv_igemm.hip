@@ -167,6 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         mask = m3;
         f0 = (DGRAD ? pt : -pt) * p.frame_stride;
       }
+      if (p.dst_merge && p.ntaps == 5) mask |= (mask & 1u) << 4;   // the fifth slot reads the window's first pixel (of the second map)
       a_mask[i] = mask;
       const long long h0 = DGRAD ? (oh + p.pad) : (oh * p.stride - p.pad);
       const long long w0 = DGRAD ? (ow + p.pad) : (ow * p.stride - p.pad);
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
     const int c_lo = n0 / p.dst_merge, c_hi = (min(p.N, n0 + BN) - 1) / p.dst_merge;
     tmask = 0u;
     for (int c = c_lo; c <= c_hi; ++c) tmask |= ((c >> 1) ? 0x5u : 0x1u) * ((c & 1) ? 0x3u : 0x1u);
+    if (p.ntaps == 5 && c_lo == 0) tmask |= 0x10u;   // (the downsample's slot: class (0,0) only)
   }
   const int nk = __builtin_popcount(tmask & (p.ntaps >= 32 ? ~0u : (1u << p.ntaps) - 1u)) * p.KC / BK;
 
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 3 : 1) void conv_igemm_
         tap = nx_tap;
         toff = (long long)nx_kh * p.src_row_stride + (long long)nx_kw * p.src_pix_stride;
         if (p.KT > 1) toff += (long long)nx_kt * p.frame_stride;
+        if (p.dst_merge && nx_tap == 4) toff = p.extra_off;   // (uniform: the fifth slot of a merged launch, same pixel as slot 0)
         toff = (DGRAD ? -toff : toff) + nx_c0;
       }
 #pragma unroll
@@ -690,14 +693,14 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
   const int esz = d->dtype == QT_F32 ? 4 : 2;
   {
     ConvArgs a = {};
-    a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw; a.KW = d->kw; a.stride = d->stride;
+    a.M = (int)M; a.N = d->n_out; a.KC = d->k_per_tap; a.ntaps = d->kh * d->kw + (d->dst_merge_extra ? 1 : 0); a.KW = d->kw; a.stride = d->stride;
     a.pad = d->pad; a.quad = qt_quad_split(d->quad); a.dst_sub = d->dst_sub;
     a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
     a.src_img_stride = d->src_img_stride; a.src_row_stride = d->src_row_stride; a.src_pix_stride = d->src_pix_stride;
     a.dst_merge = d->dst_merge; a.dst_h = d->dst_h; a.dst_w = d->dst_w;
     if (!kt3 && qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
   }
-  const int rows = qt_cdiv(M, tile_m(M, d->n_out, (kt3 ? d->kt : 1) * d->kh * d->kw * d->k_per_tap * esz / kRowBytes));
+  const int rows = qt_cdiv(M, tile_m(M, d->n_out, ((kt3 ? d->kt : 1) * d->kh * d->kw + (d->dst_merge_extra ? 1 : 0)) * d->k_per_tap * esz / kRowBytes));
   return d->dst_merge > 0 ? rows * (d->n_out / d->dst_merge) : rows;  // merged parity classes: one row per class
 }
 
@@ -779,6 +782,15 @@ extern "C" int qt_conv2d_igemm(const qt_conv_desc* d, const qt_conv_io* io, void
   a.gridM = a.gridN = 0;
   a.dst_sub = d->dst_sub; a.dst_h = d->dst_h; a.dst_w = d->dst_w; a.dst_oh = d->dst_off_h; a.dst_ow = d->dst_off_w;
   a.dst_merge = d->dst_merge; a.dst_merge_res0 = d->dst_merge_res0;
+  a.extra_off = 0;
+  if (d->dst_merge_extra) {
+    QT_CHECK_ARG(d->dst_merge > 0 && io->extra_src && ((uintptr_t)io->extra_src % 16) == 0,
+                 "qt_conv2d_igemm: dst_merge_extra needs dst_merge and a 16-byte aligned extra_src");
+    const long long diff = (long long)((intptr_t)io->extra_src - (intptr_t)io->src);
+    QT_CHECK_ARG(diff % esz == 0, "qt_conv2d_igemm: extra_src is not element-aligned to src");
+    a.extra_off = diff / esz;
+    a.ntaps = 5;
+  }
   QT_CHECK_ARG(d->dst_merge == 0 || (d->dst_merge > 0 && d->dst_merge % 8 == 0 && d->dst_sub == 2 &&
                                      d->n_out == 4 * d->dst_merge && d->dst_off_h == 0 && d->dst_off_w == 0 &&
                                      !io->scale && !io->shift && d->mode == QT_CONV_FWD &&

@@ -659,8 +659,16 @@ extern "C" int qt_stem_bn_bwd_wgrad(int dtype, const void* dpooled, const unsign
   return QT_OK;
 }
 
+// conv_wgrad_s2.hip: the stride-2 convolutions of a transition block (3x3 / 2 pad 1, 1x1 / 2) on parity planes (bf16)
+bool qt_wgrad_s2_eligible(const qt_conv_desc* d);
+size_t qt_wgrad_s2_workspace_bytes(const qt_conv_desc* d);
+int qt_wgrad_s2_launch(const qt_conv_desc* d, const void* dy, const void* x, float* grad_oihw, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 extern "C" size_t qt_conv2d_wgrad_workspace_bytes(const qt_conv_desc* d) {
-  return d ? qt_wgrad_patch_workspace_bytes(d) : 0;
+  if (!d) return 0;
+  if (d->mode == QT_CONV_FWD && qt_wgrad_s2_eligible(d)) return qt_wgrad_s2_workspace_bytes(d);
+  return qt_wgrad_patch_workspace_bytes(d);
 }
 
 extern "C" int qt_conv2d_wgrad(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
@@ -673,8 +681,10 @@ extern "C" int qt_conv2d_wgrad_oihw(const qt_conv_desc* d, const void* dy, const
   QT_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)grad_oihw % 4) == 0 &&
                    ((uintptr_t)workspace % 16) == 0,
                "qt_conv2d_wgrad_oihw: misaligned pointer");
+  if (d->mode == QT_CONV_FWD && qt_wgrad_s2_eligible(d))
+    return qt_wgrad_s2_launch(d, dy, x, grad_oihw, workspace, workspace_bytes, stream);
   if (d->mode != QT_CONV_FWD || !qt_wgrad_patch_eligible(d)) {
-    qt_set_error("qt_conv2d_wgrad_oihw: only the shapes of the streaming kernel (bf16 3x3 stride 1)");
+    qt_set_error("qt_conv2d_wgrad_oihw: only the shapes of the streaming kernels (bf16: 3x3 stride 1; 3x3 / 1x1 stride 2)");
     return QT_ERR_UNSUPPORTED;
   }
   return qt_wgrad_patch_launch(d, dy, x, grad_oihw, workspace, workspace_bytes, 1, stream);

@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void wgrad_partial_sum_kernel(const float* __r
       const float4 v = red[g][col];
       o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
     }
-    if (!oihw) {
+    if (oihw != 1) {   // 0: accumulated into dw;  2: written as is
       reinterpret_cast<float4*>(dw)[jq] = o;
     } else {
       // j = (n*9 + tap)*KC + c  ->  OIHW element (n*KC + c)*9 + tap: the gradient is WRITTEN in the
@@ -766,6 +766,20 @@ int wp_variant() {
 }
 
 }  // namespace
+
+// dw = sum over `nsplit` ranges of part[range][filt] in a fixed order (conv_wgrad_s2.hip shares the reduction).  layout 0:
+// added to dw ([O][taps][I]); 1: written to OIHW from [O][9][I]; 2: written as is.
+int qt_wgrad_partial_sum_launch(const float* part, float* dw, size_t filt, int nsplit, int KC, int layout, hipStream_t stream) {
+  const int nq = (int)(filt / 4);
+  if (nsplit > 16)
+    hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, part, dw, nq, nsplit,
+                       (long long)nq, KC, layout);
+  else
+    hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, part, dw, nq, nsplit,
+                       (long long)nq, KC, layout);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
 
 // Smallest image width whose 3x3 stride-1 weight gradients take the streaming kernel
 // (0 = never; default 7 = every eligible layer of the model, the 7x7 stage included; env QTCNN_WGRAD_PATCH_MIN_W).

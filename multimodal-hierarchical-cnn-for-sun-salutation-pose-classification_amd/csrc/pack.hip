@@ -147,7 +147,10 @@ __device__ __forceinline__ void pack_tile(float* tile, const float* w, T* __rest
       const int i = it2 / TAPS, tap = it2 - i * TAPS;
       const float* t = tile + o * S + i * TAPS + tap;
       long long dst;
-      if (TAPS == 1 || !s2) {
+      if (TAPS == 1 && s2 == 4) {
+        // the fifth tap slot of the block's merged stride-2 operand (rows of class (0,0), five slots per row)
+        dst = ((long long)(i0 + i) * 5 + 4) * O + o0 + o;
+      } else if (TAPS == 1 || !s2) {
         dst = ((long long)(i0 + i) * TAPS + tap) * O + o0 + o;
       } else {
         // parity-class layout of pack_dgrad_s2_kernel: class (ph,pw), taps {1} / {2,0} per axis
@@ -161,6 +164,7 @@ __device__ __forceinline__ void pack_tile(float* tile, const float* w, T* __rest
         dst = base + ((long long)(i0 + i) * (nh * nw) + th * nw + tw) * O + o0 + o;
         // merged layout of pack_dgrad_s2m_kernel: rows (class, i), 2 x 2 tap slots (the unused ones stay zero)
         if (s2 == 2) dst = (((long long)cls * I + i0 + i) * 4 + th * 2 + tw) * O + o0 + o;
+        if (s2 == 3) dst = (((long long)cls * I + i0 + i) * 5 + th * 2 + tw) * O + o0 + o;   // (five slots per row, slot 4: see above)
       }
       PackPair<T>::store(dg + dst, t[0], t[S]);
     }
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(PackBatchArgs
   T* dg = static_cast<T*>(a.dgrad[it]);
   if (a.k[it] == 1) {
     const int tiles_i = I / PK_T1;
-    pack_tile<T, 1, PK_T1, PK_T1>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) * PK_T1, (b % tiles_i) * PK_T1, false, a.adam,
+    pack_tile<T, 1, PK_T1, PK_T1>(tile, a.w[it], fwd, dg, O, I, (b / tiles_i) * PK_T1, (b % tiles_i) * PK_T1, (int)a.s2[it], a.adam,
                                   a.g[it], a.m[it], a.v[it]);
   } else {
     const int tiles_i = I >> 5;
@@ -414,7 +418,9 @@ static int pack_batched(int dtype, const qt_pack_item* items, const qt_adam_item
                    "qt_adam_pack_weights_batched: item %d: optimizer state does not match the weight", j);
       a.g[j] = u.grad; a.m[j] = u.exp_avg; a.v[j] = u.exp_avg_sq;
     }
-    a.O[j] = q.O; a.I[j] = q.I; a.k[j] = (unsigned char)q.k; a.s2[j] = (unsigned char)(q.stride2_dgrad == 2 ? 2 : (q.stride2_dgrad ? 1 : 0));
+    a.O[j] = q.O; a.I[j] = q.I; a.k[j] = (unsigned char)q.k; a.s2[j] = (unsigned char)((q.stride2_dgrad >= 2 && q.stride2_dgrad <= 4) ? q.stride2_dgrad : (q.stride2_dgrad ? 1 : 0));
+    QT_CHECK_ARG(q.stride2_dgrad != 4 || q.k == 1, "qt_pack_weights_batched: item %d: stride2_dgrad = 4 is for 1x1 filters", j);
+    QT_CHECK_ARG(q.stride2_dgrad != 3 || q.k == 3, "qt_pack_weights_batched: item %d: stride2_dgrad = 3 is for 3x3 filters", j);
     a.first_block[j] = blocks;
     blocks += (q.O / te) * (q.I / te);
   }

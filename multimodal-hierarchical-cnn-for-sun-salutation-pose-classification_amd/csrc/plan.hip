@@ -34,6 +34,18 @@ static bool merged_s2_enabled() {
   return v != 0;
 }
 
+// QTCNN_DS_SLOT (default 1): where the generic tile runs the merged stride-2 data gradient (28x28 / 14x14 gradient maps), the
+// block's 1x1 / stride-2 downsample rides in the same launch as a fifth tap slot (qt_conv_desc.dst_merge_extra) instead of
+// a launch of its own whose output is then re-read as a residual (0: same-box A/B)
+static bool ds_slot_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("QTCNN_DS_SLOT");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+
 namespace {
 
 constexpr int kImg = 224;
@@ -61,6 +73,8 @@ struct ConvL {
   long long cls_off[4];
   int cls_kh[4], cls_kw[4];
   bool merged_dgrad = false;   // 3x3 stride 2: one 2x2-tap launch for all four parity classes
+  bool merged5 = false;        // ... whose operand has a fifth tap slot per row: the block's downsample (slot_conv) rides along
+  int slot_conv = -1;          // merged5: the downsample conv;  on the downsample: the conv1 whose operand holds its slot
 };
 
 struct Block {
@@ -234,6 +248,10 @@ void build_graph(qt_plan* p) {
         cd.hin = h; cd.hout = c1.hout; cd.bn = bnd;
         p->convs.push_back(cd);
         blk.ds = (int)p->convs.size() - 1;
+        if (stride == 2) {   // candidates for the shared data-gradient launch (decided in layout_workspace)
+          p->convs[blk.conv1].slot_conv = blk.ds;
+          p->convs[blk.ds].slot_conv = blk.conv1;
+        }
       }
       p->blocks.push_back(blk);
       h = c1.hout;
@@ -336,7 +354,13 @@ void layout_workspace(qt_plan* p) {
     // 3x3 stride 2: the data-gradient operand holds all four parity classes with 2 x 2 tap slots each (16/9 of the
     // filter, the unused slots zero: qt_pack_dgrad_s2_merged)
     c.merged_dgrad = i > 0 && c.stride == 2 && c.k == 3 && merged_s2_enabled();
-    c.w_dgrad = ws.take((c.merged_dgrad ? (size_t)16 * c.cout * c.cin : n) * es);
+    // (conv_pt.hip serves the 7x7 gradient map with its four-tap instantiation: no fifth slot there)
+    c.merged5 = c.merged_dgrad && c.slot_conv >= 0 && c.hout >= 14 && ds_slot_enabled();
+    if (c.k == 3 && c.slot_conv >= 0 && !c.merged5) {   // no shared launch: the downsample keeps its own data gradient
+      p->convs[c.slot_conv].slot_conv = -1;
+      c.slot_conv = -1;
+    }
+    c.w_dgrad = ws.take((c.merged5 ? (size_t)20 * c.cout * c.cin : c.merged_dgrad ? (size_t)16 * c.cout * c.cin : n) * es);
   }
   // f32 [O][kh][kw][I] weight-gradient scratch of all convs, contiguous: zeroed by ONE memset per backward
   p->dw_begin = ws.off;
@@ -587,12 +611,13 @@ struct Exec {
   };
   void igemm(const qt_conv_desc& d, const void* src, const void* w, void* dst, const float* scale, const float* shift,
              const void* res, const void* mask, float* stats, int relu, int kind = -1, const BnLink* links = nullptr,
-             int nlinks = 0, const unsigned char* mask_bits = nullptr) {
+             int nlinks = 0, const unsigned char* mask_bits = nullptr, const void* extra_src = nullptr) {
     if (!ok()) return;
     qt_conv_desc dd = d;
     dd.relu = relu;
     qt_conv_io io = {src, w, dst, scale, shift, res, mask, stats};
     io.relu_mask_bits = mask_bits;
+    io.extra_src = extra_src;
     for (int k = 0; k < nlinks && k < 2; ++k) {
       io.bwd_bn[k].y = links[k].y; io.bwd_bn[k].mean = links[k].mean;
       io.bwd_bn[k].invstd = links[k].invstd; io.bwd_bn[k].partial = links[k].partial;
@@ -628,7 +653,8 @@ struct Exec {
     const double fwd_pixels = d.mode == QT_CONV_FWD ? (double)d.out_h * d.out_w : (double)d.in_h * d.in_w;
     const bool stem = d.k_per_tap == 32 && d.kw == 1 && d.stride == 2 && d.n_out == 64;
     // (merged parity classes: 4 C outputs x 4 tap slots stand for the C outputs x 9 taps of the stride-2 conv)
-    const double k = stem ? 147.0 : (d.dst_merge ? 9.0 / 4.0 : (double)d.kh * d.kw) * d.k_per_tap;
+    // (... plus, with the fifth slot, the C x C outputs x 1 tap of the 1x1 downsample)
+    const double k = stem ? 147.0 : (d.dst_merge ? (d.dst_merge_extra ? 10.0 : 9.0) / 4.0 : (double)d.kh * d.kw) * d.k_per_tap;
     return 2.0 * imgs * fwd_pixels * k * d.n_out;
   }
   // algorithmic HBM bytes of a conv launch: source map, weights, destination and every per-pixel epilogue operand, each once
@@ -647,8 +673,8 @@ struct Exec {
     if (io.relu_mask_bits) per_pixel += 1.0 / (8.0 * es);
     if (io.bwd_bn[0].y) per_pixel += 1.0;
     if (io.bwd_bn[1].y) per_pixel += 1.0;
-    const double wgt = (double)d.kh * d.kw * d.k_per_tap * d.n_out * es;
-    return src + wgt + rows * ncol * es * per_pixel;
+    const double wgt = ((double)d.kh * d.kw + (d.dst_merge_extra ? 1.0 : 0.0)) * d.k_per_tap * d.n_out * es;
+    return src * (d.dst_merge_extra ? 2.0 : 1.0) + wgt + rows * ncol * es * per_pixel;
   }
   int begin_timed(double flops, int kind, void* on = nullptr, double bytes = 0.0) {
     if (!p->profiling) return -1;
@@ -747,6 +773,17 @@ struct Exec {
   }
 };
 
+// qt_pack_item.stride2_dgrad of a conv's data-gradient operand, and where it lives: a downsample whose data gradient rides
+// in its block's merged launch writes the fifth tap slot of conv1's operand instead of an operand of its own
+int dgrad_layout(const ConvL& c) {
+  if (c.stride != 2) return 0;
+  if (c.k == 1) return c.slot_conv >= 0 ? 4 : 1;
+  return c.merged5 ? 3 : (c.merged_dgrad ? 2 : 1);
+}
+size_t dgrad_operand(const qt_plan* p, const ConvL& c) {
+  return (c.k == 1 && c.slot_conv >= 0) ? p->convs[c.slot_conv].w_dgrad : c.w_dgrad;
+}
+
 unsigned long long weight_sig(const qt_plan* p, void* const* T) {
   unsigned long long h = 1469598103934665603ull;
   auto mix = [&](const void* ptr) { h = (h ^ (unsigned long long)(uintptr_t)ptr) * 1099511628211ull; };
@@ -770,7 +807,7 @@ int pack_weights(qt_plan* p, void* workspace, void* const* T, int for_backward, 
       if (i == 0)
         e.run(qt_pack_stem_weight(e.dt, e.tf(c.w), e.at(c.w_fwd), e.stem_taps(), stream));
       else
-        add(e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2 ? (c.merged_dgrad ? 2 : 1) : 0);
+        add(e.tf(c.w), e.at(c.w_fwd), for_backward ? e.at(dgrad_operand(p, c)) : nullptr, c.cout, c.cin, c.k, dgrad_layout(c));
     }
   }
   if (!p->lstm)  // (CnnLstm's classifier is a thin f32 product: no packed copy)
@@ -817,7 +854,7 @@ int adam_step(qt_plan* p, void* workspace, void* const* T, float* const* G, floa
   if (p->has_image)
     for (size_t i = 1; i < p->convs.size(); ++i) {
       const ConvL& c = p->convs[i];
-      if (int st = add(c.w, e.at(c.w_fwd), for_backward ? e.at(c.w_dgrad) : nullptr, c.cout, c.cin, c.k, c.stride == 2 ? (c.merged_dgrad ? 2 : 1) : 0)) return st;
+      if (int st = add(c.w, e.at(c.w_fwd), for_backward ? e.at(dgrad_operand(p, c)) : nullptr, c.cout, c.cin, c.k, dgrad_layout(c))) return st;
     }
   if (!p->lstm)
     if (int st = add(p->cls0.w, e.at(p->cls0.w_fwd), for_backward ? e.at(p->cls0.w_dgrad) : nullptr, p->cls0.out, p->cls0.in, 1, false))
@@ -1144,7 +1181,9 @@ struct Bwd : Exec {
       d.kh = d.kw = 2; d.stride = 1; d.pad = 0;
       d.src_pix_stride = c.cout; d.src_row_stride = c.hout * c.cout; d.src_img_stride = (long long)c.hout * c.hout * c.cout;
       d.dst_sub = 2; d.dst_h = d.dst_w = c.hin; d.dst_merge = c.cin; d.dst_merge_res0 = sparse ? 1 : 0;
-      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, 1, links, nlinks, mask_bits);
+      d.dst_merge_extra = c.merged5 ? 1 : 0;   // (+ the downsample's gradient map through the fifth tap slot)
+      igemm(d, at(c.gy), at(c.w_dgrad), dst, nullptr, nullptr, resid, mask, nullptr, 0, 1, links, nlinks, mask_bits,
+            c.merged5 ? at(p->convs[c.slot_conv].gy) : nullptr);
       return qt_conv2d_stats_rows(&d);
     }
     bool empty_class = false;
@@ -1190,6 +1229,14 @@ struct Bwd : Exec {
     fork();
     void* ws_ = wstream;
     const size_t n = stem ? (size_t)64 * 7 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
+    if (!stem && qt_conv2d_wgrad_workspace_bytes(&fwd_desc) > 0) {
+      // streaming kernels (3x3 stride 1; the stride-2 pair of a transition block): the fixed-order sum of the partial
+      // filters WRITES .grad in OIHW -- no scratch, no zero fill, no atomics
+      const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_, wgrad_bytes(c, fwd_desc));
+      run(qt_conv2d_wgrad_oihw(&fwd_desc, at(c.gy), src, gf(c.w), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
+      end_timed(slot, ws_);
+      return;
+    }
     if (!stem && c.k == 1) {  // [O][1][I] is already OIHW
       run(zero(gf(c.w), n * 4, ws_));
       const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_, wgrad_bytes(c, fwd_desc));
@@ -1198,12 +1245,6 @@ struct Bwd : Exec {
       return;
     }
     const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_, wgrad_bytes(c, fwd_desc));  // c.dw was zeroed at the start of this backward
-    if (!stem && qt_conv2d_wgrad_workspace_bytes(&fwd_desc) > 0) {
-      // streaming kernel: the partial-filter sum writes .grad in OIHW directly
-      run(qt_conv2d_wgrad_oihw(&fwd_desc, at(c.gy), src, gf(c.w), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
-      end_timed(slot, ws_);
-      return;
-    }
     run(qt_conv2d_wgrad_ws(&fwd_desc, at(c.gy), src, at<float>(c.dw), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
     end_timed(slot, ws_);
     if (stem)
@@ -1484,14 +1525,18 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       const void* resid = e.at(blk.gout);
       // the downsample's data gradient reaches one pixel in four: if nothing else reads the map densely (the region
       // heads below do), leave the rest unwritten and let only that parity class of conv1's data gradient add it
-      const bool sparse_ds = blk.ds >= 0 && c1.stride == 2 && c1.k == 3 && !(bi == 4 && p->attention) &&
+      const bool sparse_ds = blk.ds >= 0 && c1.stride == 2 && c1.k == 3 && !c1.merged5 && !(bi == 4 && p->attention) &&
                              !(bi == 6 && !p->standard && !p->attention);
       if (blk.ds >= 0) {
         const ConvL& cd = p->convs[blk.ds];
         e.bn_backward(cd, e.at(blk.gout), nullptr, rows_bn2 ? e.at<float>(p->stats_ds) : nullptr, rows_bn2);
         e.wgrad(cd, e.conv_desc(cd, QT_CONV_FWD), e.at(x), false);
-        e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr, nullptr, 0, sparse_ds);
-        resid = e.at(blk.gtmp);
+        if (c1.merged5) {   // the downsample's data gradient is the fifth tap slot of conv1's launch below: no map, no residual
+          resid = nullptr;
+        } else {
+          e.dgrad(cd, e.at(blk.gtmp), nullptr, nullptr, nullptr, 0, sparse_ds);
+          resid = e.at(blk.gtmp);
+        }
       }
       if (bi == 4 && p->attention) {  // layer2's output also feeds the two heads
         const ConvL& cq = p->convs[p->quad_conv];
@@ -1735,7 +1780,7 @@ extern "C" int qt_plan_init_workspace(qt_plan* p, void* workspace, void* stream)
   // the nine real taps only)
   for (const ConvL& c : p->convs)
     if (c.merged_dgrad && e2 == hipSuccess)
-      e2 = hipMemsetAsync(static_cast<unsigned char*>(workspace) + c.w_dgrad, 0, (size_t)16 * c.cout * c.cin * p->esz, s);
+      e2 = hipMemsetAsync(static_cast<unsigned char*>(workspace) + c.w_dgrad, 0, (size_t)(c.merged5 ? 20 : 16) * c.cout * c.cin * p->esz, s);
   hipError_t e3 = hipStreamSynchronize(s);  // `one` is a host temporary
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     qt_set_error("qt_plan_init_workspace: HIP error");

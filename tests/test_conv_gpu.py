@@ -342,6 +342,61 @@ def test_conv_wgrad_tile_kernel_shapes(cfg):
         assert rel_err(got, ref) <= 3e-5, name
 
 
+@pytest.mark.parametrize("cfg", [
+    (3, 64, 128, 56, 56, 3),     # layer2.0.conv1
+    (2, 64, 128, 56, 56, 1),     # layer2.0.downsample.0
+    (5, 128, 256, 28, 28, 3),    # layer3.0.conv1: 8 channel tiles share a range of positions
+    (5, 128, 256, 28, 28, 1),
+    (7, 256, 512, 14, 14, 3),    # layer4.0.conv1: 8x8 padded positions, a tile spans an image
+    (7, 256, 512, 14, 14, 1),
+    (33, 64, 64, 24, 24, 3),     # ragged batch against the ranges
+    (4, 64, 128, 20, 12, 3),     # rectangular map: row pitch != column count
+    (300, 64, 64, 8, 8, 3),      # more images than ranges: ranges cut through images, 5x5 padded positions per image
+    (1, 64, 64, 16, 16, 1),      # one image: most workgroups exit at once
+])
+def test_conv_wgrad_stride2_on_parity_planes(cfg):
+    """conv_wgrad_s2.hip: weight gradient of the stride-2 convolutions of a transition block (3x3 / 2 pad 1 and the 1x1 / 2
+    downsample) against torch.nn.grad.conv2d_weight; written to OIHW through NaN-filled scratch, bit-reproducible, and in
+    agreement with the generic kernel it replaces."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    dt = torch.bfloat16
+    B, Cin, Cout, H, W, k = cfg
+    pad = 1 if k == 3 else 0
+    Ho, Wo = H // 2, W // 2
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dt).float()
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, 2, pad)
+    xd, dyd = nhwc(x).to(dev, dt), nhwc(dy).to(dev, dt)
+    d = L.ConvDesc()
+    d.dtype, d.mode, d.batch = L.qt_dtype(dt), L.QT_CONV_FWD, B
+    d.in_h, d.in_w, d.out_h, d.out_w = H, W, Ho, Wo
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = Cin, Cout, k, k, 2, pad
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = H * W * Cin, W * Cin, Cin
+    lib.qt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = lib.qt_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nbytes > 0
+    outs = []
+    for _ in range(2):
+        wsb = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=dev)
+        g_oihw = torch.full((Cout, Cin, k, k), float("nan"), dtype=torch.float32, device=dev)
+        L.check(lib.qt_conv2d_wgrad_oihw(ctypes.byref(d), L.ptr(dyd), L.ptr(xd), L.ptr(g_oihw), L.ptr(wsb),
+                                         ctypes.c_size_t(nbytes), L.stream_ptr()), "qt_conv2d_wgrad_oihw")
+        torch.cuda.synchronize()
+        outs.append(g_oihw.cpu())
+    assert rel_err(outs[0], ref) <= 3e-5
+    assert torch.equal(outs[0], outs[1])
+    try:   # the generic kernel behind the same descriptor
+        lib.qt_set_wgrad_s2(0)
+        assert lib.qt_conv2d_wgrad_workspace_bytes(ctypes.byref(d)) == 0
+        dw = run_wgrad(L, dt, dyd, xd, B, (H, W), (Ho, Wo), Cin, Cout, k, k, 2, pad)
+    finally:
+        lib.qt_set_wgrad_s2(-1)
+    assert rel_err(dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2), outs[0]) <= 3e-5
+
+
 def test_conv_wgrad_streaming_kernel_channel_slice():
     """X is a 64-channel slice of a wider NHWC tensor (explicit strides), as the plan's views are."""
     dev = _dev()
@@ -459,6 +514,84 @@ def test_stride2_dgrad_merged_classes(dt, cfg):
         d.dst_merge_res0 = 0
     # bad shapes are refused
     d.n_out = 2 * Cin
+    assert lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()) != 0
+
+
+class PackItem(ctypes.Structure):   # qt_pack_item
+    _fields_ = [("w_oihw", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
+                ("O", ctypes.c_int), ("I", ctypes.c_int), ("k", ctypes.c_int), ("stride2_dgrad", ctypes.c_int)]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 56), (3, 128, 256, 28), (17, 64, 128, 56), (1, 64, 64, 12)])
+def test_stride2_dgrad_merged_with_the_downsample_as_fifth_tap_slot(dt, cfg):
+    """qt_conv_desc.dst_merge_extra: the data gradients of a transition block's conv1 (3x3 / 2) and of its downsample
+    (1x1 / 2; torchvision BasicBlock) in ONE launch -- the downsample's gradient map is read through a
+    fifth tap slot that only reaches parity class (0,0).  Operand packed by qt_pack_weights_batched (stride2_dgrad 3 + 4).
+    Values (+ residual, ReLU mask) against torch.nn.grad.conv2d_input of both convolutions, link sums against the
+    written gradient."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    B, Cin, Cout, H = cfg
+    Ho = H // 2
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cout * 9)) ** 0.5).to(dt).float()
+    wd = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cout) ** 0.5).to(dt).float()
+    dy = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    dyd = torch.randn(B, Cout, Ho, Ho, generator=g).to(dt).float()
+    other = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    act = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    ybn = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    mean = torch.randn(Cin, generator=g) * 0.1
+    invstd = torch.rand(Cin, generator=g) + 0.5
+    both = torch.nn.grad.conv2d_input((B, Cin, H, H), w, dy, 2, 1) + torch.nn.grad.conv2d_input((B, Cin, H, H), wd, dyd, 2, 0)
+
+    esz = 4 if dt == torch.float32 else 2
+    op = torch.zeros(20 * Cout * Cin, dtype=dt, device=dev)       # [4 Cin][5 slots][Cout]; unused slots stay zero
+    wdev, wddev = w.to(dev).contiguous(), wd.to(dev).contiguous()
+    items = (PackItem * 2)(PackItem(wdev.data_ptr(), None, op.data_ptr(), Cout, Cin, 3, 3),
+                           PackItem(wddev.data_ptr(), None, op.data_ptr(), Cout, Cin, 1, 4))
+    lib.qt_pack_weights_batched.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.check(lib.qt_pack_weights_batched(L.qt_dtype(dt), items, 2, L.stream_ptr()), "qt_pack_weights_batched")
+    # both gradient maps in ONE allocation (any two device tensors would do: the kernel takes their distance)
+    maps = torch.empty(2, B, Ho, Ho, Cout, dtype=dt, device=dev)
+    maps[0] = nhwc(dy).to(dev, dt)
+    maps[1] = nhwc(dyd).to(dev, dt)
+
+    d = L.ConvDesc()
+    d.dtype, d.mode, d.batch = L.qt_dtype(dt), L.QT_CONV_FWD, B
+    d.in_h = d.in_w = Ho
+    d.out_h = d.out_w = Ho
+    d.k_per_tap, d.n_out = Cout, 4 * Cin
+    d.kh, d.kw, d.stride, d.pad = 2, 2, 1, 0
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = Ho * Ho * Cout, Ho * Cout, Cout
+    d.dst_sub, d.dst_h, d.dst_w, d.dst_off_h, d.dst_off_w, d.dst_merge = 2, H, H, 0, 0, Cin
+    d.dst_merge_extra = 1
+    rows = lib.qt_conv2d_stats_rows(ctypes.byref(d))
+    assert rows > 0 and rows % 4 == 0
+    res = nhwc(other).to(dev, dt).view(-1, Cin)
+    msk = nhwc(act).to(dev, dt).view(-1, Cin)
+    yb = nhwc(ybn).to(dev, dt).view(-1, Cin)
+    md, isd = mean.to(dev), invstd.to(dev)
+    for with_ops in (False, True):
+        part = torch.full((rows, 2, Cin), float("nan"), dtype=torch.float32, device=dev)
+        out = torch.full((B * H * H, Cin), float("nan"), dtype=dt, device=dev)
+        io = L.ConvIO(maps[0].data_ptr(), L.ptr(op), L.ptr(out), None, None, L.ptr(res) if with_ops else None,
+                      L.ptr(msk) if with_ops else None, None,
+                      L.ptr(yb), L.ptr(md), L.ptr(isd), L.ptr(part), None, None, None, None)
+        io.extra_src = maps[1].data_ptr()
+        L.check(lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()), "qt_conv2d_igemm")
+        torch.cuda.synchronize()
+        got = out.float().cpu().view(B, H, H, Cin).permute(0, 3, 1, 2)
+        ref = (both + other) * (act > 0) if with_ops else both
+        assert rel_err(got, ref) <= TOL[dt], with_ops
+        sums = part.sum(0).cpu()
+        xhat = (ybn - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        assert rel_err(sums[0], got.sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+        assert rel_err(sums[1], (got * xhat).sum((0, 2, 3))) <= 1e-3 + TOL[dt]
+    # the slot needs its second map
+    io.extra_src = None
     assert lib.qt_conv2d_igemm(ctypes.byref(d), ctypes.byref(io), L.stream_ptr()) != 0
 
 
