@@ -526,12 +526,19 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    red0 = getattr(model, "_grad_sync", None)
+    if red0 is not None and not args.forward_only:
+        red0.measure_tail = True   # two events per join: how long the last compute kernel had been done before the all-reduce was
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     host_issue = time.perf_counter() - t0   # host time to ISSUE the K steps (no sync): close to `elapsed` = host-bound
     fence()
     elapsed = time.perf_counter() - t0
+    exposed_tail = None
+    if red0 is not None and red0.measure_tail:
+        red0.measure_tail = False
+        exposed_tail = red0.exposed_tail_ms()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -669,6 +676,10 @@ def main():
                    "gradient_bytes_per_step": int(red.bytes_reduced // max(1, steps_done)) if red is not None else None,
                    "buckets_per_step": getattr(red, "buckets_per_step", None),
                    "bucket_order": getattr(red, "bucket_log", None),
+                   "exposed_tail_ms_per_step": None if exposed_tail is None else round(exposed_tail, 3),
+                   "exposed_tail_note": "compute stream's wait for the communication stream at the end of backward (events on "
+                                        "the compute stream around the join, rank 0, mean over the timed steps): the part of "
+                                        "the gradient all-reduce that no kernel covered",
                    "average": "ncclAvg on the communication stream, joined once at the end of backward"}
     if dist is not None:
         dist.barrier()

@@ -625,6 +625,83 @@ __global__ __launch_bounds__(256) void wgrad_partial_sum_kernel(const float* __r
   }
 }
 
+// Light-footprint form (round 4).  The sum runs on the weight-gradient stream BESIDE the main stream's data-gradient kernels,
+// which hold 460-512 of a SIMD's 512 registers per lane and all but 4 KB of a CU's LDS: the kernel above (66 VGPRs, 4 KB of
+// LDS) cannot start a wave until one of their whole-CU workgroups retires, and in the step it measures 20-70 us per launch
+// against 9-14 us alone (13 launches: ~0.6 ms of the stream that bounds the backward pass).  Here a wave owns 8 float4
+// columns x 8 groups of ranges: lane = group * 8 + column adds ranges group, group + 8, ... in ascending order, four loads
+// in flight, and the eight groups are added by three butterfly exchanges in a fixed order -- no LDS, <= 32 VGPRs, so its
+// waves fit beside anything.  Bit-reproducible (fixed order), not bit-identical to the form above (another order).
+__global__ __launch_bounds__(256) void wgrad_partial_sum_light_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                      int nq, int nsplit, long long stride_q, int KC, int oihw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 7, grp = lane >> 3;
+  const int jq = (blockIdx.x * 4 + wave) * 8 + col;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (jq < nq) {
+    const float4* src = reinterpret_cast<const float4*>(part) + jq + (long long)grp * stride_q;
+    const long long step = 8 * stride_q;
+    int k = grp;
+    for (; k + 24 < nsplit; k += 32) {
+      const float4 v0 = src[0], v1 = src[step], v2 = src[2 * step], v3 = src[3 * step];
+      src += 4 * step;
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; k < nsplit; k += 8) {
+      const float4 v = src[0];
+      src += step;
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) {   // groups 0..7 -> every lane of a column holds the total (same order on every lane pair)
+    s.x += __shfl_xor(s.x, m, 64);
+    s.y += __shfl_xor(s.y, m, 64);
+    s.z += __shfl_xor(s.z, m, 64);
+    s.w += __shfl_xor(s.w, m, 64);
+  }
+  if (grp != 0 || jq >= nq) return;
+  if (oihw != 1) {
+    float4* o = reinterpret_cast<float4*>(dw) + jq;
+    if (oihw == 0) {
+      const float4 v = *o;
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *o = s;
+  } else {
+    const long long j = (long long)jq * 4;
+    const int c = (int)(j % KC);
+    const long long nt = j / KC;
+    const int tap = (int)(nt % 9);
+    const long long n = nt / 9;
+    float* dst = dw + (n * KC + c) * 9 + tap;
+    dst[0] = s.x; dst[9] = s.y; dst[18] = s.z; dst[27] = s.w;
+  }
+}
+
+// QTCNN_WGRAD_SUM (default 1 = the light form; 0 = the LDS form above, same-box A/B)
+int sum_partials(const float* part, float* dw, int nq, int nsplit, int KC, int layout, hipStream_t stream) {
+  static int light = -1;
+  if (light < 0) {
+    const char* e = getenv("QTCNN_WGRAD_SUM");
+    light = e ? atoi(e) : 1;
+  }
+  if (light)
+    hipLaunchKernelGGL(wgrad_partial_sum_light_kernel, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, part, dw, nq, nsplit,
+                       (long long)nq, KC, layout);
+  else if (nsplit > 16)
+    hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, part, dw, nq, nsplit,
+                       (long long)nq, KC, layout);
+  else
+    hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, part, dw, nq, nsplit,
+                       (long long)nq, KC, layout);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
 int g_wgrad_patch_min_w = -1;  // smallest image width routed here; 0 = off
 
 int min_w() {
@@ -672,16 +749,7 @@ int launch_patch(WPArgs a, size_t part_bytes, int oihw, hipStream_t stream) {
   if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), LDS, lds_limit_set)) return rc;
   hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(256 * G), LDS, stream, a);
   QT_CHECK_LAUNCH();
-  if (a.part) {
-    const int nq = (int)(filt / 4);
-    if (real_split > 16)
-      hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, a.part, a.dw, nq,
-                         real_split, (long long)nq, a.KC, oihw);
-    else
-      hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, a.part, a.dw, nq,
-                         real_split, (long long)nq, a.KC, oihw);
-    QT_CHECK_LAUNCH();
-  }
+  if (a.part) return sum_partials(a.part, a.dw, (int)(filt / 4), real_split, a.KC, oihw, stream);
   return QT_OK;
 }
 
@@ -743,16 +811,7 @@ int launch_tile(WPArgs a, size_t part_bytes, int oihw, hipStream_t stream) {
   int rc = g.nt == 8 ? launch_tile_nt<8>(t, g.lds, stream)
          : g.nt == 6 ? launch_tile_nt<6>(t, g.lds, stream) : launch_tile_nt<4>(t, g.lds, stream);
   if (rc != QT_OK) return rc;
-  if (a.part) {
-    const int nq = (int)(filt / 4);
-    if (real_split > 16)
-      hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, a.part, a.dw, nq,
-                         real_split, (long long)nq, a.KC, oihw);
-    else
-      hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, a.part, a.dw, nq,
-                         real_split, (long long)nq, a.KC, oihw);
-    QT_CHECK_LAUNCH();
-  }
+  if (a.part) return sum_partials(a.part, a.dw, (int)(filt / 4), real_split, a.KC, oihw, stream);
   return QT_OK;
 }
 
@@ -770,15 +829,7 @@ int wp_variant() {
 // dw = sum over `nsplit` ranges of part[range][filt] in a fixed order (conv_wgrad_s2.hip shares the reduction).  layout 0:
 // added to dw ([O][taps][I]); 1: written to OIHW from [O][9][I]; 2: written as is.
 int qt_wgrad_partial_sum_launch(const float* part, float* dw, size_t filt, int nsplit, int KC, int layout, hipStream_t stream) {
-  const int nq = (int)(filt / 4);
-  if (nsplit > 16)
-    hipLaunchKernelGGL(wgrad_partial_sum_kernel<32>, dim3(qt_cdiv(nq, 8)), dim3(256), 0, stream, part, dw, nq, nsplit,
-                       (long long)nq, KC, layout);
-  else
-    hipLaunchKernelGGL(wgrad_partial_sum_kernel<8>, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, part, dw, nq, nsplit,
-                       (long long)nq, KC, layout);
-  QT_CHECK_LAUNCH();
-  return QT_OK;
+  return sum_partials(part, dw, (int)(filt / 4), nsplit, KC, layout, stream);
 }
 
 // Smallest image width whose 3x3 stride-1 weight gradients take the streaming kernel

@@ -42,6 +42,11 @@ class GradBucketReducer:
         self.buckets_per_step = 0
         self._first_step_open = True
         self._avg_ok = dist.get_backend(process_group) == "nccl"
+        # exposed tail of the reduction: with `measure_tail` set, every join brackets its wait for the communication stream
+        # with two events on the compute stream -- the time the last compute kernel has been finished while the all-reduce
+        # of the last bucket(s) was still running.  (bench.py sets it for its timed steps and reports the mean.)
+        self.measure_tail = False
+        self._tail_events = []
 
     def __call__(self, bucket, phase, side_fence=None):
         if bucket is None:
@@ -49,7 +54,15 @@ class GradBucketReducer:
                 self._first_step_open = False
                 self.buckets_per_step = len(self.bucket_log)
             if self.comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                cur = torch.cuda.current_stream()
+                if self.measure_tail:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(cur)
+                    cur.wait_stream(self.comm_stream)
+                    b.record(cur)
+                    self._tail_events.append((a, b))
+                else:
+                    cur.wait_stream(self.comm_stream)
             return
         self.bytes_reduced += bucket.numel() * bucket.element_size()
         if self._first_step_open:
@@ -74,6 +87,14 @@ class GradBucketReducer:
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 bucket.div_(self.world)
+
+    def exposed_tail_ms(self):
+        """Mean wait of the compute stream at the join over the measured steps (synchronise first), None if none."""
+        if not self._tail_events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._tail_events]
+        self._tail_events = []
+        return sum(ms) / len(ms)
 
 
 def broadcast_state(model, src=0, process_group=None):

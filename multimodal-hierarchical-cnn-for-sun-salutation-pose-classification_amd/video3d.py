@@ -727,23 +727,39 @@ class _ClipFunction(torch.autograd.Function):
         if ctx.fwd_id != owner._fwd_counter:
             raise QtError("backward() after a later forward() on the same model: one set of activations is kept")
         with torch.cuda.device(dlogits.device):
-            grads = owner._backward_impl(dlogits.contiguous().float())
             sync = getattr(owner, "_grad_sync", None)
-            if sync is not None:
-                # data parallelism (dp.attach_data_parallel): there is no plan with phase buckets behind the clip models,
-                # so every gradient of the step is averaged over the ranks as ONE flat f32 bucket at the end of backward
-                live = [g for g in grads if g is not None]
-                if live:
-                    flat = torch.cat([g.reshape(-1).float() for g in live])
-                    sync(flat, 1)
-                    sync(None, 0)   # join: the compute stream sees the averaged bucket
-                    outs, off = [], 0
-                    for g in live:
-                        n = g.numel()
-                        outs.append(flat[off:off + n].view_as(g).to(g.dtype))
-                        off += n
-                    it = iter(outs)
-                    grads = [None if g is None else next(it) for g in grads]
+            if sync is None:
+                return (None, None, None, *owner._backward_impl(dlogits.contiguous().float()))
+            # Data parallelism (dp.attach_data_parallel).  There is no plan behind the clip models, but their backward still
+            # finishes its gradients in a known order: the dense head first, then the conv blocks from the last to the first.
+            # _backward_impl hands them over in buckets as they become final (emit): each bucket is packed into one flat f32
+            # tensor and its all-reduce starts on the communication stream while the earlier -- and by far heavier -- conv
+            # blocks are still running; only the last, small bucket (blocks 4..1 + LSTM: < 7 MB of the 40 MB) is exposed.
+            # (Round 3 reduced ONE bucket after the whole backward: the all-reduce was fully exposed.)  The gradients
+            # returned to autograd are views of the averaged buckets: no copy back.
+            buckets = []
+
+            def emit(g, names, phase):
+                live = [(n, g[n]) for n in names if g.get(n) is not None]
+                if not live:
+                    return
+                flat = torch.cat([t.reshape(-1).float() for _, t in live])
+                sync(flat, phase)
+                buckets.append((live, flat))
+
+            grads = owner._backward_impl(dlogits.contiguous().float(), emit)
+            sync(None, 0)   # join: the compute stream sees the averaged buckets
+            by_name = {}
+            for live, flat in buckets:
+                off = 0
+                for n, t in live:
+                    by_name[n] = flat[off:off + t.numel()].view_as(t).to(t.dtype)
+                    off += t.numel()
+            names = [n for n, _ in owner.named_parameters()]
+            missing = [n for n, g0 in zip(names, grads) if g0 is not None and n not in by_name]
+            if missing:
+                raise QtError(f"data parallelism: gradients of {missing} were produced but never handed over in a bucket")
+            grads = [None if g0 is None else by_name[n] for n, g0 in zip(names, grads)]
         return (None, None, None, *grads)
 
 
@@ -899,7 +915,8 @@ class Quadtree3DCNN(_ClipModel):
         self._saved = (blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, last, p) if keep else None
         return logits
 
-    def _backward_impl(self, dlogits):
+    def _backward_impl(self, dlogits, emit=None):
+        """emit(g, names, phase): data-parallel hand-over of the gradients `names` of dict g, final as of this point"""
         self.__dict__["_bwd_count"] = self.__dict__.get("_bwd_count", 0) + 1   # gradients exist: packed weights may go stale
         o, dt = ops(), self.compute_dtype
         blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, last, p = self._saved
@@ -932,6 +949,8 @@ class Quadtree3DCNN(_ClipModel):
                     g[f"numerical_lstm.{nm}_l{k}"] = lg[4 * k + j]
         else:
             side = None
+        if emit is not None:   # bucket 1: the dense head (the LSTM's gradients are still running on the side stream)
+            emit(g, [k for k in g if k.startswith(("classifier.", "numerical_projection."))], 1)
         # image branch
         C_last = blocks[-1].cout_p
         dout = torch.empty(t * B * h * w, C_last, dtype=dt, device=dev)
@@ -941,8 +960,12 @@ class Quadtree3DCNN(_ClipModel):
         for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), reversed(names)):
             dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
             g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
+            if emit is not None and nm == "conv3d_final_features":   # bucket 2: 7.1 M of the 9.9 M parameters, ready first
+                emit(g, [k for k in g if k.startswith(nm + ".")], 2)
         if side is not None:
             side.join(*lg)
+        if emit is not None:   # bucket 3: conv blocks 4 .. 1 and the LSTM (joined above)
+            emit(g, [k for k in g if k.startswith(("conv3d_block", "numerical_lstm."))], 4)
         self._saved = None
         return [g.get(n) for n, _ in self.named_parameters()]
 
@@ -1007,7 +1030,7 @@ class Ji3DCNN(_ClipModel):
         self._saved = (blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, p) if keep else None
         return logits
 
-    def _backward_impl(self, dlogits):
+    def _backward_impl(self, dlogits, emit=None):
         self.__dict__["_bwd_count"] = self.__dict__.get("_bwd_count", 0) + 1   # gradients exist: packed weights may go stale
         o, dt = ops(), self.compute_dtype
         blocks, saved_blocks, (t, h, w, B, T), fused, hid, lstm, p = self._saved
@@ -1025,6 +1048,8 @@ class Ji3DCNN(_ClipModel):
         lg = lstm.backward(dfused[:, 128:].contiguous(), B, T)
         for j, nm in enumerate(("weight_ih", "weight_hh", "bias_ih", "bias_hh")):
             g[f"numerical_lstm.{nm}_l0"] = lg[j]
+        if emit is not None:   # bucket 1: classifier + LSTM (this model's LSTM runs on the compute stream)
+            emit(g, list(g), 1)
         C_last = blocks[-1].cout_p
         dout = torch.empty(t * B * h * w, C_last, dtype=dt, device=dev)
         o.check(o.L.qt_avgpool_tb_bwd(_lib.qt_dtype(dt), _ptr(dfused), _ptr(dout), t, B, h * w, C_last, ld, 0, _lib.stream_ptr()),
@@ -1032,5 +1057,7 @@ class Ji3DCNN(_ClipModel):
         for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), ("visual_stream.4", "visual_stream.2", "visual_stream.0")):
             dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
             g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
+        if emit is not None:   # bucket 2: the three conv blocks (0.3 M parameters)
+            emit(g, [k for k in g if k.startswith("visual_stream.")], 2)
         self._saved = None
         return [g.get(n) for n, _ in self.named_parameters()]

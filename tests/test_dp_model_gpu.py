@@ -180,6 +180,13 @@ def test_bench_self_launches_its_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["forward"]["value"] > 0
+    # the line checks itself: two ranks really reduced the 25,986,028 trainable-and-used f32 gradients (SURVEY.md 8e:
+    # 103.9 MB per step) in the four phase buckets, and the join's exposed tail was measured
+    dpi = rec["data_parallel"]
+    assert dpi["world_size"] == 2 and dpi["backend"] == "gloo" and dpi["rccl"] is False
+    assert abs(dpi["gradient_bytes_per_step"] - 25986028 * 4) <= 64 * 4, dpi   # (views padded to 16 bytes)
+    assert dpi["buckets_per_step"] == 4 and [b[0] for b in dpi["bucket_order"]] == [1, 2, 4, 8]
+    assert dpi["exposed_tail_ms_per_step"] is not None and dpi["exposed_tail_ms_per_step"] >= 0
     # asking for 2 GPUs under a 1-rank launcher is an error, not a silent 1-GPU run
     env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
