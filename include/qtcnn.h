@@ -205,6 +205,10 @@ int qt_conv2d_igemm(const qt_conv_desc* desc, const qt_conv_io* io, void* stream
  * (Quadtree_from scratch/Quadtree_train.py:65).  `dw` must be zeroed (or hold the
  * running sum) by the caller: partial tiles are added with f32 atomics. */
 int qt_conv2d_wgrad(const qt_conv_desc* desc, const void* dy, const void* x, float* dw, void* stream);
+/* nn.Linear backward-weight (classifier.0 of the reference, Quadtree_from scratch/models.py:264-271): dw [out][in] f32 =
+ * dy^T x over `rows` rows of dy [rows][out] and x [rows][in] (both of `dtype`, dense), WRITTEN -- where every tile of dw
+ * has a single range of rows (always at rows <= 256) with plain stores, no zero fill and no atomics. */
+int qt_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, int rows, int out, int in, void* stream);
 /* Same, with a caller-owned scratch buffer of qt_conv2d_wgrad_workspace_bytes(desc) bytes (0: this
  * shape does not use one).  With it the streaming kernel writes one partial filter per range of
  * positions with plain stores and a second kernel adds them to `dw` in a fixed order: no atomics,
@@ -218,6 +222,12 @@ int qt_conv2d_wgrad_ws(const qt_conv_desc* desc, const void* dy, const void* x, 
  * no zero fill, no qt_unpack_conv_wgrad.  QT_ERR_UNSUPPORTED for every other shape. */
 int qt_conv2d_wgrad_oihw(const qt_conv_desc* desc, const void* dy, const void* x, float* grad_oihw, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same, with the sum of the partial filters enqueued on `sum_stream` (behind the kernel through an event) instead of the
+ * kernel's stream, which is then free for its next launch at once.  `workspace` must stay untouched until that sum has run:
+ * the caller orders its next use of it behind sum_stream (csrc/plan.hip alternates two workspaces).  sum_stream NULL or ==
+ * stream: qt_conv2d_wgrad_oihw. */
+int qt_conv2d_wgrad_oihw_on(const qt_conv_desc* desc, const void* dy, const void* x, float* grad_oihw, void* workspace,
+                            size_t workspace_bytes, void* stream, void* sum_stream);
 /* bf16 3x3 / stride 1 / pad 1 weight gradients of images at least `min_width` wide take the
  * streaming kernel (csrc/conv_wgrad_patch.hip: one workgroup accumulates all nine taps of a
  * 64x64 channel tile while dY and X stream through LDS once).  0 = never, <0 = default (7: every stage of the

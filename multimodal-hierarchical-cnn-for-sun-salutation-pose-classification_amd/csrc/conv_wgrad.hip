@@ -14,6 +14,8 @@
 // LDS image is XOR-swizzled per 32-byte block so both kinds of read are bank
 // conflict free.  The pixel axis is split over workgroups; partial tiles are
 // accumulated with global_atomic_add_f32 into the zero-initialised f32 gradient.
+#include <string.h>
+
 #include "qt_common.h"
 
 namespace {
@@ -35,6 +37,7 @@ struct WgradArgs {
   // jump over the KP - LB pixels other threads stage
   long long step1, wrap_w, wrap_h, adv_off;
   int adv_h, adv_w;
+  int overwrite;    // 1 (only with ksplit == 1): every element of dw has ONE producer -- plain stores, dw need not be zeroed
 };
 
 constexpr int KP = 64;  // pixels per K-step
@@ -313,8 +316,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = n0 + wm * (BMW / 2) + i * 16 + lg * 4 + r;
-          if (n < p.N && c_o < p.KC && tap_o < p.ntaps)
-            atomicAdd(p.dw + ((long long)n * p.ntaps + tap_o) * p.KC + c_o, acc[i][j][r]);
+          if (n < p.N && c_o < p.KC && tap_o < p.ntaps) {
+            float* o = p.dw + ((long long)n * p.ntaps + tap_o) * p.KC + c_o;
+            if (p.overwrite) *o = acc[i][j][r];   // (uniform)
+            else atomicAdd(o, acc[i][j][r]);
+          }
         }
       }
   }
@@ -349,6 +355,13 @@ int launch(WgradArgs a, hipStream_t stream) {
   if (a.ksplit >= 6 && (a.ksplit & 7)) a.ksplit = qt_cdiv(a.ksplit, 8) * 8;  // empty tail splits exit at once
   a.pix_per_split = pps;
   a.gtaps = gtaps;
+  if (a.overwrite && a.ksplit != 1) {   // several pixel ranges per tile: zero, then accumulate
+    if (hipMemsetAsync(a.dw, 0, (size_t)a.N * a.ntaps * a.KC * 4, stream) != hipSuccess) {
+      qt_set_error("qt_linear_wgrad: memset failed");
+      return QT_ERR_LAUNCH;
+    }
+    a.overwrite = 0;
+  }
   {
     constexpr int CPRBh = (STEM ? 256 : BNW) * ES / 16, LBh = KP / (256 / CPRBh);
     const long long srs = (long long)a.stride * a.x_row_stride, sps = (long long)a.stride * a.x_pix_stride;
@@ -690,6 +703,22 @@ extern "C" int qt_conv2d_wgrad_oihw(const qt_conv_desc* d, const void* dy, const
   return qt_wgrad_patch_launch(d, dy, x, grad_oihw, workspace, workspace_bytes, 1, stream);
 }
 
+static thread_local int g_wgrad_overwrite = 0;   // set around the one call of qt_linear_wgrad below
+
+// conv_wgrad_patch.hip: stream of the next partial-filter sum of this thread (NULL: the kernel's own)
+void qt_wgrad_set_sum_stream(void* s);
+
+// qt_conv2d_wgrad_oihw with the fixed-order sum of the partial filters on `sum_stream` (ordered behind the kernel by an
+// event): the kernel's stream goes straight on to its next launch.  The caller keeps `workspace` untouched until the sum has
+// run (e.g. two workspaces used in turn, the reuse ordered behind an event on sum_stream) -- csrc/plan.hip does.
+extern "C" int qt_conv2d_wgrad_oihw_on(const qt_conv_desc* d, const void* dy, const void* x, float* grad_oihw, void* workspace,
+                                       size_t workspace_bytes, void* stream, void* sum_stream) {
+  qt_wgrad_set_sum_stream(sum_stream);
+  const int st = qt_conv2d_wgrad_oihw(d, dy, x, grad_oihw, workspace, workspace_bytes, stream);
+  qt_wgrad_set_sum_stream(nullptr);
+  return st;
+}
+
 extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   QT_CHECK_ARG(d && dy && x && dw, "qt_conv2d_wgrad: null argument");
@@ -712,6 +741,7 @@ extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const v
   a.div_ohw = make_fastdiv((unsigned)(d->out_h * d->out_w));
   a.div_ow = make_fastdiv((unsigned)d->out_w);
   a.tilesN = a.tilesC = a.gtaps = a.ksplit = a.pix_per_split = 0;
+  a.overwrite = g_wgrad_overwrite;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (qt_wgrad_patch_eligible(d)) return qt_wgrad_patch_launch(d, dy, x, dw, workspace, workspace_bytes, 0, stream);
   // packed stem: 7 row taps x 32 elements form one 224-wide virtual channel axis
@@ -738,4 +768,21 @@ extern "C" int qt_conv2d_wgrad_ws(const qt_conv_desc* d, const void* dy, const v
   }
   if (stem) return launch<float, 64, 224, true>(a, s);
   return launch<float, 64, 64, false>(a, s);
+}
+
+// dw [out][in] f32 = dy^T x for a Linear layer, WRITTEN (not accumulated): the generic kernel on 1x1 images; when the grid has
+// a single range of rows per tile -- classifier.0 of the reference (Linear 5376 -> 2688 at 256 rows: 882 tiles;
+// /root/reference/Quadtree_from scratch/models.py:264-271) -- every element has one producer and is stored plainly: no
+// 58 MB zero fill, no float atomics; otherwise zero + accumulate as qt_conv2d_wgrad.
+extern "C" int qt_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, int rows, int out, int in, void* stream) {
+  QT_CHECK_ARG(dy && x && dw && rows > 0 && out > 0 && in > 0, "qt_linear_wgrad: bad argument");
+  qt_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.dtype = dtype; d.mode = QT_CONV_FWD; d.batch = rows; d.in_h = d.in_w = d.out_h = d.out_w = 1;
+  d.kh = d.kw = 1; d.stride = 1; d.pad = 0;
+  d.k_per_tap = in; d.n_out = out; d.src_pix_stride = in; d.src_row_stride = in; d.src_img_stride = in;
+  g_wgrad_overwrite = 1;
+  const int st = qt_conv2d_wgrad_ws(&d, dy, x, dw, nullptr, 0, stream);
+  g_wgrad_overwrite = 0;
+  return st;
 }

@@ -38,6 +38,8 @@ struct WPArgs {
   int N, KC, H, W, PW, PH, B, PP;
   int total;              // B * PP padded positions
   int pps, nsplit, tiles, tilesC;
+  int reg, regR, regS;    // region mode (qt_conv_desc.quad, tile kernel only): S x S regions of R x R per map, each with its
+                          // own pad row / column in front: reg = R + 1 is the pitch of a region on the padded grid (0: plain)
   int halo;               // rows of X kept on each side of a chunk: ceil32(PW + 1)
   int adv_h, adv_w;       // 32 positions = adv_h padded rows + adv_w columns
   FastDiv div_pp, div_pw;
@@ -340,10 +342,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_tile_kernel(WTArgs a) {
     for (int r = tid; r < tabn; r += 512) {
       const int rr = r >= p.PP ? r - p.PP : r;
       const int ph = (int)fdiv((unsigned)rr, p.div_pw), pw = rr - ph * p.PW;
-      const bool ok = ph >= 1 && pw >= 1;
       const unsigned nx = r >= p.PP ? (unsigned)p.x_is * 2u : 0u, ny = r >= p.PP ? (unsigned)p.dy_is * 2u : 0u;
-      tx[r] = ok ? (unsigned)((ph - 1) * p.x_rs + (pw - 1) * p.x_ps) * 2u + nx : kOob;
-      ty[r] = ok ? (unsigned)((ph - 1) * p.dy_rs + (pw - 1) * p.dy_ps) * 2u + ny : kOob;
+      bool ok;
+      unsigned xo, yo;
+      if (p.reg == 0) {
+        ok = ph >= 1 && pw >= 1;
+        xo = (unsigned)((ph - 1) * p.x_rs + (pw - 1) * p.x_ps);
+        yo = (unsigned)((ph - 1) * p.dy_rs + (pw - 1) * p.dy_ps);
+      } else {
+        // S x S regions of a shared map (the quadrant / sub-quadrant heads: Quadtree_from scratch/models.py:277-287, :62-78),
+        // every region behind its own pad row and column: a tap that leaves the region reads zeros, i.e. the zero halo at
+        // the seams.  X is the un-split map, dY the dense per-region images [map][S*S][R][R][N].
+        const int qr = ph / p.reg, qc = pw / p.reg;
+        const int rr2 = ph - qr * p.reg - 1, cc2 = pw - qc * p.reg - 1;
+        ok = rr2 >= 0 && cc2 >= 0;
+        xo = (unsigned)((qr * p.regR + rr2) * p.x_rs + (qc * p.regR + cc2) * p.x_ps);
+        yo = (unsigned)((((qr * p.regS + qc) * p.regR + rr2) * p.regR + cc2) * p.N);
+      }
+      tx[r] = ok ? xo * 2u + nx : kOob;
+      ty[r] = ok ? yo * 2u + ny : kOob;
     }
   }
 
@@ -682,14 +699,28 @@ __global__ __launch_bounds__(256) void wgrad_partial_sum_light_kernel(const floa
   }
 }
 
+// The sum of a weight gradient's partial filters may run on ANOTHER stream than the kernel that wrote them
+// (qt_conv2d_wgrad_oihw_on): set around that one call, consumed here.
+thread_local hipStream_t g_sum_stream = nullptr;
+
 // QTCNN_WGRAD_SUM (default 1 = the light form; 0 = the LDS form above, same-box A/B)
 int sum_partials(const float* part, float* dw, int nq, int nsplit, int KC, int layout, hipStream_t stream) {
+  if (g_sum_stream && g_sum_stream != stream) {   // behind the kernel on `stream`, but not in ITS queue
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess ||
+        hipStreamWaitEvent(g_sum_stream, ev, 0) != hipSuccess) {
+      qt_set_error("qt_conv2d_wgrad_oihw_on: HIP event error");
+      return QT_ERR_LAUNCH;
+    }
+    (void)hipEventDestroy(ev);   // (deferred until the event has completed)
+    stream = g_sum_stream;
+  }
   static int light = -1;
   if (light < 0) {
     const char* e = getenv("QTCNN_WGRAD_SUM");
     light = e ? atoi(e) : 1;
   }
-  if (light)
+  if (light && nsplit > 16)   // (few ranges: half of the light form's lanes would idle; r04v trace: 78-83 us against 45-71 in the step)
     hipLaunchKernelGGL(wgrad_partial_sum_light_kernel, dim3(qt_cdiv(nq, 32)), dim3(256), 0, stream, part, dw, nq, nsplit,
                        (long long)nq, KC, layout);
   else if (nsplit > 16)
@@ -828,6 +859,7 @@ int wp_variant() {
 
 // dw = sum over `nsplit` ranges of part[range][filt] in a fixed order (conv_wgrad_s2.hip shares the reduction).  layout 0:
 // added to dw ([O][taps][I]); 1: written to OIHW from [O][9][I]; 2: written as is.
+void qt_wgrad_set_sum_stream(void* s) { g_sum_stream = static_cast<hipStream_t>(s); }
 int qt_wgrad_partial_sum_launch(const float* part, float* dw, size_t filt, int nsplit, int KC, int layout, hipStream_t stream) {
   return sum_partials(part, dw, (int)(filt / 4), nsplit, KC, layout, stream);
 }
@@ -842,18 +874,37 @@ extern "C" void qt_set_wgrad_patch_variant(int v) { g_wp_variant = v < 0 ? 3 : v
 bool qt_wgrad_patch_eligible(const qt_conv_desc* d) {
   const int mw = min_w();
   if (mw <= 0 || d->dtype != QT_BF16) return false;
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->quad) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
   if (d->in_h != d->out_h || d->in_w != d->out_w) return false;
   if (d->n_out % 64 || d->k_per_tap % 64) return false;
   if (d->out_w < mw || d->out_w < 7 || d->out_h < 7 || d->out_w > 120) return false;
+  if (d->quad) {   // region heads: the tile kernel only (offset tables), square regions
+    const int S = qt_quad_split(d->quad);
+    if (wp_variant() != 3 || d->in_h != d->in_w) return false;
+    const int PW = S * (d->in_w + 1);
+    if (!tile_geometry(PW, PW * PW).nt) return false;
+    if ((long long)d->batch * PW * PW >= (1ll << 30)) return false;
+    if ((long long)d->batch * d->src_img_stride * 2 >= (1ll << 30) ||
+        (long long)d->batch * S * S * d->out_h * d->out_w * d->n_out * 2 >= (1ll << 30)) return false;
+    return true;
+  }
   if ((long long)d->batch * (d->out_h + 1) * (d->out_w + 1) >= (1ll << 30)) return false;
   return true;
+}
+
+// padded positions per image (per map in region mode)
+static int padded_positions(const qt_conv_desc* d) {
+  if (d->quad) {
+    const int PW = qt_quad_split(d->quad) * (d->in_w + 1);
+    return PW * PW;
+  }
+  return (d->out_h + 1) * (d->out_w + 1);
 }
 
 // bytes of partial-filter workspace the deterministic path wants for this convolution
 size_t qt_wgrad_patch_workspace_bytes(const qt_conv_desc* d) {
   if (!qt_wgrad_patch_eligible(d)) return 0;
-  const int total = d->batch * (d->out_h + 1) * (d->out_w + 1);
+  const int total = d->batch * padded_positions(d);
   int pps, nsplit;
   split_ranges(total, (d->n_out / 64) * (d->k_per_tap / 64), WP_CH * kGroups, &pps, &nsplit);
   return (size_t)nsplit * d->n_out * 9 * d->k_per_tap * 4;
@@ -867,9 +918,16 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   a.x = static_cast<const bf16_t*>(x);
   a.dw = dw;
   a.N = d->n_out; a.KC = d->k_per_tap; a.H = d->out_h; a.W = d->out_w; a.B = d->batch;
+  a.reg = a.regR = a.regS = 0;
   a.PW = a.W + 1; a.PH = a.H + 1; a.PP = a.PW * a.PH;
   a.x_is = d->src_img_stride; a.x_rs = d->src_row_stride; a.x_ps = d->src_pix_stride;
   a.dy_ps = a.N; a.dy_rs = a.W * a.N; a.dy_is = (long long)a.H * a.dy_rs;
+  if (d->quad) {   // (eligibility checked the tile kernel is on and fits)
+    a.regS = qt_quad_split(d->quad); a.regR = d->in_w; a.reg = a.regR + 1;
+    a.PW = a.PH = a.regS * a.reg; a.PP = a.PW * a.PH;
+    a.W = a.PW - 1; a.H = a.PH - 1;   // (what the geometry helpers below derive the pitch from)
+    a.dy_is = (long long)a.regS * a.regS * a.regR * a.regR * a.N;
+  }
   a.total = a.B * a.PP;
   a.halo = (a.PW + 1 + 31) / 32 * 32;
   a.div_pp = make_fastdiv((unsigned)a.PP);
@@ -894,6 +952,10 @@ int qt_wgrad_patch_launch(const qt_conv_desc* d, const void* dy, const void* x, 
   if (variant == 3) {
     const int rc = launch_tile(a, workspace_bytes, oihw, s);
     if (rc >= 0) return rc;
+  }
+  if (a.reg) {   // (the ring kernels walk plain images only)
+    qt_set_error("qt_conv2d_wgrad: region mode needs the tile-resident kernel");
+    return QT_ERR_UNSUPPORTED;
   }
   if (variant == 2) return launch_patch<2, 2, 8, 4>(a, workspace_bytes, oihw, s);
   return launch_patch<kGroups, 4, 16, 8>(a, workspace_bytes, oihw, s);

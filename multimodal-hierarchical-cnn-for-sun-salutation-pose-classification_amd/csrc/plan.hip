@@ -142,6 +142,13 @@ struct qt_plan {
   bool use_side = true;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // a THIRD stream for the thin, latency-bound kernels of the head's backward (bias column sums, the pose MLP's and
+  // classifier.3's small products: ~15 launches of 5-30 us that depend on each other but on no convolution).  On the
+  // weight-gradient stream they sat in front of classifier.0's / the quadrant conv's / layer4's weight gradients, and that
+  // stream bounds the backward pass (round 4): QTCNN_THIN_STREAM=0 puts them back there.
+  bool use_thin = true;
+  hipStream_t thin = nullptr;
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
   // state of the last forward
   int last_batch = 0, last_training = 0;
   unsigned long long last_seed = 0;
@@ -362,12 +369,28 @@ void layout_workspace(qt_plan* p) {
     }
     c.w_dgrad = ws.take((c.merged5 ? (size_t)20 * c.cout * c.cin : c.merged_dgrad ? (size_t)16 * c.cout * c.cin : n) * es);
   }
-  // f32 [O][kh][kw][I] weight-gradient scratch of all convs, contiguous: zeroed by ONE memset per backward
+  // f32 [O][kh][kw][I] weight-gradient scratch, contiguous, zeroed by ONE memset per backward.  Only the convolutions whose
+  // weight gradient is ACCUMULATED into it get a slice: the stem, the region heads (quadrant / sub-quadrant convs) and, in the
+  // f32 build, every 3x3.  The streaming kernels (bf16: 3x3 stride 1, the stride-2 pair of a transition block) write .grad
+  // in OIHW themselves and the generic 1x1 path zeroes .grad itself: round 3 zeroed 45 MB here per step, 11 MB of it needed.
   p->dw_begin = ws.off;
   for (size_t i = 0; i < p->convs.size(); ++i) {
     ConvL& c = p->convs[i];
     const size_t n = (i == 0) ? (size_t)64 * 8 * 32 : (size_t)c.cout * c.cin * c.k * c.k;
-    c.dw = ws.take(n * 4);
+    bool scratch = i == 0;
+    if (!scratch && c.k != 1) {   // (the descriptor Exec::conv_desc / quad_desc / region_desc hands to wgrad())
+      qt_conv_desc d;
+      memset(&d, 0, sizeof(d));
+      const int S = c.regions == 16 ? 4 : (c.regions == 4 ? 2 : 1);
+      d.dtype = p->d.dtype; d.mode = QT_CONV_FWD; d.batch = (int)B;
+      d.kh = d.kw = c.k; d.stride = c.stride; d.pad = c.pad;
+      d.in_h = d.in_w = c.hin; d.out_h = d.out_w = c.hout; d.k_per_tap = c.cin; d.n_out = c.cout;
+      d.quad = S == 1 ? 0 : S;
+      d.src_pix_stride = c.cin; d.src_row_stride = S * c.hin * c.cin;
+      d.src_img_stride = (long long)S * c.hin * S * c.hin * c.cin;
+      scratch = qt_conv2d_wgrad_workspace_bytes(&d) == 0;
+    }
+    c.dw = scratch ? ws.take(n * 4) : 0;
   }
   p->dw_end = ws.off;
   // one partial filter per range of positions (at most 256 workgroups x 64 x 9 x 64 f32, whatever the
@@ -467,7 +490,8 @@ struct Exec {
 
   // ---- plan-owned side stream: independent branches run next to the caller's stream ----
   void* wstream = nullptr;  // == stream when the side stream is off
-  bool forked = false;
+  void* tstream = nullptr;  // thin-kernel stream of the head's backward (== wstream when it is off)
+  bool forked = false, forked2 = false;
   void hip(hipError_t e, const char* what) {
     if (e != hipSuccess && status == QT_OK) {
       qt_set_error("%s: %s", what, hipGetErrorString(e));
@@ -483,6 +507,27 @@ struct Exec {
       hip(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming), "hipEventCreate");
     }
     if (ok()) wstream = p->side;
+    tstream = wstream;
+    if (!p->use_thin || !ok()) return;
+    if (!p->thin) {
+      hip(hipStreamCreateWithFlags(&p->thin, hipStreamNonBlocking), "hipStreamCreate");
+      hip(hipEventCreateWithFlags(&p->ev_fork2, hipEventDisableTiming), "hipEventCreate");
+      hip(hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (ok()) tstream = p->thin;
+  }
+  // everything enqueued on `stream` so far happens before later thin-stream work; returns the stream to launch on
+  void* fork_thin() {
+    if (!tstream || tstream == stream) return stream;
+    if (tstream == wstream) {   // (no third stream: the weight-gradient stream, as until round 3)
+      fork();
+      return wstream;
+    }
+    if (!ok()) return tstream;
+    hip(hipEventRecord(p->ev_fork2, static_cast<hipStream_t>(stream)), "hipEventRecord");
+    hip(hipStreamWaitEvent(p->thin, p->ev_fork2, 0), "hipStreamWaitEvent");
+    forked2 = true;
+    return tstream;
   }
   // everything enqueued on `stream` so far happens before later side-stream work
   void fork() {
@@ -497,6 +542,12 @@ struct Exec {
     hip(hipEventRecord(p->ev_join, p->side), "hipEventRecord");
     hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join, 0), "hipStreamWaitEvent");
     forked = false;
+  }
+  void join_thin() {
+    if (!forked2 || !p->thin || !ok()) return;
+    hip(hipEventRecord(p->ev_join2, p->thin), "hipEventRecord");
+    hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join2, 0), "hipStreamWaitEvent");
+    forked2 = false;
   }
 
   // run `body` with every launch going to the side stream (after fork()), with its own stats scratch
@@ -1244,6 +1295,12 @@ struct Bwd : Exec {
       end_timed(slot, ws_);
       return;
     }
+    if (!stem && c.dw == 0) {
+      // (the streaming kernels refused a shape they accepted when the plan was laid out, e.g. a QTCNN_* switch changed since)
+      status = QT_ERR_UNSUPPORTED;
+      qt_set_error("wgrad: no accumulation scratch was laid out for this convolution");
+      return;
+    }
     const int slot = begin_timed(conv_flops(fwd_desc), 2, ws_, wgrad_bytes(c, fwd_desc));  // c.dw was zeroed at the start of this backward
     run(qt_conv2d_wgrad_ws(&fwd_desc, at(c.gy), src, at<float>(c.dw), at(p->wgrad_part), p->wgrad_part_bytes, ws_));
     end_timed(slot, ws_);
@@ -1356,23 +1413,25 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     e.run(qt_relu_mask_scale(dt, e.at(p->dhidden), e.at(p->hidden), (long long)B * p->hidden_dim, drop_mul, stream));
     const qt_conv_desc lf = e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD);
     {
-      e.fork();
-      void* ss = e.wstream ? e.wstream : stream;
-      if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, B, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, ss));
+      // thin kernels (bias sums, classifier.3's product) -> the thin stream; classifier.0's weight gradient -> the
+      // weight-gradient stream, which then goes straight on to the quadrant conv's and layer4's
+      void* ts = e.fork_thin();
+      if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, B, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, ts));
       if (e.gf(p->cls3.w)) {
         memset(&g, 0, sizeof(g));
         g.M = p->cls3.out; g.N = p->cls3.in; g.K = B;
         g.a_dtype = QT_F32; g.b_dtype = dt; g.c_dtype = QT_F32;
         g.a_row_stride = 1; g.a_k_stride = p->cls3.out; g.b_row_stride = 1; g.b_k_stride = p->cls3.in;
         g.c_row_stride = p->cls3.in;
-        e.run(qt_gemm_small(&g, dlogits, e.at(p->hidden), nullptr, e.gf(p->cls3.w), ss));
+        e.run(qt_gemm_small(&g, dlogits, e.at(p->hidden), nullptr, e.gf(p->cls3.w), ts));
       }
       // ---- classifier.0: bias and weight gradients ----
-      if (e.gf(p->cls0.b)) e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, ss));
-      if (e.gf(p->cls0.w)) {
-        e.run(zero(e.gf(p->cls0.w), (size_t)p->cls0.in * p->cls0.out * 4, ss));
+      if (e.gf(p->cls0.b)) e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, ts));
+      e.fork();
+      void* ss = e.wstream ? e.wstream : stream;
+      if (e.gf(p->cls0.w)) {   // written, not accumulated: no 58 MB zero fill, no float atomics (one row range per tile)
         const int slot = e.begin_timed(e.conv_flops(lf), 2, ss);
-        e.run(qt_conv2d_wgrad(&lf, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), ss));
+        e.run(qt_linear_wgrad(dt, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), B, p->cls0.out, p->cls0.in, ss));
         e.end_timed(slot, ss);
       }
     }
@@ -1384,8 +1443,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // stream (behind classifier.0's weight gradient) while the main stream enters the backbone ----
     if (p->attention) {
       // numerical_mlp = Linear -> ReLU -> Dropout (models.py:43-46), output inside the fused matrix
-      e.fork();
-      void* ms = e.wstream ? e.wstream : stream;
+      void* ms = e.fork_thin();
       e.run(qt_relu_mask_cols(dt, e.at(p->dfused), e.at(p->fused), e.at<float>(p->dh1), B, p->mlp0.out, p->fused_ld,
                               p->mlp_col0, drop_mul, ms));
       if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, p->mlp0.out, p->mlp0.out, e.gf(p->mlp0.b), 0, ms));
@@ -1398,8 +1456,7 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), ms));
       }
     } else if (p->has_numerical) {
-      e.fork();
-      void* ms = e.wstream ? e.wstream : stream;
+      void* ms = e.fork_thin();
       const unsigned char* dz = e.at<unsigned char>(p->dfused) + (size_t)p->mlp_col0 * p->esz;
       if (e.gf(p->mlp1.b)) e.run(qt_col_sum(dt, dz, B, p->mlp1.out, p->fused_ld, e.gf(p->mlp1.b), 0, ms));
       if (e.gf(p->mlp1.w)) {
@@ -1432,18 +1489,14 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       const ConvL& cq = p->convs[p->quad_conv];
       const ConvL& cs = p->convs[p->sub_conv];
       e.run(qt_region_avgpool_bwd(dt, e.at(p->dfused), dt, e.at(cq.y), e.at(cq.gy), B, 2, 196, 128, p->fused_ld, 512, stream));
-      if (e.gf(cq.bias)) {
-        e.fork();
-        e.run(qt_col_sum(dt, e.at(cq.gy), (long long)B * 4 * 196, 128, 128, e.gf(cq.bias), 0, e.wstream ? e.wstream : stream));
-      }
+      if (e.gf(cq.bias)) e.run(qt_col_sum(dt, e.at(cq.gy), (long long)B * 4 * 196, 128, 128, e.gf(cq.bias), 0, e.fork_thin()));
       e.wgrad(cq, e.region_desc(cq, 2, QT_CONV_FWD), e.at(p->blocks[3].out), false);
       // ---- attention gate (models.py:81-89), then the sub-quadrant vectors ----
       e.run(qt_attention_gate_bwd(dt, e.at(p->dfused), e.at<float>(p->vsub), e.at<float>(p->att_act),
                                   e.at<float>(p->att_alpha), e.tf(p->att0.w), e.tf(p->att2.w), e.at<float>(p->att_ds),
                                   e.at<float>(p->att_dpre), e.at<float>(p->dvsub), B, p->fused_ld, 512 + 4 * 128, stream));
       {
-        e.fork();
-        void* as = e.wstream ? e.wstream : stream;
+        void* as = e.fork_thin();
         const int rows = B * 16;
         if (e.gf(p->att0.w)) {  // [32][64] = dpre^T v
           memset(&g, 0, sizeof(g));
@@ -1463,20 +1516,14 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         if (e.gf(p->att2.b)) e.run(qt_col_sum(QT_F32, e.at(p->att_ds), rows, 1, 1, e.gf(p->att2.b), 0, as));
       }
       e.run(qt_region_avgpool_bwd(dt, e.at(p->dvsub), QT_F32, e.at(cs.y), e.at(cs.gy), B, 4, 49, 64, 16 * 64, 0, stream));
-      if (e.gf(cs.bias)) {
-        e.fork();
-        e.run(qt_col_sum(dt, e.at(cs.gy), (long long)B * 16 * 49, 64, 64, e.gf(cs.bias), 0, e.wstream ? e.wstream : stream));
-      }
+      if (e.gf(cs.bias)) e.run(qt_col_sum(dt, e.at(cs.gy), (long long)B * 16 * 49, 64, 64, e.gf(cs.bias), 0, e.fork_thin()));
       e.wgrad(cs, e.region_desc(cs, 4, QT_CONV_FWD), e.at(p->blocks[3].out), false);
     }
     // ---- quadrant head (weights are trainable in every variant) ----
     if (p->has_image && !p->standard && !p->attention) {
       const ConvL& cq = p->convs[p->quad_conv];
       e.run(qt_quad_pool_bwd(dt, e.at(p->dfused), e.at(p->q), e.at(p->dq), B, p->fused_ld, 512, stream));
-      if (e.gf(cq.bias)) {
-        e.fork();
-        e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, e.wstream ? e.wstream : stream));
-      }
+      if (e.gf(cq.bias)) e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, e.fork_thin()));
       e.wgrad(cq, e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), false);
     }
   }
@@ -1624,6 +1671,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   if ((phases & QT_BWD_LAYER1) || !backbone_grads) {
     e.forked = e.forked || (p->side != nullptr && e.wstream == p->side);
     e.join();
+    e.forked2 = e.forked2 || (p->thin != nullptr && e.tstream == p->thin);   // (thin work of an earlier phase call)
+    e.join_thin();
   }
   return e.status;
 }
@@ -1651,6 +1700,8 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
   p->d = *desc;
   p->esz = desc->dtype == QT_F32 ? 4 : 2;
   if (const char* v = getenv("QTCNN_SIDE_STREAM")) p->use_side = atoi(v) != 0;
+  if (const char* v = getenv("QTCNN_THIN_STREAM")) p->use_thin = atoi(v) != 0;
+  if (!p->use_side) p->use_thin = false;
   build_graph(p);
   layout_workspace(p);
   *out = p;
@@ -1660,6 +1711,9 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
 extern "C" void qt_plan_destroy(qt_plan* p) {
   if (!p) return;
   if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->thin) (void)hipStreamDestroy(p->thin);
+  if (p->ev_fork2) (void)hipEventDestroy(p->ev_fork2);
+  if (p->ev_join2) (void)hipEventDestroy(p->ev_join2);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
@@ -1765,6 +1819,16 @@ extern "C" int qt_plan_side_fence(qt_plan* p, void* waiting_stream) {
     return QT_ERR_LAUNCH;
   }
   (void)hipEventDestroy(ev);  // destruction is deferred until the event has completed
+  if (p->thin && p->use_thin) {   // the head's thin kernels (bias sums, pose-MLP gradients) run on a stream of their own
+    hipEvent_t ev2;
+    if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(ev2, p->thin) != hipSuccess ||
+        hipStreamWaitEvent(static_cast<hipStream_t>(waiting_stream), ev2, 0) != hipSuccess) {
+      qt_set_error("qt_plan_side_fence: HIP error");
+      return QT_ERR_LAUNCH;
+    }
+    (void)hipEventDestroy(ev2);
+  }
   return QT_OK;
 }
 

@@ -397,6 +397,29 @@ def test_conv_wgrad_stride2_on_parity_planes(cfg):
     assert rel_err(dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2), outs[0]) <= 3e-5
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(256, 2688, 5376), (37, 2688, 5376), (64, 128, 192), (4096, 128, 64)])
+def test_linear_wgrad_is_written_not_accumulated(dt, cfg):
+    """qt_linear_wgrad: nn.Linear backward-weight into a NaN-filled destination (plain stores where a tile has one row range --
+    classifier.0 at batch 256 -- zero + atomics for the long-row case), against dy^T x in f64."""
+    dev = _dev()
+    L = pkg("_lib")
+    rows, out, inn = cfg
+    g = torch.Generator().manual_seed(23)
+    dy = torch.randn(rows, out, generator=g).to(dt).float()
+    x = torch.randn(rows, inn, generator=g).to(dt).float()
+    ref = (dy.double().t() @ x.double()).float()
+    dw = torch.full((out, inn), float("nan"), dtype=torch.float32, device=dev)
+    L.lib().qt_linear_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    dyd, xd = dy.to(dev, dt), x.to(dev, dt)
+    for _ in range(2):   # (a second call over the first result: nothing is accumulated)
+        L.check(L.lib().qt_linear_wgrad(L.qt_dtype(dt), L.ptr(dyd), L.ptr(xd), L.ptr(dw), rows, out, inn,
+                                        L.stream_ptr()), "qt_linear_wgrad")
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), ref) <= 3e-5
+
+
 def test_conv_wgrad_streaming_kernel_channel_slice():
     """X is a 64-channel slice of a wider NHWC tensor (explicit strides), as the plan's views are."""
     dev = _dev()
@@ -435,6 +458,52 @@ def test_quadrant_wgrad(dt):
                    strides=(14 * 14 * C, 14 * C, C))
     got = dw.cpu().view(N, 3, 3, C).permute(0, 3, 1, 2)
     assert rel_err(got, ref) <= 3e-5
+
+
+@pytest.mark.parametrize("cfg", [(3, 256, 128, 7, 2), (37, 256, 128, 7, 2), (5, 128, 128, 14, 2), (9, 128, 64, 7, 4)])
+def test_region_wgrad_on_the_tile_kernel(cfg):
+    """The region heads' weight gradient (quadrant conv of QuadtreeCNN, Quadtree_from scratch/models.py:234-238,284-287;
+    quadrant / sub-quadrant convs of AttentionHierarchicalCNN, :62-78) on the tile-resident streaming kernel: every region sits
+    behind its own pad row and column on the padded grid, so the zero halo at the seams is the ordinary padding.  Written to
+    OIHW through NaN-filled scratch, bit-reproducible, against per-region torch.nn.grad.conv2d_weight and the generic kernel."""
+    dev = _dev()
+    L = pkg("_lib")
+    lib = L.lib()
+    dt = torch.bfloat16
+    B, C, N, R, S = cfg
+    H = S * R
+    g = torch.Generator().manual_seed(29)
+    base = torch.randn(B, C, H, H, generator=g).to(dt).float()
+    dyq = torch.randn(B, S * S, N, R, R, generator=g).to(dt).float()
+    ref = sum(torch.nn.grad.conv2d_weight(base[:, :, (q // S) * R:(q // S + 1) * R, (q % S) * R:(q % S + 1) * R].contiguous(),
+                                          (N, C, 3, 3), dyq[:, q].contiguous(), 1, 1) for q in range(S * S))
+    dyd = dyq.permute(0, 1, 3, 4, 2).contiguous().to(dev, dt)
+    xd = nhwc(base).to(dev, dt)
+    d = L.ConvDesc()
+    d.dtype, d.mode, d.batch = L.qt_dtype(dt), L.QT_CONV_FWD, B
+    d.in_h = d.in_w = d.out_h = d.out_w = R
+    d.k_per_tap, d.n_out, d.kh, d.kw, d.stride, d.pad = C, N, 3, 3, 1, 1
+    d.src_img_stride, d.src_row_stride, d.src_pix_stride = H * H * C, H * C, C
+    d.quad = S
+    lib.qt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = lib.qt_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nbytes > 0
+    outs = []
+    for _ in range(2):
+        wsb = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=dev)
+        g_oihw = torch.full((N, C, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+        L.check(lib.qt_conv2d_wgrad_oihw(ctypes.byref(d), L.ptr(dyd), L.ptr(xd), L.ptr(g_oihw), L.ptr(wsb),
+                                         ctypes.c_size_t(nbytes), L.stream_ptr()), "qt_conv2d_wgrad_oihw")
+        torch.cuda.synchronize()
+        outs.append(g_oihw.cpu())
+    assert rel_err(outs[0], ref) <= 3e-5
+    assert torch.equal(outs[0], outs[1])
+    try:   # the generic kernel behind the same descriptor
+        lib.qt_set_wgrad_patch_min_width(0)
+        dw = run_wgrad(L, dt, dyd, xd, B, (R, R), (R, R), C, N, 3, 3, 1, 1, quad=S, strides=(H * H * C, H * C, C))
+    finally:
+        lib.qt_set_wgrad_patch_min_width(-1)
+    assert rel_err(dw.cpu().view(N, 3, 3, C).permute(0, 3, 1, 2), outs[0]) <= 3e-5
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
