@@ -142,13 +142,6 @@ struct qt_plan {
   bool use_side = true;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // a THIRD stream for the thin, latency-bound kernels of the head's backward (bias column sums, the pose MLP's and
-  // classifier.3's small products: ~15 launches of 5-30 us that depend on each other but on no convolution).  On the
-  // weight-gradient stream they sat in front of classifier.0's / the quadrant conv's / layer4's weight gradients, and that
-  // stream bounds the backward pass (round 4): QTCNN_THIN_STREAM=0 puts them back there.
-  bool use_thin = true;
-  hipStream_t thin = nullptr;
-  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
   // state of the last forward
   int last_batch = 0, last_training = 0;
   unsigned long long last_seed = 0;
@@ -490,8 +483,7 @@ struct Exec {
 
   // ---- plan-owned side stream: independent branches run next to the caller's stream ----
   void* wstream = nullptr;  // == stream when the side stream is off
-  void* tstream = nullptr;  // thin-kernel stream of the head's backward (== wstream when it is off)
-  bool forked = false, forked2 = false;
+  bool forked = false;
   void hip(hipError_t e, const char* what) {
     if (e != hipSuccess && status == QT_OK) {
       qt_set_error("%s: %s", what, hipGetErrorString(e));
@@ -507,27 +499,6 @@ struct Exec {
       hip(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming), "hipEventCreate");
     }
     if (ok()) wstream = p->side;
-    tstream = wstream;
-    if (!p->use_thin || !ok()) return;
-    if (!p->thin) {
-      hip(hipStreamCreateWithFlags(&p->thin, hipStreamNonBlocking), "hipStreamCreate");
-      hip(hipEventCreateWithFlags(&p->ev_fork2, hipEventDisableTiming), "hipEventCreate");
-      hip(hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming), "hipEventCreate");
-    }
-    if (ok()) tstream = p->thin;
-  }
-  // everything enqueued on `stream` so far happens before later thin-stream work; returns the stream to launch on
-  void* fork_thin() {
-    if (!tstream || tstream == stream) return stream;
-    if (tstream == wstream) {   // (no third stream: the weight-gradient stream, as until round 3)
-      fork();
-      return wstream;
-    }
-    if (!ok()) return tstream;
-    hip(hipEventRecord(p->ev_fork2, static_cast<hipStream_t>(stream)), "hipEventRecord");
-    hip(hipStreamWaitEvent(p->thin, p->ev_fork2, 0), "hipStreamWaitEvent");
-    forked2 = true;
-    return tstream;
   }
   // everything enqueued on `stream` so far happens before later side-stream work
   void fork() {
@@ -542,12 +513,6 @@ struct Exec {
     hip(hipEventRecord(p->ev_join, p->side), "hipEventRecord");
     hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join, 0), "hipStreamWaitEvent");
     forked = false;
-  }
-  void join_thin() {
-    if (!forked2 || !p->thin || !ok()) return;
-    hip(hipEventRecord(p->ev_join2, p->thin), "hipEventRecord");
-    hip(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->ev_join2, 0), "hipStreamWaitEvent");
-    forked2 = false;
   }
 
   // run `body` with every launch going to the side stream (after fork()), with its own stats scratch
@@ -1413,9 +1378,9 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     e.run(qt_relu_mask_scale(dt, e.at(p->dhidden), e.at(p->hidden), (long long)B * p->hidden_dim, drop_mul, stream));
     const qt_conv_desc lf = e.linear_desc(p->cls0.in, p->cls0.out, QT_CONV_FWD);
     {
-      // thin kernels (bias sums, classifier.3's product) -> the thin stream; classifier.0's weight gradient -> the
-      // weight-gradient stream, which then goes straight on to the quadrant conv's and layer4's
-      void* ts = e.fork_thin();
+      e.fork();
+      void* ss = e.wstream ? e.wstream : stream;
+      void* ts = ss;
       if (e.gf(p->cls3.b)) e.run(qt_col_sum(QT_F32, dlogits, B, p->cls3.out, p->cls3.out, e.gf(p->cls3.b), 0, ts));
       if (e.gf(p->cls3.w)) {
         memset(&g, 0, sizeof(g));
@@ -1427,8 +1392,6 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       }
       // ---- classifier.0: bias and weight gradients ----
       if (e.gf(p->cls0.b)) e.run(qt_col_sum(dt, e.at(p->dhidden), B, p->cls0.out, p->cls0.out, e.gf(p->cls0.b), 0, ts));
-      e.fork();
-      void* ss = e.wstream ? e.wstream : stream;
       if (e.gf(p->cls0.w)) {   // written, not accumulated: no 58 MB zero fill, no float atomics (one row range per tile)
         const int slot = e.begin_timed(e.conv_flops(lf), 2, ss);
         e.run(qt_linear_wgrad(dt, e.at(p->dhidden), e.at(p->fused), e.gf(p->cls0.w), B, p->cls0.out, p->cls0.in, ss));
@@ -1443,7 +1406,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // stream (behind classifier.0's weight gradient) while the main stream enters the backbone ----
     if (p->attention) {
       // numerical_mlp = Linear -> ReLU -> Dropout (models.py:43-46), output inside the fused matrix
-      void* ms = e.fork_thin();
+      e.fork();
+      void* ms = e.wstream ? e.wstream : stream;
       e.run(qt_relu_mask_cols(dt, e.at(p->dfused), e.at(p->fused), e.at<float>(p->dh1), B, p->mlp0.out, p->fused_ld,
                               p->mlp_col0, drop_mul, ms));
       if (e.gf(p->mlp0.b)) e.run(qt_col_sum(QT_F32, e.at(p->dh1), B, p->mlp0.out, p->mlp0.out, e.gf(p->mlp0.b), 0, ms));
@@ -1456,7 +1420,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         e.run(qt_gemm_small(&g, e.at(p->dh1), numerical, nullptr, e.gf(p->mlp0.w), ms));
       }
     } else if (p->has_numerical) {
-      void* ms = e.fork_thin();
+      e.fork();
+      void* ms = e.wstream ? e.wstream : stream;
       const unsigned char* dz = e.at<unsigned char>(p->dfused) + (size_t)p->mlp_col0 * p->esz;
       if (e.gf(p->mlp1.b)) e.run(qt_col_sum(dt, dz, B, p->mlp1.out, p->fused_ld, e.gf(p->mlp1.b), 0, ms));
       if (e.gf(p->mlp1.w)) {
@@ -1489,14 +1454,18 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       const ConvL& cq = p->convs[p->quad_conv];
       const ConvL& cs = p->convs[p->sub_conv];
       e.run(qt_region_avgpool_bwd(dt, e.at(p->dfused), dt, e.at(cq.y), e.at(cq.gy), B, 2, 196, 128, p->fused_ld, 512, stream));
-      if (e.gf(cq.bias)) e.run(qt_col_sum(dt, e.at(cq.gy), (long long)B * 4 * 196, 128, 128, e.gf(cq.bias), 0, e.fork_thin()));
+      if (e.gf(cq.bias)) {
+        e.fork();
+        e.run(qt_col_sum(dt, e.at(cq.gy), (long long)B * 4 * 196, 128, 128, e.gf(cq.bias), 0, e.wstream ? e.wstream : stream));
+      }
       e.wgrad(cq, e.region_desc(cq, 2, QT_CONV_FWD), e.at(p->blocks[3].out), false);
       // ---- attention gate (models.py:81-89), then the sub-quadrant vectors ----
       e.run(qt_attention_gate_bwd(dt, e.at(p->dfused), e.at<float>(p->vsub), e.at<float>(p->att_act),
                                   e.at<float>(p->att_alpha), e.tf(p->att0.w), e.tf(p->att2.w), e.at<float>(p->att_ds),
                                   e.at<float>(p->att_dpre), e.at<float>(p->dvsub), B, p->fused_ld, 512 + 4 * 128, stream));
       {
-        void* as = e.fork_thin();
+        e.fork();
+        void* as = e.wstream ? e.wstream : stream;
         const int rows = B * 16;
         if (e.gf(p->att0.w)) {  // [32][64] = dpre^T v
           memset(&g, 0, sizeof(g));
@@ -1516,14 +1485,20 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
         if (e.gf(p->att2.b)) e.run(qt_col_sum(QT_F32, e.at(p->att_ds), rows, 1, 1, e.gf(p->att2.b), 0, as));
       }
       e.run(qt_region_avgpool_bwd(dt, e.at(p->dvsub), QT_F32, e.at(cs.y), e.at(cs.gy), B, 4, 49, 64, 16 * 64, 0, stream));
-      if (e.gf(cs.bias)) e.run(qt_col_sum(dt, e.at(cs.gy), (long long)B * 16 * 49, 64, 64, e.gf(cs.bias), 0, e.fork_thin()));
+      if (e.gf(cs.bias)) {
+        e.fork();
+        e.run(qt_col_sum(dt, e.at(cs.gy), (long long)B * 16 * 49, 64, 64, e.gf(cs.bias), 0, e.wstream ? e.wstream : stream));
+      }
       e.wgrad(cs, e.region_desc(cs, 4, QT_CONV_FWD), e.at(p->blocks[3].out), false);
     }
     // ---- quadrant head (weights are trainable in every variant) ----
     if (p->has_image && !p->standard && !p->attention) {
       const ConvL& cq = p->convs[p->quad_conv];
       e.run(qt_quad_pool_bwd(dt, e.at(p->dfused), e.at(p->q), e.at(p->dq), B, p->fused_ld, 512, stream));
-      if (e.gf(cq.bias)) e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, e.fork_thin()));
+      if (e.gf(cq.bias)) {
+        e.fork();
+        e.run(qt_col_sum(dt, e.at(p->dq), (long long)B * 196, 128, 128, e.gf(cq.bias), 0, e.wstream ? e.wstream : stream));
+      }
       e.wgrad(cq, e.quad_desc(QT_CONV_FWD), e.at(p->blocks[5].out), false);
     }
   }
@@ -1671,8 +1646,6 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
   if ((phases & QT_BWD_LAYER1) || !backbone_grads) {
     e.forked = e.forked || (p->side != nullptr && e.wstream == p->side);
     e.join();
-    e.forked2 = e.forked2 || (p->thin != nullptr && e.tstream == p->thin);   // (thin work of an earlier phase call)
-    e.join_thin();
   }
   return e.status;
 }
@@ -1700,8 +1673,6 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
   p->d = *desc;
   p->esz = desc->dtype == QT_F32 ? 4 : 2;
   if (const char* v = getenv("QTCNN_SIDE_STREAM")) p->use_side = atoi(v) != 0;
-  if (const char* v = getenv("QTCNN_THIN_STREAM")) p->use_thin = atoi(v) != 0;
-  if (!p->use_side) p->use_thin = false;
   build_graph(p);
   layout_workspace(p);
   *out = p;
@@ -1711,9 +1682,6 @@ extern "C" int qt_plan_create(const qt_plan_desc* desc, qt_plan** out) {
 extern "C" void qt_plan_destroy(qt_plan* p) {
   if (!p) return;
   if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->thin) (void)hipStreamDestroy(p->thin);
-  if (p->ev_fork2) (void)hipEventDestroy(p->ev_fork2);
-  if (p->ev_join2) (void)hipEventDestroy(p->ev_join2);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
@@ -1819,16 +1787,6 @@ extern "C" int qt_plan_side_fence(qt_plan* p, void* waiting_stream) {
     return QT_ERR_LAUNCH;
   }
   (void)hipEventDestroy(ev);  // destruction is deferred until the event has completed
-  if (p->thin && p->use_thin) {   // the head's thin kernels (bias sums, pose-MLP gradients) run on a stream of their own
-    hipEvent_t ev2;
-    if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess ||
-        hipEventRecord(ev2, p->thin) != hipSuccess ||
-        hipStreamWaitEvent(static_cast<hipStream_t>(waiting_stream), ev2, 0) != hipSuccess) {
-      qt_set_error("qt_plan_side_fence: HIP error");
-      return QT_ERR_LAUNCH;
-    }
-    (void)hipEventDestroy(ev2);
-  }
   return QT_OK;
 }
 
