@@ -283,40 +283,59 @@ __global__ void pool3d_bn_bwd_apply_kernel(const T* __restrict__ dout, const uns
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_tb_kernel(const T* __restrict__ x, float* __restrict__ dst, int Tn, int B, int HW, int C,
                                                          int ld, int col0) {
-  // one workgroup per clip; 256 / (C/8) position lanes per channel group, each adds its positions in ascending order, then
-  // the lanes are added in ascending order through LDS: deterministic.  (One thread per channel group walked all
-  // Tn * HW positions alone: 107 us for 32 clips of 2 x 49 x 512 -- a latency chain on 32 CUs.)
+  // workgroup (clip b, slice of <= 32 channel groups): 256 / slice position lanes per channel group, each adds its positions in
+  // ascending order (four loads in flight), then the lanes are added in ascending order through LDS: deterministic.
+  // (One thread per channel group walked all Tn * HW positions alone: 107 us for 32 clips of 2 x 49 x 512; one workgroup per
+  // clip with 256 / G lanes, round 3: 72 us for 32 clips of 196 x 1024 -- 98 dependent loads per thread on 32 CUs.)
   __shared__ float red[256 * 8];
   const int b = blockIdx.x, G = C / 8;
-  const int R = G <= 256 ? 256 / G : 1;
+  const int GS = G < 32 ? G : 32;                // channel groups of this workgroup (G is a multiple of 32 or < 32)
+  const int R = 256 / GS;                        // position lanes per channel group
+  const int gl = (int)threadIdx.x % GS, r = (int)threadIdx.x / GS;
+  const int g = blockIdx.y * GS + gl;
   const int np = Tn * HW;
-  for (int g0 = 0; g0 < G; g0 += 256) {
-    const int g = g0 + (int)threadIdx.x % (G < 256 ? G : 256), r = (int)threadIdx.x / (G < 256 ? G : 256);
-    float s[8];
+  float s[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    if (g < G && r < R)
-      for (int q = r; q < np; q += R) {
-        const int t = q / HW, pp = q - t * HW;
-        float v[8];
-        QtVec8<T>::load(x + (((long long)t * B + b) * HW + pp) * C + g * 8, v);
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (g < G && r < R) {
+    auto at = [&](int q) -> const T* {
+      const int t = q / HW, pp = q - t * HW;
+      return x + (((long long)t * B + b) * HW + pp) * C + g * 8;
+    };
+    int q = r;
+    for (; q + 3 * R < np; q += 4 * R) {
+      float v0[8], v1[8], v2[8], v3[8];
+      QtVec8<T>::load(at(q), v0);
+      QtVec8<T>::load(at(q + R), v1);
+      QtVec8<T>::load(at(q + 2 * R), v2);
+      QtVec8<T>::load(at(q + 3 * R), v3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += v[e];
-      }
+      for (int e = 0; e < 8; ++e) s[e] += v0[e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
-    __syncthreads();
-    if (r == 0 && g < G) {
-      const int stride = G < 256 ? G : 256;
-      const float inv = 1.f / (float)np;
+      for (int e = 0; e < 8; ++e) s[e] += v1[e];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float a = 0.f;
-        for (int k = 0; k < R; ++k) a += red[(k * stride + (int)threadIdx.x) * 8 + e];
-        dst[(long long)b * ld + col0 + g * 8 + e] = a * inv;
-      }
+      for (int e = 0; e < 8; ++e) s[e] += v2[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v3[e];
     }
-    __syncthreads();
+    for (; q < np; q += R) {
+      float v[8];
+      QtVec8<T>::load(at(q), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+  __syncthreads();
+  if (r == 0 && g < G) {
+    const float inv = 1.f / (float)np;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+      for (int k = 0; k < R; ++k) a += red[(k * GS + gl) * 8 + e];
+      dst[(long long)b * ld + col0 + g * 8 + e] = a * inv;
+    }
   }
 }
 // g [T][B][HW][C] = d[b*ld + col0 + c] / (T*HW)
@@ -546,9 +565,9 @@ extern "C" int qt_avgpool_tb(int dtype, const void* x, float* dst, int frames, i
   QT_CHECK_ARG(dtype == QT_F32 || dtype == QT_BF16, "qt_avgpool_tb: bad dtype %d", dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == QT_F32)
-    hipLaunchKernelGGL(avgpool_tb_kernel<float>, dim3(batch), dim3(256), 0, s, (const float*)x, dst, frames, batch, hw, C, ld, col0);
+    hipLaunchKernelGGL(avgpool_tb_kernel<float>, dim3(batch, (C / 8 + 31) / 32), dim3(256), 0, s, (const float*)x, dst, frames, batch, hw, C, ld, col0);
   else
-    hipLaunchKernelGGL(avgpool_tb_kernel<bf16_t>, dim3(batch), dim3(256), 0, s, (const bf16_t*)x, dst, frames, batch, hw, C, ld, col0);
+    hipLaunchKernelGGL(avgpool_tb_kernel<bf16_t>, dim3(batch, (C / 8 + 31) / 32), dim3(256), 0, s, (const bf16_t*)x, dst, frames, batch, hw, C, ld, col0);
   QT_CHECK_LAUNCH();
   return QT_OK;
 }

@@ -269,6 +269,9 @@ FUSED_POOL = os.environ.get("QTCNN_POOL3D_FUSED", "1") != "0"
 # QTCNN_LSTM_SIDE_STREAM (default 1): Quadtree3DCNN's LSTM branch (a dozen latency-bound launches of 32 workgroups, 0.3 ms
 # forward and 0.25 ms backward in a row) runs on a second stream beside the conv blocks, which it does not depend on
 LSTM_SIDE = os.environ.get("QTCNN_LSTM_SIDE_STREAM", "1") != "0"
+# QTCNN_WGRAD_SIDE_STREAM (default 1): the conv blocks' weight gradients run on a stream of their own beside the data-gradient /
+# BatchNorm / pooling chain of the backward pass (0: in line, as until round 3)
+WGRAD_SIDE = os.environ.get("QTCNN_WGRAD_SIDE_STREAM", "1") != "0"
 # QTCNN_PACK_CACHE (default 1): the clip models re-pack a conv block's filter / BatchNorm vectors only when one of them changed
 PACK_CACHE = os.environ.get("QTCNN_PACK_CACHE", "1") != "0"
 # QTCNN_CONV3D_SLAB (default 1): conv3d_block2's forward on the slab-resident kernel (csrc/conv3d_slab.hip); 0: 27-tap implicit GEMM
@@ -280,9 +283,9 @@ class _Side:
     """fork / join of a per-device second stream around a branch; tensors made there and used on the main stream are
     recorded on it (the caching allocator's pools are per stream)"""
 
-    def __init__(self, dev):
+    def __init__(self, dev, slot=0):
         self.main = torch.cuda.current_stream(dev)
-        key = (dev.index if dev.index is not None else torch.cuda.current_device())
+        key = ((dev.index if dev.index is not None else torch.cuda.current_device()), slot)
         if key not in _side_streams:
             _side_streams[key] = torch.cuda.Stream(device=dev)
         self.side = _side_streams[key]
@@ -501,8 +504,9 @@ class _ConvBlock:
         hi = min(T, T + 1 - kt)
         return lo, lo + kt - 1, max(0, hi - lo)
 
-    def backward(self, dt, dout, saved):
-        """dout: d/d(block output) -> (dx or None, dW, db, dgamma, dbeta)"""
+    def backward(self, dt, dout, saved, wside=None):
+        """dout: d/d(block output) -> (dx or None, dW, db, dgamma, dbeta).  wside: a _Side whose stream takes the weight
+        gradient (the caller joins it before dW is used)"""
         o = ops()
         x, y, a, arg, stats, (T, B, H, W), training, pooled, ymax = saved
         dev = x.device
@@ -536,49 +540,60 @@ class _ConvBlock:
             db = torch.zeros(self.cout_p, dtype=torch.float32, device=dev)
         else:
             db = self.gamma_p.detach().float() * stats[1] * dbeta
-        dW = torch.empty_like(self.conv.weight)
-        dx = None
-        if raw_ws:
-            ws = torch.empty(raw_ws, dtype=torch.uint8, device=dev)
-            o.check(o.L.qt_conv3d_first_wgrad(_lib.qt_dtype(dt), _ptr(x), _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(raw_ws), B, T, H, W,
-                                              _lib.stream_ptr()), "qt_conv3d_first_wgrad")
-            return dx, dW, self._vec_grad(db), self._vec_grad(dgamma), self._vec_grad(dbeta)
-        if self.first:
-            d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
-            dw = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
-            o.wgrad(d, _ptr(dy), _ptr(x), dw)
-        elif (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
-              and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and self._slab_wgrad_bytes(B, T, H, W)):
-            # conv3d_block2: weight gradient and data gradient on the slab-resident kernels (csrc/conv3d_slab.hip)
-            nws = self._slab_wgrad_bytes(B, T, H, W)
-            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-            o.check(o.L.qt_conv3d_c32_wgrad(_lib.qt_dtype(dt), _ptr(x), self.cin_p, _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(nws), B, T, H,
-                                            W, _lib.stream_ptr()), "qt_conv3d_c32_wgrad")
-            o.L.qt_conv3d_c32_dgrad_scratch_bytes.restype = _c.c_size_t
-            nscr = int(o.L.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
-            scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
-            dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
-            o.conv3d_c32_dgrad(dt, dy, self.wd, dx, scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
-                               nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
-            return dx, dW, self._vec_grad(db), self._vec_grad(dgamma), self._vec_grad(dbeta)
+        slab = (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
+                and dy.data_ptr() % 16 == 0)
+
+        def weight_gradient():
+            """dW from (x, dy): the kernels below only read what the chain above has produced"""
+            dW = torch.empty_like(self.conv.weight)
+            if raw_ws:
+                ws = torch.empty(raw_ws, dtype=torch.uint8, device=dev)
+                o.check(o.L.qt_conv3d_first_wgrad(_lib.qt_dtype(dt), _ptr(x), _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(raw_ws), B, T,
+                                                  H, W, _lib.stream_ptr()), "qt_conv3d_first_wgrad")
+                return dW
+            if self.first:
+                d = self._desc(dt, _lib.QT_CONV_FWD, T, B, H, W)
+                dw = torch.zeros(self.cout_p, 128, dtype=torch.float32, device=dev)
+                o.wgrad(d, _ptr(dy), _ptr(x), dw)
+            elif slab and x.data_ptr() % 16 == 0 and self._slab_wgrad_bytes(B, T, H, W):
+                # conv3d_block2: weight gradient on the slab-resident kernel (csrc/conv3d_slab.hip)
+                nws = self._slab_wgrad_bytes(B, T, H, W)
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+                o.check(o.L.qt_conv3d_c32_wgrad(_lib.qt_dtype(dt), _ptr(x), self.cin_p, _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(nws), B,
+                                                T, H, W, _lib.stream_ptr()), "qt_conv3d_c32_wgrad")
+                return dW
+            else:
+                # one launch per frame tap over the contiguous range of frames the tap connects (the contraction runs over
+                # pixels: f32 sums, nothing accumulates through an activation map); with a workspace the bf16 build takes the
+                # tile-resident kernel and its fixed-order partial sums: deterministic, no float atomics
+                frame_in, frame_out = B * H * W * self.cin_p * esz, B * H * W * self.cout_p * esz
+                dw = torch.zeros(3, self.cout_p, 9, self.cin_p, dtype=torch.float32, device=dev)
+                for kt in range(3):
+                    dlo, slo, cnt = self._ranges(T, kt)   # forward: out[dlo + i] read in[slo + i]
+                    if cnt == 0:
+                        continue
+                    d2 = o_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
+                    o.wgrad(d2, _ptr(dy, dlo * frame_out), _ptr(x, slo * frame_in), dw[kt])
+            o.check(o.L.qt_unpack_conv3d_wgrad(_ptr(dw), _ptr(dW), self.cout, self.cin, self.cout_p, self.cin_p,
+                                               1 if self.first else 0, _lib.stream_ptr()), "qt_unpack_conv3d_wgrad")
+            return dW
+
+        # The weight gradient hangs off the chain  dout -> dy -> dx -> (next block): on the weight-gradient stream (wside) its
+        # MFMA kernels run beside the byte-moving BatchNorm / pooling passes of the NEXT block's backward (round 4; the 2-D
+        # plan's arrangement, csrc/plan.hip).  x and dy were allocated on the compute stream: recorded on the side stream so
+        # that the caching allocator does not hand their memory out again while it still reads them.
+        if wside is not None:
+            for t_ in (x, dy):
+                t_.record_stream(wside.side)
+            with wside.fork():
+                dW = weight_gradient()
         else:
-            # weight gradient: one launch per frame tap over the contiguous range of frames the tap connects (the contraction
-            # runs over pixels: f32 sums, nothing accumulates through an activation map); with a workspace the bf16 build takes
-            # the tile-resident kernel and its fixed-order partial sums: deterministic, no float atomics
-            frame_in, frame_out = B * H * W * self.cin_p * esz, B * H * W * self.cout_p * esz
-            dw = torch.zeros(3, self.cout_p, 9, self.cin_p, dtype=torch.float32, device=dev)
-            for kt in range(3):
-                dlo, slo, cnt = self._ranges(T, kt)   # forward: out[dlo + i] read in[slo + i]
-                if cnt == 0:
-                    continue
-                d2 = o_desc(dt, _lib.QT_CONV_FWD, cnt * B, H, W, self.cin_p, self.cout_p, 3, 1)
-                o.wgrad(d2, _ptr(dy, dlo * frame_out), _ptr(x, slo * frame_in), dw[kt])
-            # data gradient: one 27-tap launch; conv3d_block2's on the slab-resident kernel (two passes over dy's channel halves)
-            dd = self._desc(dt, _lib.QT_CONV_DGRAD, T, B, H, W)
+            dW = weight_gradient()
+        dx = None
+        if not self.first:   # data gradient: one 27-tap launch; conv3d_block2's on the slab-resident kernel (two passes)
             dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
             nscr = 0
-            if (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
-                    and dy.data_ptr() % 16 == 0):
+            if slab:
                 o.L.qt_conv3d_c32_dgrad_scratch_bytes.restype = _c.c_size_t
                 nscr = int(o.L.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
             if nscr:
@@ -586,10 +601,9 @@ class _ConvBlock:
                 o.conv3d_c32_dgrad(dt, dy, self.wd, dx, scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
                                    nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
             else:
+                dd = self._desc(dt, _lib.QT_CONV_DGRAD, T, B, H, W)
                 o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx), flops=2.0 * rows * 27 * self.cin * self.cout,
                         nbytes=esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p))
-        o.check(o.L.qt_unpack_conv3d_wgrad(_ptr(dw), _ptr(dW), self.cout, self.cin, self.cout_p, self.cin_p,
-                                           1 if self.first else 0, _lib.stream_ptr()), "qt_unpack_conv3d_wgrad")
         return dx, dW, self._vec_grad(db), self._vec_grad(dgamma), self._vec_grad(dbeta)
 
 
@@ -957,11 +971,16 @@ class Quadtree3DCNN(_ClipModel):
         o.check(o.L.qt_avgpool_tb_bwd(_lib.qt_dtype(dt), _ptr(dfused), _ptr(dout), t, B, h * w, C_last, ld, 0, _lib.stream_ptr()),
                 "qt_avgpool_tb_bwd")
         names = ("conv3d_block1", "conv3d_block2", "conv3d_block3", "conv3d_block4_new", "conv3d_final_features")
+        wside = _Side(dev, 1) if WGRAD_SIDE else None
         for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), reversed(names)):
-            dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
+            dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv, wside)
             g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
             if emit is not None and nm == "conv3d_final_features":   # bucket 2: 7.1 M of the 9.9 M parameters, ready first
+                if wside is not None:
+                    wside.join(dW)   # (the bucket is packed on the compute stream)
                 emit(g, [k for k in g if k.startswith(nm + ".")], 2)
+        if wside is not None:
+            wside.join(*[g[f"{nm}.0.weight"] for nm in names])
         if side is not None:
             side.join(*lg)
         if emit is not None:   # bucket 3: conv blocks 4 .. 1 and the LSTM (joined above)
@@ -1054,9 +1073,12 @@ class Ji3DCNN(_ClipModel):
         dout = torch.empty(t * B * h * w, C_last, dtype=dt, device=dev)
         o.check(o.L.qt_avgpool_tb_bwd(_lib.qt_dtype(dt), _ptr(dfused), _ptr(dout), t, B, h * w, C_last, ld, 0, _lib.stream_ptr()),
                 "qt_avgpool_tb_bwd")
+        wside = _Side(dev, 1) if WGRAD_SIDE else None
         for blk, sv, nm in zip(reversed(blocks), reversed(saved_blocks), ("visual_stream.4", "visual_stream.2", "visual_stream.0")):
-            dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv)
+            dout, dW, db, dgamma, dbeta = blk.backward(dt, dout, sv, wside)
             g[f"{nm}.0.weight"], g[f"{nm}.0.bias"], g[f"{nm}.1.weight"], g[f"{nm}.1.bias"] = dW, db, dgamma, dbeta
+        if wside is not None:
+            wside.join(*[g[f"{nm}.0.weight"] for nm in ("visual_stream.4", "visual_stream.2", "visual_stream.0")])
         if emit is not None:   # bucket 2: the three conv blocks (0.3 M parameters)
             emit(g, [k for k in g if k.startswith("visual_stream.")], 2)
         self._saved = None
