@@ -1525,12 +1525,6 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
     // ReLU masks of the data-gradient epilogues as one bit per element (written by the training forward's qt_bn_act_mask
     // launches): 1/16 of the bytes of the bf16 activation they replace as an operand.  QTCNN_MASK_BITS=0: the activations.
     static const bool mask_bits = !(getenv("QTCNN_MASK_BITS") && atoi(getenv("QTCNN_MASK_BITS")) == 0);
-    // QTCNN_BWD_LINKS (bit mask, default 15 = all): which stages' data-gradient epilogues also emit the BatchNorm-backward
-    // sums of the BatchNorm(s) that consume their output (bit L-1 = the launches that write gradients of layer L's maps).
-    // A cleared bit: plain epilogue + the separate qt_bn_bwd_reduce pass (a byte-moving kernel that runs beside the
-    // weight-gradient stream's MFMA kernels, where the link lengthens an MFMA kernel).  Same-box A/B switch.
-    static const int link_mask = getenv("QTCNN_BWD_LINKS") ? atoi(getenv("QTCNN_BWD_LINKS")) : 15;
-    auto links_on = [&](int hw) { return (link_mask >> (hw == 56 ? 0 : hw == 28 ? 1 : hw == 14 ? 2 : 3)) & 1; };
     for (int bi = bi_hi; bi >= bi_lo; --bi) {
       const Block& blk = p->blocks[bi];
       const ConvL& c1 = p->convs[blk.conv1];
@@ -1543,11 +1537,10 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
       {
         const BnL& b1 = p->bns[c1.bn];
         Exec::BnLink l = {e.at(c1.y), e.at<float>(b1.mean), e.at<float>(b1.invstd), e.at<float>(p->stats_bn1)};
-        const int nl1 = links_on(c2.hin) ? 1 : 0;
-        const int r1 = mask_bits ? e.dgrad(c2, e.at(c1.gy), nullptr, nullptr, &l, nl1, false, e.at<unsigned char>(blk.a1_bits))
-                                 : e.dgrad(c2, e.at(c1.gy), nullptr, e.at(blk.a1), &l, nl1);
+        const int r1 = mask_bits ? e.dgrad(c2, e.at(c1.gy), nullptr, nullptr, &l, 1, false, e.at<unsigned char>(blk.a1_bits))
+                                 : e.dgrad(c2, e.at(c1.gy), nullptr, e.at(blk.a1), &l, 1);
         // bn1 / conv1
-        e.bn_backward(c1, e.at(c1.gy), nullptr, nl1 ? e.at<float>(p->stats_bn1) : nullptr, nl1 ? r1 : 0);
+        e.bn_backward(c1, e.at(c1.gy), nullptr, e.at<float>(p->stats_bn1), r1);
       }
       e.wgrad(c1, f1, e.at(x), false);
       // gradient w.r.t. the block input = conv1 dgrad + identity path (+ quadrant head for layer3's output)
@@ -1598,9 +1591,8 @@ int backward(qt_plan* p, void* workspace, void* const* T, float* const* G, const
           links[nlinks++] = {e.at(pcd.y), e.at<float>(pbd.mean), e.at<float>(pbd.invstd), e.at<float>(p->stats_ds)};
         }
       }
-      if (!links_on(c1.hin)) nlinks = 0;
       rows_bn2 = e.dgrad(c1, gprev, resid, mask, links, nlinks, sparse_ds, mbits);
-      if (bi == 0 || nlinks == 0) rows_bn2 = 0;
+      if (bi == 0) rows_bn2 = 0;
     }
     p->bwd_rows_bn2 = rows_bn2;
     if (do_rest) {

@@ -273,6 +273,7 @@ LSTM_SIDE = os.environ.get("QTCNN_LSTM_SIDE_STREAM", "1") != "0"
 # BatchNorm / pooling chain of the backward pass (0: in line, as until round 3)
 WGRAD_SIDE = os.environ.get("QTCNN_WGRAD_SIDE_STREAM", "1") != "0"
 # QTCNN_PACK_CACHE (default 1): the clip models re-pack a conv block's filter / BatchNorm vectors only when one of them changed
+# (writes through `p.data` are not seen: model.invalidate_packed(), see there)
 PACK_CACHE = os.environ.get("QTCNN_PACK_CACHE", "1") != "0"
 # QTCNN_CONV3D_SLAB (default 1): conv3d_block2's forward on the slab-resident kernel (csrc/conv3d_slab.hip); 0: 27-tap implicit GEMM
 SLAB_C32 = os.environ.get("QTCNN_CONV3D_SLAB", "1") != "0"
@@ -714,6 +715,17 @@ class _ClipModel(nn.Module):
             self.__dict__["_blocks"] = [_ConvBlock(c, b, p, f) for c, b, p, f in specs]
             self.__dict__["_blocks_key"] = key
         return self.__dict__["_blocks"]
+
+    def invalidate_packed(self):
+        """Forget the packed copies of every conv block's filter / BatchNorm vectors: the next forward re-packs them.
+        The cache (QTCNN_PACK_CACHE) follows the parameters' version counters, FusedAdam's raw updates and the model's own
+        backward passes; a write that bumps none of them -- `p.data.copy_(ema)`, `p.data.mul_(...)`: `.data` carries its
+        own version counter -- is invisible to it.  Call this after such a write (load_state_dict and in-place ops on the
+        parameters themselves need nothing)."""
+        for blk in self.__dict__.get("_blocks") or ():
+            blk._packed_ver = None
+
+    invalidate_packed_weights = invalidate_packed   # (the name the plan-backed 2-D models use, quadtree.py)
 
     def _run(self, image_sequence, numerical_sequence):
         self._check_hooks()

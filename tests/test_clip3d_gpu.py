@@ -606,6 +606,14 @@ def test_packed_operands_follow_the_parameters(monkeypatch):
     with torch.no_grad():
         w.mul_(2.0)                                        # (exact: back to the first weights)
     assert torch.equal(eval_logits(True), a0)
+    # a write through `.data` bumps no version counter the cache can see: model.invalidate_packed() is the documented way
+    w.data.mul_(0.5)
+    assert torch.equal(eval_logits(True), a0)              # (stale on purpose: that is the limitation)
+    m.invalidate_packed()
+    assert torch.equal(eval_logits(True), a1)
+    w.data.mul_(2.0)
+    m.invalidate_packed()
+    assert torch.equal(eval_logits(True), a0)
     for make in (lambda ps: P.FusedAdam(ps, lr=1e-2), lambda ps: torch.optim.Adam(ps, lr=1e-2, fused=True)):
         opt = make(list(m.parameters()))
         before = eval_logits(True)
