@@ -326,6 +326,56 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict
   }
 }
 
+// The same pass for the training step's backward chain (bf16, no mask / g_out operand): dy = P g + Q y + R with the
+// per-channel P = ca, Q = -ca cc invstd, R = -ca cb - Q mean folded ONCE per thread -- the grid stride is a multiple of the
+// channel groups per row, so a thread keeps its eight channels -- and two 16-byte loads of each operand in flight.  In the step
+// this kernel runs on the main stream BESIDE the weight-gradient stream's MFMA kernels (which leave 84 of a SIMD's 512
+// registers per lane): 44 VGPRs instead of 60 put two of its waves on a SIMD instead of one, and the operand loads of two
+// elements overlap -- the pass sits in the chain  data gradient -> finalize -> apply -> data gradient  that bounds the
+// backward pass (round 4).  QTCNN_BN_APPLY_LIGHT=0: the general kernel above (same-box A/B).
+__global__ __launch_bounds__(256) void bn_bwd_apply_light_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ y,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ coef, bf16_t* __restrict__ dy,
+                                                                 long long total, int cgs, int C) {
+  // (FOUR channels = 8 bytes per thread and element: 12 coefficient registers instead of 24; total / cgs count 4-channel groups;
+  //  32-bit element indices -- the launcher checks total < 2^29 -- so an address is a scalar base + one offset register)
+  const unsigned stride = gridDim.x * 256u;   // (a multiple of cgs: checked by the launcher)
+  unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned n = (unsigned)total;
+  const int c0 = (int)(i % (unsigned)cgs) * 4;
+  float P[4], Q[4], R[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ca = coef[c0 + e], cb = coef[C + c0 + e], cc = coef[2 * C + c0 + e];
+    P[e] = ca;
+    Q[e] = -ca * cc * invstd[c0 + e];
+    R[e] = -ca * cb - Q[e] * mean[c0 + e];
+  }
+  const uint2* __restrict__ g2 = reinterpret_cast<const uint2*>(g);
+  const uint2* __restrict__ y2 = reinterpret_cast<const uint2*>(y);
+  uint2* __restrict__ d2 = reinterpret_cast<uint2*>(dy);
+  auto pack2 = [](float lo, float hi) -> unsigned {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(bf16_t)lo, (bf16_t)hi};
+    return __builtin_bit_cast(unsigned, v);
+  };
+  auto one = [&](const uint2& gu, const uint2& yu, unsigned at) {
+    uint2 o;
+    o.x = pack2(P[0] * __uint_as_float(gu.x << 16) + Q[0] * __uint_as_float(yu.x << 16) + R[0],
+                P[1] * __uint_as_float(gu.x & 0xffff0000u) + Q[1] * __uint_as_float(yu.x & 0xffff0000u) + R[1]);
+    o.y = pack2(P[2] * __uint_as_float(gu.y << 16) + Q[2] * __uint_as_float(yu.y << 16) + R[2],
+                P[3] * __uint_as_float(gu.y & 0xffff0000u) + Q[3] * __uint_as_float(yu.y & 0xffff0000u) + R[3]);
+    d2[at] = o;
+  };
+#pragma unroll 1
+  for (; i + stride < n; i += 2u * stride) {   // two elements in flight (i + stride < 2^31: total < 2^29)
+    const uint2 ga = g2[i], ya = y2[i], gb = g2[i + stride], yb = y2[i + stride];
+    one(ga, ya, i);
+    one(gb, yb, i + stride);
+  }
+  for (; i < n; i += stride) one(g2[i], y2[i], i);
+}
+
 // ---------------------------------------------------------------------------------
 // Stem: a = relu(y*scale+shift) on [B][112][112][64]; 3x3/2 pad 1 max pool -> [B][56][56][64]
 // (+ argmax position 0..8 in scan order, first maximum wins like ATen).
@@ -934,6 +984,19 @@ extern "C" int qt_bn_bwd_apply(int dtype, const void* g, const void* mask, const
   QT_CHECK_ARG(g && y && mean && invstd && coef && dy && M > 0 && C > 0 && C % 8 == 0, "qt_bn_bwd_apply: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(M * (C / 8));
+  static int light = -1;
+  if (light < 0) {
+    const char* e = getenv("QTCNN_BN_APPLY_LIGHT");
+    light = e ? atoi(e) : 1;
+  }
+  const int cgs = C / 4;   // (4-channel groups per row)
+  const int lgrid = grid_for(M * cgs);
+  if (light && dtype == QT_BF16 && !mask && !g_out && ((long long)lgrid * 256) % cgs == 0 && M * cgs < (1ll << 29)) {
+    hipLaunchKernelGGL(bn_bwd_apply_light_kernel, dim3(lgrid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, coef,
+                       (bf16_t*)dy, M * cgs, cgs, C);
+    QT_CHECK_LAUNCH();
+    return QT_OK;
+  }
   if (dtype == QT_F32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)mask,
                        (const float*)y, mean, invstd, coef, (float*)dy, (float*)g_out, M, C);

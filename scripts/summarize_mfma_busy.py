@@ -17,7 +17,7 @@ ms = {"train": float(sys.argv[3]), "eval": float(sys.argv[4])}
 steps = 5  # bench.py --steps 3 --warmup 2
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 algorithmic = {"train": 11.0792e9 * 256, "eval": 3.7718e9 * 256}
-FAMS = ("conv_igemm", "conv_pt", "conv_s2", "stem_wgrad_rows", "conv_wgrad_tile", "conv_wgrad_patch", "conv_wgrad", "conv_l1_ring", "conv_stem", "linear_splitk")
+FAMS = ("conv_igemm", "conv_pt", "conv_s2", "stem_wgrad_rows", "conv_wgrad_tile", "conv_wgrad_patch", "conv_wgrad_s2", "conv_wgrad", "conv_l1_ring", "conv_stem", "linear_splitk")
 sys.path.insert(0, root)
 import bench  # noqa: E402
 out = {"kind": "mfma_busy", "model": "quadtree", "kernel_sources_sha1": bench.kernel_sources_sha1(), "counter": "SQ_VALU_MFMA_BUSY_CYCLES (rocprofv3 --pmc, one pass, --kernel-trace only)", "batch": 256, "dtype": "bf16",

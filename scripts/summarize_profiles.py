@@ -27,7 +27,7 @@ def family(kernel):
     if model != "quadtree":   # other models: the kernel's own name without template arguments
         k = kernel.split("(")[0].split("<")[0].split()[-1] if kernel.strip() else "other"
         return k.split("::")[-1]
-    for key in ("conv_igemm_kernel", "conv_pt_kernel", "conv_s2_kernel", "stem_bn_bwd_apply2x2", "stem_wgrad_rows", "conv_wgrad_tile_kernel", "conv_wgrad_patch_kernel", "conv_wgrad_kernel", "conv_l1_ring_kernel",
+    for key in ("conv_igemm_kernel", "conv_pt_kernel", "conv_s2_kernel", "stem_bn_bwd_apply2x2", "stem_wgrad_rows", "conv_wgrad_tile_kernel", "conv_wgrad_patch_kernel", "conv_wgrad_s2_kernel", "conv_wgrad_kernel", "conv_l1_ring_kernel",
                 "conv_stem_kernel", "conv_patch_kernel", "wgrad_partial_sum", "bn_bwd_apply", "bn_bwd_reduce",
                 "bn_act", "stem_pool_bwd", "stem_bn_bwd_sums", "stem_pool", "pack_weights_batched",
                 "multi_tensor_apply"):
