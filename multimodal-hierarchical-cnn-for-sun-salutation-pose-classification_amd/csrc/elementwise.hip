@@ -1074,6 +1074,75 @@ extern "C" int qt_stem_bn_bwd_reduce(int dtype, const void* dpooled, const unsig
   return QT_OK;
 }
 
+// The same sums in a light-footprint form (bf16; round 4): in the step this kernel is the last link of the main stream's chain
+// in front of the stem's weight gradient and runs beside the weight-gradient stream's last layer-1 launch, which leaves a CU
+// 5 KB of LDS and 84 registers per lane: the kernel above (74 VGPRs, 16 KB of LDS) measured 103 us there against 41 us alone.
+// Four channels (8 bytes) per thread, mask threshold and BatchNorm constants folded (sum g v is corrected by mean and invstd
+// once at the end), lanes of a channel group added by two butterfly steps, one 2 KB exchange between the four waves.
+static __global__ __launch_bounds__(256) void stem_bn_bwd_sums_light_kernel(const bf16_t* __restrict__ dpooled,
+                                                                     const bf16_t* __restrict__ y_at_max,
+                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     float* __restrict__ partial, unsigned total4) {
+  constexpr int C = 64;
+  const int c0 = (threadIdx.x & 15) * 4;   // gridDim.x * 256 is a multiple of 16
+  float sc[4], sh[4], s1[4], s2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = scale[c0 + e];
+    sh[e] = shift[c0 + e];
+    s1[e] = s2[e] = 0.f;
+  }
+  const uint2* __restrict__ d2 = reinterpret_cast<const uint2*>(dpooled);
+  const uint2* __restrict__ v2 = reinterpret_cast<const uint2*>(y_at_max);
+  const unsigned stride = gridDim.x * 256u;
+  auto add = [&](const uint2& du, const uint2& vu) {
+    const float d[4] = {__uint_as_float(du.x << 16), __uint_as_float(du.x & 0xffff0000u), __uint_as_float(du.y << 16),
+                        __uint_as_float(du.y & 0xffff0000u)};
+    const float v[4] = {__uint_as_float(vu.x << 16), __uint_as_float(vu.x & 0xffff0000u), __uint_as_float(vu.y << 16),
+                        __uint_as_float(vu.y & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = (v[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
+      s1[e] += g;
+      s2[e] += g * v[e];
+    }
+  };
+  unsigned i = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll 1
+  for (; i + stride < total4; i += 2u * stride) {
+    const uint2 da = d2[i], va = v2[i], db = d2[i + stride], vb = v2[i + stride];
+    add(da, va);
+    add(db, vb);
+  }
+  if (i < total4) add(d2[i], v2[i]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {   // sum g (v - mean) invstd = invstd (sum g v - mean sum g)
+    s2[e] = (s2[e] - mean[c0 + e] * s1[e]) * invstd[c0 + e];
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) {   // the four lanes of a wave that share a channel group
+      s1[e] += __shfl_xor(s1[e], m, 64);
+      s2[e] += __shfl_xor(s2[e], m, 64);
+    }
+  }
+  __shared__ float red[4][64][2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][c0 + e][0] = s1[e];
+      red[wave][c0 + e][1] = s2[e];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float a = red[0][threadIdx.x][0] + red[1][threadIdx.x][0] + red[2][threadIdx.x][0] + red[3][threadIdx.x][0];
+    const float b = red[0][threadIdx.x][1] + red[1][threadIdx.x][1] + red[2][threadIdx.x][1] + red[3][threadIdx.x][1];
+    partial[((long long)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+    partial[((long long)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+
 static int stem_sums_rows(int batch) {
   const long long blocks = ((long long)batch * 56 * 56 * 8 + 255) / 256;
   return (int)(blocks > 1024 ? 1024 : blocks);
@@ -1089,6 +1158,17 @@ extern "C" int qt_stem_bn_bwd_sums(int dtype, const void* dpooled, const void* y
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = stem_sums_rows(batch);
   const long long total = (long long)batch * 56 * 56 * 8;
+  static int light = -1;   // QTCNN_STEM_SUMS_LIGHT (default 1): 0 = the general kernel (same-box A/B)
+  if (light < 0) {
+    const char* e = getenv("QTCNN_STEM_SUMS_LIGHT");
+    light = e ? atoi(e) : 1;
+  }
+  if (light && dtype == QT_BF16 && total * 2 < (1ll << 30)) {
+    hipLaunchKernelGGL(stem_bn_bwd_sums_light_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)dpooled, (const bf16_t*)y_at_max,
+                       scale, shift, mean, invstd, partial, (unsigned)(total * 2));
+    QT_CHECK_LAUNCH();
+    return QT_OK;
+  }
   if (dtype == QT_F32)
     hipLaunchKernelGGL(stem_bn_bwd_sums_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dpooled,
                        (const float*)y_at_max, scale, shift, mean, invstd, partial, total);
