@@ -133,10 +133,9 @@ typedef struct qt_conv_io {
   const void* extra_src;  /* qt_conv_desc.dst_merge_extra: [batch][in_h][in_w][k_per_tap] with src's strides, or NULL */
 } qt_conv_io;
 
-/* 3x3 stride-1 convs with the input patch resident in LDS (csrc/conv_patch.hip) instead of the
- * generic implicit GEMM: 0 never, 1 every eligible shape (56x56x64 and 28x28x128 inputs; the
- * one-tile-per-workgroup kernel is experimental), 2 (default) only the persistent sliding-ring
- * kernel for the 56x56 64->64 bf16 layers. */
+/* The 56x56 64->64 bf16 3x3 stride-1 convs (ResNet layer1) on the persistent sliding-ring kernel with the input window
+ * resident in LDS (csrc/conv_patch.hip) instead of the generic implicit GEMM: 0 never, anything else (default) on.
+ * (Rounds 1-3 had an experimental one-tile-per-workgroup kernel behind mode 1; removed in round 4.) */
 void qt_set_patch_conv(int mode);
 /* 3x3 / stride 1 / pad 1 convolutions on dense 28x28, 14x14 and 7x7 maps with >= 16 images and a multiple of 128 output
  * channels (the twelve such convs of layer2..4, forward and data gradient) take the patch-resident ping-pong kernel

@@ -1,25 +1,18 @@
-// 3x3 / stride 1 / pad 1 convolution (forward and data gradient) with the input patch
-// resident in LDS: every input pixel is fetched from L2 ONCE per workgroup and reused by all
-// nine taps, instead of once per tap as in the generic implicit GEMM (conv_igemm.hip).
+// 3x3 / stride 1 / pad 1 convolution of ResNet layer1 (56x56 map, 64 -> 64 channels, bf16; forward and data gradient)
+// with the input window resident in LDS: every input pixel is fetched from L2 ONCE per workgroup and reused by all nine
+// taps, instead of once per tap as in the generic implicit GEMM (conv_igemm.hip).
 //
-// Why: on gfx950 a CU pulls ~70 GB/s from L2 into LDS, so an MFMA tile needs >~140 FLOP per
-// staged byte to be matrix-bound.  The generic 128x64 / 128x128 tiles of layer1 / layer2 sit
-// at 43 / 64 FLOP/B (L2-bound); with halo reuse the same layers reach 150-190 FLOP/B.
+// Replaces the conv2d forward / backward-input ATen calls reached from /root/reference/Quadtree_from scratch/models.py:222-229
+// (torchvision resnet18 layer1) and Quadtree_train.py:65.
 //
-// Formulation.  Pixels are numbered in ZERO-PADDED coordinates q = (img*(H+2) + hp)*(W+2) + wp;
-// the border positions hold zeros and their outputs are discarded.  In that numbering a tap is
-// a CONSTANT row shift: source(q, kh, kw) = q + (kh-1)*(W+2) + (kw-1).  A workgroup owns BM = 256
-// consecutive padded positions and stages the BM + 2*(W+2) + 2 positions they touch, one
-// 128-byte channel chunk at a time (border / out-of-range rows come from a zero page), then
-// issues, per tap, MFMAs whose A fragments are read at LDS row (m + kh*(W+2) + kw).  Tensors in
-// HBM stay dense NHWC: padding exists only in the tile's index space (waste (H+2)(W+2)/HW:
-// 7 % at 56x56, 15 % at 28x28), so no other kernel changes.
+// Formulation.  Pixels are numbered in ZERO-PADDED coordinates q = (img*(H+2) + hp)*(W+2) + wp; the border positions hold
+// zeros and their outputs are discarded.  In that numbering a tap is a CONSTANT row shift:
+// source(q, kh, kw) = q + (kh-1)*(W+2) + (kw-1).  Tensors in HBM stay dense NHWC: padding exists only in the tile's index
+// space (7 % more positions at 56x56), so no other kernel changes.
 //
-// 512 threads = 8 waves (4 x 2), wave tile 64 x BN/2.  Weights stream through a 3-deep LDS
-// ring of filter ROWS (three taps = 48 MFMAs per wave per barrier; LDS-DMA, counted vmcnt);
-// the patch of the next channel chunk is prefetched into a second patch buffer when it fits.
-// Epilogue as in conv_igemm.hip (scale/shift, residual, ReLU, mask, BatchNorm partial sums),
-// with the padded position decoded back to the dense row.
+// (Rounds 1-3 also carried an experimental one-tile-per-workgroup kernel for the 56x56 / 28x28 stages behind
+// QTCNN_PATCH_CONV=1; it only ever tied the generic kernel -- EXPERIMENTS.md, round 1 -- and was removed in round 4.  The
+// persistent ring kernel below is what the models run.)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -48,327 +41,12 @@ struct PatchArgs {
   int flip;            // 1: data gradient (taps mirrored)
   int relu;
   int gridM, gridN;
-  int PR;              // staged patch rows (multiple of 64)
-  int pbufs;           // patch buffers in LDS (2 when they fit)
   FastDiv div_pp, div_pw;
 };
 
 constexpr int kRowBytes = 128;
 constexpr int BM = 256;
 constexpr int NT = 512;
-
-// Rows of the staged f32 tile -> dense NHWC rows with the fused epilogue; `mt` = row of the
-// per-tile partial-sum tables.
-template <typename T, int BN, int NTH>
-__device__ __forceinline__ void patch_epilogue(const PatchArgs& p, unsigned char* smem, long long q0, int mt, int n0,
-                                               int tid) {
-  constexpr int ROWB = BN * 4;
-  constexpr int TPR = BN / 8;
-  constexpr int RPP = NTH / TPR;
-  constexpr int NPASS = BM / RPP;
-  const int cg = tid % TPR, r0 = tid / TPR;
-  const int nbase = n0 + cg * 8;
-  const bool n_ok = nbase < p.N;
-  float sc[8], sh[8], mu0[8], is0[8], mu1[8], is1[8];
-  const bool bwd_stats = p.bn_y[0] != nullptr;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = (p.scale && n_ok) ? p.scale[nbase + e] : 1.f;
-    sh[e] = (p.shift && n_ok) ? p.shift[nbase + e] : 0.f;
-    mu0[e] = (bwd_stats && n_ok) ? p.bn_mean[0][nbase + e] : 0.f;
-    is0[e] = (bwd_stats && n_ok) ? p.bn_invstd[0][nbase + e] : 0.f;
-    mu1[e] = (p.bn_y[1] && n_ok) ? p.bn_mean[1][nbase + e] : 0.f;
-    is1[e] = (p.bn_y[1] && n_ok) ? p.bn_invstd[1][nbase + e] : 0.f;
-  }
-  float s1[8], s2[8], s3[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
-  T* __restrict__ dst = static_cast<T*>(p.dst);
-  const T* __restrict__ res = static_cast<const T*>(p.residual);
-  const T* __restrict__ msk = static_cast<const T*>(p.relu_mask);
-  const unsigned char* __restrict__ mbits = p.relu_mask_bits;
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int r = r0 + ps * RPP;
-    const long long q = q0 + r;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg) ^ (r & 7)) << 4));
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((2 * cg + 1) ^ (r & 7)) << 4));
-    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    if (q < p.Q && n_ok) {
-      const unsigned uq = (unsigned)q;
-      const unsigned img = fdiv(uq, p.div_pp);
-      const unsigned rem = uq - img * (unsigned)p.PP;
-      const unsigned hp = fdiv(rem, p.div_pw);
-      const unsigned wp = rem - hp * (unsigned)p.PW;
-      if (hp >= 1 && hp <= (unsigned)p.H && wp >= 1 && wp <= (unsigned)p.W) {
-        const long long off = ((((long long)img * p.H + (hp - 1)) * p.W + (wp - 1))) * p.N + nbase;
-        if (p.stats_partial != nullptr && !bwd_stats) {  // (uniform: an eval forward keeps no sums)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * v[e];
-          }
-        }
-if (p.scale || p.shift) {  // (uniform)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-        }
-        if (res) {
-          float rv[8];
-          QtVec8<T>::load(res + off, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (msk) {
-          float mv[8];
-          QtVec8<T>::load(msk + off, mv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-        }
-        if (mbits) qt_apply_mask_bits(mbits[off >> 3], v);
-        QtVec8<T>::store(dst + off, v);
-        if (bwd_stats) {
-          float yv[8];
-          QtVec8<T>::load(static_cast<const T*>(p.bn_y[0]) + off, yv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * (yv[e] - mu0[e]) * is0[e];
-          }
-          if (p.bn_y[1]) {
-            QtVec8<T>::load(static_cast<const T*>(p.bn_y[1]) + off, yv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s3[e] += v[e] * (yv[e] - mu1[e]) * is1[e];
-          }
-        }
-      }
-    }
-  }
-
-  if (p.stats_partial || bwd_stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [RPP][BN][3]
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[(r0 * BN + cg * 8 + e) * 3 + 0] = s1[e];
-      red[(r0 * BN + cg * 8 + e) * 3 + 1] = s2[e];
-      red[(r0 * BN + cg * 8 + e) * 3 + 2] = s3[e];
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float a = 0.f, b = 0.f, c = 0.f;
-      for (int r = 0; r < RPP; ++r) {
-        a += red[(r * BN + tid) * 3 + 0];
-        b += red[(r * BN + tid) * 3 + 1];
-        c += red[(r * BN + tid) * 3 + 2];
-      }
-      if (n0 + tid < p.N) {
-        float* o0 = bwd_stats ? p.bn_partial[0] : p.stats_partial;
-        o0[((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-        o0[((long long)mt * 2 + 1) * p.N + n0 + tid] = b;
-        if (bwd_stats && p.bn_y[1]) {
-          p.bn_partial[1][((long long)mt * 2 + 0) * p.N + n0 + tid] = a;
-          p.bn_partial[1][((long long)mt * 2 + 1) * p.N + n0 + tid] = c;
-        }
-      }
-    }
-  }
-}
-
-// Geometry is compile time (map width WW, data-gradient flip, channel chunks, patch buffers): every
-// LDS fragment address is then a per-lane base plus an immediate, which removes the ~7 VALU
-// instructions per MFMA that a runtime row shift costs (measured with SQ_INSTS_VALU).
-template <typename T, int BN, int WW, bool FLIP, int NCHUNKS, int PBUFS>
-__global__ __launch_bounds__(NT) void conv_patch_kernel(PatchArgs p) {
-  constexpr int PW = WW + 2;
-  constexpr int PR = (BM + 2 * PW + 2 + 63) / 64 * 64;
-  constexpr int BK = kRowBytes / (int)sizeof(T);
-  constexpr int TM = 4;            // 64 positions per wave
-  constexpr int TN = BN / 32;      // BN/2 channels per wave
-  constexpr int DW = BN / 64;      // weight DMA instructions per wave per step
-  constexpr int MAXPASS = 6;       // patch rows / 64 (<= 384 rows)
-  constexpr int WSTAGE = BN * kRowBytes;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const T* __restrict__ src = static_cast<const T*>(p.src);
-  const T* __restrict__ wgt = static_cast<const T*>(p.wgt);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
-  const int bid = qt_xcd_remap(blockIdx.x, p.gridM * p.gridN);
-  const int mt = bid / p.gridN, nt = bid - mt * p.gridN;
-  const long long q0 = (long long)mt * BM;
-  const int n0 = nt * BN;
-  constexpr int npass = PR >> 6;
-  constexpr int PATCH_BYTES = PR * kRowBytes;
-  const unsigned smem_base = lds_addr_of(smem);
-  const unsigned wring = smem_base + PBUFS * PATCH_BYTES;   // weight ring behind the patch buffer(s)
-  const T* zero_src = reinterpret_cast<const T*>(qt_zero_page);
-
-  // ---- patch rows staged by this thread: pointer to the pixel's channel 0 (+ this lane's chunk) ----
-  const int rbase = tid >> 3;                       // 0..63
-  const int chunk = (tid & 7) ^ (rbase & 7);        // source chunk (swizzle on the source side)
-  const T* prow[MAXPASS];
-#pragma unroll
-  for (int i = 0; i < MAXPASS; ++i) {
-    prow[i] = nullptr;
-    if (i < npass) {
-      const long long q = q0 - PW - 1 + (i * 64 + rbase);
-      if (q >= 0 && q < p.Q) {
-        const unsigned uq = (unsigned)q;
-        const unsigned img = fdiv(uq, p.div_pp);
-        const unsigned rem = uq - img * (unsigned)p.PP;
-        const unsigned hp = fdiv(rem, p.div_pw);
-        const unsigned wp = rem - hp * (unsigned)p.PW;
-        if (hp >= 1 && hp <= (unsigned)p.H && wp >= 1 && wp <= (unsigned)p.W)
-          prow[i] = src + (((long long)img * p.H + (hp - 1)) * p.W + (wp - 1)) * p.C + chunk * (16 / (int)sizeof(T));
-      }
-    }
-  }
-  const T* wrow[DW];
-#pragma unroll
-  for (int i = 0; i < DW; ++i) {
-    const int n = n0 + i * 64 + rbase;
-    wrow[i] = n < p.N ? wgt + (long long)n * 9 * p.C + chunk * (16 / (int)sizeof(T)) : nullptr;
-  }
-
-  constexpr int nchunks = NCHUNKS;
-  constexpr int ngroups = nchunks * 3;   // a group = the three taps of one filter row of one chunk
-  constexpr int DG = 3 * DW;         // weight DMA instructions per wave per group
-  constexpr int GSTAGE = 3 * WSTAGE;
-  constexpr int pbufs = PBUFS;       // 2: next chunk's patch is prefetched; 1: staged at the chunk seam
-  auto dma_patch = [&](int c) {
-    const unsigned pb = smem_base + (pbufs == 2 ? (c & 1) : 0) * PATCH_BYTES + wave * (8 * kRowBytes);
-#pragma unroll
-    for (int i = 0; i < MAXPASS; ++i)
-      if (i < npass) glds16(prow[i] ? prow[i] + c * BK : zero_src, pb + i * (64 * kRowBytes));
-  };
-  auto dma_group = [&](int g) {
-    const int c = g / 3, kh = g - c * 3;
-    const unsigned wb = wring + (g % 3) * GSTAGE + wave * (8 * kRowBytes);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < DW; ++i)
-        glds16(wrow[i] ? wrow[i] + (long long)(kh * 3 + t) * p.C + c * BK : zero_src,
-               wb + t * WSTAGE + i * (64 * kRowBytes));
-  };
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fk = lane >> 4;
-
-  // Weight ring of three filter-row groups (slot g % 3).  Issue order: patch(0), G0, G1, G2;
-  // step g (after its barrier) refills the slot consumed in step g-1 with group g+2 and, at the
-  // middle row of a chunk, prefetches the next chunk's patch.  The counted wait of step g lets
-  // everything issued after group g stay in flight.
-  dma_patch(0);
-  dma_group(0);
-  if (ngroups > 1) dma_group(1);
-  if (ngroups > 2) dma_group(2);
-#pragma unroll
-  for (int g = 0; g < ngroups; ++g) {
-    const int c = g / 3, kh = g - c * 3;
-    if (pbufs == 1 && kh == 0 && c > 0) {
-      // single patch buffer: everyone is done with the previous chunk (barrier of this step
-      // below would come too late), so drain, stage, and wait here
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      dma_patch(c);
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    } else if (g + 1 >= ngroups) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else if (g == 0) {
-      if (ngroups > 2)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * DG) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DG) : "memory");
-    } else if (pbufs == 2 && kh == 2 && c + 1 < nchunks) {  // next patch was issued after group g
-      if (npass == 6)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DG + 6) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DG + 5) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DG) : "memory");
-    }
-    if (g >= 1 && g + 2 < ngroups) dma_group(g + 2);
-    if (pbufs == 2 && kh == 1 && c + 1 < nchunks) dma_patch(c + 1);
-
-    const unsigned char* sp = smem + (pbufs == 2 ? (c & 1) : 0) * PATCH_BYTES;
-    const unsigned char* sg = smem + pbufs * PATCH_BYTES + (g % 3) * GSTAGE;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int shift = FLIP ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
-      const unsigned char* sw = sg + kw * WSTAGE;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint4 fw[TN], fa[TM];
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int r = wn * (BN / 2) + i * 16 + frow;
-          fw[i] = *reinterpret_cast<const uint4*>(sw + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const int r = wm * 64 + j * 16 + frow + shift;
-          fa[j] = *reinterpret_cast<const uint4*>(sp + r * kRowBytes + (((kk * 4 + fk) ^ (r & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) QtMma<T>::run(acc[i][j], fw[i], fa[j]);
-      }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-  // ---- epilogue: accumulators -> LDS f32 [BM][BN] (chunk-swizzled) -> dense NHWC rows ----
-  constexpr int ROWB = BN * 4;
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int pm = wm * 64 + j * 16 + frow;
-      const int c16 = (wn * (BN / 2) + i * 16 + fk * 4) >> 2;
-      *reinterpret_cast<f32x4*>(smem + pm * ROWB + ((c16 ^ (pm & 7)) << 4)) = acc[i][j];
-    }
-  __syncthreads();
-
-  patch_epilogue<T, BN, NT>(p, smem, q0, mt, n0, tid);
-}
-
-template <typename T, int BN, int WW, bool FLIP, int NCHUNKS, int PBUFS>
-int launch_patch(PatchArgs a, hipStream_t stream) {
-  constexpr int PR = (BM + 2 * (WW + 2) + 2 + 63) / 64 * 64;
-  constexpr int lds_loop = PBUFS * PR * kRowBytes + 9 * BN * kRowBytes;
-  constexpr int lds_epi = BM * BN * 4;
-  constexpr int red = (NT / (BN / 8)) * BN * 3 * 4;
-  constexpr int lds = lds_loop > lds_epi ? (lds_loop > red ? lds_loop : red) : (lds_epi > red ? lds_epi : red);
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_patch_kernel<T, BN, WW, FLIP, NCHUNKS, PBUFS>;
-  static std::atomic<unsigned long long> lds_limit_set{0};  // per device
-  if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), lds, lds_limit_set)) return rc;
-  a.PR = PR;
-  a.pbufs = PBUFS;
-  a.gridM = qt_cdiv(a.Q, BM);
-  a.gridN = qt_cdiv(a.N, BN);
-  hipLaunchKernelGGL(kern, dim3(a.gridM * a.gridN), dim3(NT), lds, stream, a);
-  QT_CHECK_LAUNCH();
-  return QT_OK;
-}
-
-template <typename T, int WW, int NCHUNKS, int PBUFS>
-int launch_patch_flip(const PatchArgs& a, hipStream_t stream) {
-  return a.flip ? launch_patch<T, 64, WW, true, NCHUNKS, PBUFS>(a, stream)
-                : launch_patch<T, 64, WW, false, NCHUNKS, PBUFS>(a, stream);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Persistent variant for ResNet layer1 (56x56 map, 64 -> 64 channels, bf16; forward and data
@@ -747,7 +425,7 @@ int launch_l1_ring(PatchArgs a, hipStream_t stream) {
 // 288 weight VGPRs, double-buffered patch) was also measured: 200 us, slower still; it is in
 // the git history (commit "persistent layer1 kernel"), not in the tree.  QTCNN_PATCH_CONV=1 or qt_set_patch_conv(1) turns it on.
 static int g_patch_enabled = -1;
-extern "C" void qt_set_patch_conv(int mode) { g_patch_enabled = mode < 0 ? 2 : (mode > 2 ? 2 : mode); }
+extern "C" void qt_set_patch_conv(int mode) { g_patch_enabled = mode < 0 ? 2 : (mode > 2 ? 2 : mode); }   // 0 = off, else on
 
 static bool l1_ring_shape(const qt_conv_desc* d);
 
@@ -756,15 +434,10 @@ bool qt_patch_eligible(const qt_conv_desc* d) {
     const char* v = getenv("QTCNN_PATCH_CONV");
     g_patch_enabled = v ? atoi(v) : 2;
   }
-  // 0: never; 1: every eligible shape (experimental one-tile-per-workgroup kernel included);
-  // 2 (default): only the shape served by the persistent ring kernel, which is a measured win
+  // 0: never; otherwise the shape served by the persistent ring kernel
   if (!g_patch_enabled) return false;
-  if (g_patch_enabled == 2 && !l1_ring_shape(d)) return false;
-  const int bk = d->dtype == QT_F32 ? 32 : 64;
-  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && !d->quad && !d->dst_sub &&
-         d->in_h == d->out_h && d->in_w == d->out_w && d->in_h == d->in_w &&
-         ((d->in_w == 56 && d->k_per_tap == 64) || (d->in_w == 28 && d->k_per_tap == 128)) &&
-         d->k_per_tap % bk == 0 && d->n_out % 64 == 0 && d->src_pix_stride == d->k_per_tap &&
+  return l1_ring_shape(d) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && !d->quad && !d->dst_sub &&
+         d->in_h == d->out_h && d->in_w == d->out_w && d->in_h == d->in_w && d->src_pix_stride == d->k_per_tap &&
          d->src_row_stride == d->in_w * d->k_per_tap &&
          d->src_img_stride == (long long)d->in_h * d->in_w * d->k_per_tap &&
          (long long)d->batch * (d->in_h + 2) * (d->in_w + 2) < (1ll << 31);
@@ -776,8 +449,7 @@ static bool l1_ring_shape(const qt_conv_desc* d) {
 
 int qt_patch_stats_rows(const qt_conv_desc* d) {
   const long long Q = (long long)d->batch * (d->in_h + 2) * (d->in_w + 2);
-  if (l1_ring_shape(d)) return l1_ring_grid(Q);  // the persistent kernel emits one row per workgroup
-  return qt_cdiv(Q, BM);
+  return l1_ring_grid(Q);  // the persistent kernel emits one row per workgroup
 }
 
 int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
@@ -799,14 +471,7 @@ int qt_patch_launch(const qt_conv_desc* d, const qt_conv_io* io, void* stream) {
   a.div_pw = make_fastdiv((unsigned)a.PW);
   a.gridM = a.gridN = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (l1_ring_shape(d)) {
-    const bool ops = a.residual || a.relu_mask || a.relu_mask_bits || a.bn_y[0];
-    if (a.flip) return ops ? launch_l1_ring<true, true>(a, s) : launch_l1_ring<true, false>(a, s);
-    return ops ? launch_l1_ring<false, true>(a, s) : launch_l1_ring<false, false>(a, s);
-  }
-  // 64-channel tiles: all nine taps of a chunk fit the LDS ring, three taps per barrier.
-  // bf16: one 64-channel chunk per 128 bytes; f32: 32 channels per chunk.
-  if (d->dtype == QT_BF16)
-    return a.W == 56 ? launch_patch_flip<bf16_t, 56, 1, 1>(a, s) : launch_patch_flip<bf16_t, 28, 2, 2>(a, s);
-  return a.W == 56 ? launch_patch_flip<float, 56, 2, 1>(a, s) : launch_patch_flip<float, 28, 4, 2>(a, s);
+  const bool ops = a.residual || a.relu_mask || a.relu_mask_bits || a.bn_y[0];
+  if (a.flip) return ops ? launch_l1_ring<true, true>(a, s) : launch_l1_ring<true, false>(a, s);
+  return ops ? launch_l1_ring<false, true>(a, s) : launch_l1_ring<false, false>(a, s);
 }

@@ -170,7 +170,7 @@ def test_quadrant_conv_fwd_and_dgrad(dt):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_patch_kernel_matches_generic_path(dt):
-    """The experimental LDS-resident-patch kernel (conv_patch.hip) behind the same entry point."""
+    """The layer-1 ring kernel (conv_patch.hip) behind the same entry point, next to shapes it leaves to the other kernels."""
     _dev()
     L = pkg("_lib")
     lib = L.lib()
