@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 name = sys.argv[1] if len(sys.argv) > 1 else "profile"
@@ -24,9 +25,15 @@ src = os.path.join(root, "gpurun_out", name)
 
 
 def family(kernel):
-    if model != "quadtree":   # other models: the kernel's own name without template arguments
-        k = kernel.split("(")[0].split("<")[0].split()[-1] if kernel.strip() else "other"
-        return k.split("::")[-1]
+    if model != "quadtree":   # other models: the kernel's own name without template / call arguments
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kernel)          # mangled: length-prefixed name behind the anonymous namespace
+        if m:
+            n = int(m.group(1))
+            return kernel[m.end():m.end() + n]
+        k = re.sub(r"\(anonymous namespace\)::", "", kernel)
+        k = re.sub(r"^(void|int)\s+", "", k.strip())
+        k = re.split(r"[<(]", k, maxsplit=1)[0].strip()
+        return k.split("::")[-1] or "other"
     for key in ("conv_igemm_kernel", "conv_pt_kernel", "conv_s2_kernel", "stem_bn_bwd_apply2x2", "stem_wgrad_rows", "conv_wgrad_tile_kernel", "conv_wgrad_patch_kernel", "conv_wgrad_s2_kernel", "conv_wgrad_kernel", "conv_l1_ring_kernel",
                 "conv_stem_kernel", "conv_patch_kernel", "wgrad_partial_sum", "bn_bwd_apply", "bn_bwd_reduce",
                 "bn_act", "stem_pool_bwd", "stem_bn_bwd_sums", "stem_pool", "pack_weights_batched",
