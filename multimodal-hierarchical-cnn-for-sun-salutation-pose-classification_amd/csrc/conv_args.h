@@ -54,5 +54,5 @@ struct ConvArgs {
 // conv_pt.hip (3x3 stride-1 convolutions of the 28x28 / 14x14 / 7x7 stages: input patch resident in LDS, ping-pong MFMA
 // schedule): does it take this problem, how many statistics rows (= pixel tiles) it writes, and its launch
 bool qt_pt_eligible(const qtc::ConvArgs& a, int dtype, bool dgrad);
-int qt_pt_stats_rows(const qtc::ConvArgs& a, int dtype, bool dgrad);
+int qt_pt_stats_rows(const qtc::ConvArgs& a, bool dgrad);
 int qt_pt_launch(const qtc::ConvArgs& a, int dtype, bool dgrad, hipStream_t stream);

@@ -698,7 +698,7 @@ extern "C" int qt_conv2d_stats_rows(const qt_conv_desc* d) {
     a.OH = d->out_h; a.OW = d->out_w; a.IH = d->in_h; a.IW = d->in_w;
     a.src_img_stride = d->src_img_stride; a.src_row_stride = d->src_row_stride; a.src_pix_stride = d->src_pix_stride;
     a.dst_merge = d->dst_merge; a.dst_h = d->dst_h; a.dst_w = d->dst_w;
-    if (!kt3 && qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->dtype, d->mode == QT_CONV_DGRAD);
+    if (!kt3 && qt_pt_eligible(a, d->dtype, d->mode == QT_CONV_DGRAD)) return qt_pt_stats_rows(a, d->mode == QT_CONV_DGRAD);
   }
   const int rows = qt_cdiv(M, tile_m(M, d->n_out, ((kt3 ? d->kt : 1) * d->kh * d->kw + (d->dst_merge_extra ? 1 : 0)) * d->k_per_tap * esz / kRowBytes));
   return d->dst_merge > 0 ? rows * (d->n_out / d->dst_merge) : rows;  // merged parity classes: one row per class

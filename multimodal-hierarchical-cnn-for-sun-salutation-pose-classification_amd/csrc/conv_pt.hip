@@ -66,11 +66,6 @@ struct PtArgs {
   // n*4 + q is quadrant q of map n.  1: forward, the SOURCE is the un-split map (zero halo at the seam comes for free:
   // the patch's pad positions); 2: data gradient, the DESTINATION is the un-split map.
   int quad;
-  // Persistent 128-channel tile with ONE channel tile (N = 128): the BatchNorm sums of a workgroup's items are added up in LDS
-  // (lane-private words: the same lane adds item after item, fixed order) and leave as TWO partial rows per workgroup (wave row
-  // 0 / 1) instead of two per item -- 512 rows instead of 2048 on the 28x28 stage, which the finalize kernels take without the
-  // 64:1 fold launch in front (round 4: a 5 us launch in the forward pass's single stream and in the backward's main chain).
-  int accum;
   FastDiv div_pw, div_hw, div_w;   // (div_hw / div_w: merged destination mapping)
 };
 
@@ -240,10 +235,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
                                                                     : v == 4 ? p.bn_mean[1] : p.bn_invstd[1];
       aff[i] = src ? src[c] : (v == 0 ? 1.f : 0.f);
     }
-  }
-  float* accl = aff + 6 * NC;   // [2 wave rows][3 sums][NC] f32 (q.accum; behind the six vectors: 6 * 512 words are allocated)
-  if (q.accum) {
-    for (int i = tid; i < 6 * NC; i += kNT) accl[i] = 0.f;   // (visible to every wave after the prologue's barrier)
   }
 
   // ---- per-thread staging rows -------------------------------------------------
@@ -696,14 +687,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
           s2[e] = qt_row16_sum(s2[e]);
           if constexpr (BWD) s3[e] = qt_row16_sum(s3[e]);
         }
-        if (frow == 0 && q.accum) {   // (uniform per launch) this lane's words of the workgroup's running sums
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            accl[(wm * 3 + 0) * NC + c0 + e] += s1[e];
-            accl[(wm * 3 + 1) * NC + c0 + e] += s2[e];
-            if constexpr (BWD) accl[(wm * 3 + 2) * NC + c0 + e] += s3[e];
-          }
-        } else if (frow == 0) {
+        if (frow == 0) {
           float* o0 = BWD ? p.bn_partial[0] : p.stats_partial;
           const long long row = MERGE ? ((long long)mt * 2 + wm) * 4 + mcls : (long long)mt * 2 + wm;   // (merged: one row per class too)
 #pragma unroll
@@ -731,22 +715,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_pt_kernel(PtArgs q) {
   }
   // the branch-free slots of the last chunk wrote zeros into dead buffers: landed before the LDS changes hands
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (q.accum && want_stats) {   // (uniform) two partial rows per workgroup: wave row 0 / 1
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both groups have taken the same number of barriers by now
-    float* o0 = BWD ? p.bn_partial[0] : p.stats_partial;
-    for (int i = tid; i < 2 * NC; i += kNT) {
-      const int w = i / NC, c = i - w * NC;
-      const long long row = (long long)wg * 2 + w;
-      o0[(row * 2 + 0) * NC + c] = accl[(w * 3 + 0) * NC + c];
-      o0[(row * 2 + 1) * NC + c] = accl[(w * 3 + 1) * NC + c];
-      if constexpr (BWD) {
-        if (p.bn_y[1]) {
-          p.bn_partial[1][(row * 2 + 0) * NC + c] = accl[(w * 3 + 0) * NC + c];
-          p.bn_partial[1][(row * 2 + 1) * NC + c] = accl[(w * 3 + 2) * NC + c];
-        }
-      }
-    }
-  }
 }
 
 // geometry of the 196-pixel tiles for an H x W image; false: shape not covered
@@ -805,21 +773,6 @@ inline int pt_workgroups() {
   return cus;
 }
 
-// sums added up per workgroup (PtArgs::accum): the persistent 128-channel tile with a single channel tile and several items
-// per workgroup; QTCNN_PT_ACCUM=0 switches it off (same-box A/B)
-inline bool pt_accum_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("QTCNN_PT_ACCUM");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
-template <int BN, int NTAPS, bool KS>
-inline bool pt_accum(int N, int ipw) {
-  return BN == 128 && !KS && NTAPS == 9 && N == 128 && ipw >= 2 && pt_accum_enabled();
-}
-
 template <typename T, int BN, int NBW, int NPASS, int GEO, bool DGRAD, int NTAPS = 9, bool KS = false>
 int launch(PtArgs q, hipStream_t stream) {
   constexpr int lds = 2 * NPASS * 64 * kKB + NBW * BN * kKB + (BN == 128 ? 6 * 512 * 4 : 0);   // (+ the epilogue's vectors)
@@ -831,7 +784,6 @@ int launch(PtArgs q, hipStream_t stream) {
   q.c.gridM = q.tiles_m;
   q.items = q.tiles_m * q.c.gridN;
   q.ipw = (BN == 128 && !KS) ? qt_cdiv(q.items, pt_workgroups()) : 1;
-  q.accum = pt_accum<BN, NTAPS, KS>(q.c.N, q.ipw) ? 1 : 0;
   q.stagger = (q.ipw >= 2 || pt_stagger(DGRAD || NTAPS == 4) < 0) ? pt_stagger(DGRAD || NTAPS == 4) : 0;   // (< 0: experiment builds)
 #ifdef QT_KERNEL_PROF
   q.prof = g_pt_prof;
@@ -977,7 +929,7 @@ bool qt_pt_eligible(const ConvArgs& a, int dtype, bool dgrad) {
   return true;
 }
 
-int qt_pt_stats_rows(const ConvArgs& a, int dtype, bool dgrad) {
+int qt_pt_stats_rows(const ConvArgs& a, bool dgrad) {
   PtArgs q;
   int quad;
   if (a.dst_merge) {   // (pixel tile, wave row, class)
@@ -985,16 +937,7 @@ int qt_pt_stats_rows(const ConvArgs& a, int dtype, bool dgrad) {
     return 2 * 4 * pt_tiles_m(q, a.M / (a.OH * a.OW));
   }
   pt_geometry(a.IH, a.IW, q);
-  const int tiles_m = pt_tiles_m(q, pt_images(a, dgrad, &quad));
-  // (mirrors dispatch<>: which instantiation the problem takes, and whether that one adds its items' sums up per workgroup)
-  const bool bf16 = dtype == QT_BF16;
-  const bool ks = bf16 && ksplit_enabled() && g_pt_max_wgs_fwd == 0 && (q.G == 4 || (q.npass == 5 && ksplit_enabled_rows()));
-  const bool bn256 = !ks && q.G != 4 && q.npass == 4 && bf16 && pt_bn(a) == 256;
-  if (!ks && !bn256) {
-    const int ipw = qt_cdiv(tiles_m * (a.N / 128), pt_workgroups());
-    if (pt_accum<128, 9, false>(a.N, ipw)) return 2 * qt_cdiv(tiles_m, ipw);   // two rows per workgroup
-  }
-  return 2 * tiles_m;   // one partial row per (pixel tile, wave row)
+  return 2 * pt_tiles_m(q, pt_images(a, dgrad, &quad));   // one partial row per (pixel tile, wave row)
 }
 
 int qt_pt_launch(const ConvArgs& a, int dtype, bool dgrad, hipStream_t stream) {
