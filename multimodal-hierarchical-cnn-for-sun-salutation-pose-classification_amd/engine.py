@@ -224,14 +224,13 @@ class PlanEngine:
         self.fwd_counter += 1
         return logits
 
-    def backward(self, dlogits, numerical, wanted):
-        """wanted: list of (plan tensor index, shape) in the order gradients are
-        returned.  Gradients are views of one flat f32 buffer laid out
-        [head | layer4 | layer3 + layer2 | layer1 + stem]: the order in which backward finishes them, so a
-        data-parallel caller all-reduces four buckets (59 / 34 / 10.5 / 0.6 MB), each while the next phase
-        runs; only the last, smallest one is exposed."""
+    @staticmethod
+    def gradient_buckets(names, wanted):
+        """Layout of the flat f32 gradient buffer: `wanted` = [(plan tensor index, shape)] -> (offset of every tensor, its
+        element count, the END offset of each of the four phase buckets [head | layer4 | layer3 + layer2 | layer1 + stem],
+        total elements).  Pure host arithmetic (tests/test_boundary_cpu.py pins the bucket sizes of SURVEY.md 8e with it)."""
         def bucket_of(idx):
-            name = self.names[idx]
+            name = names[idx]
             if not name.startswith("base_cnn."):
                 return 0
             if name.startswith("base_cnn.layer4."):
@@ -247,6 +246,15 @@ class PlanEngine:
             ends[bucket_of(idx)] = total
         for b in range(1, 4):
             ends[b] = max(ends[b], ends[b - 1])
+        return offs, sizes, ends, total
+
+    def backward(self, dlogits, numerical, wanted):
+        """wanted: list of (plan tensor index, shape) in the order gradients are
+        returned.  Gradients are views of one flat f32 buffer laid out
+        [head | layer4 | layer3 + layer2 | layer1 + stem]: the order in which backward finishes them, so a
+        data-parallel caller all-reduces four buckets (59 / 34 / 10.5 / 0.6 MB), each while the next phase
+        runs; only the last, smallest one is exposed."""
+        offs, sizes, ends, total = self.gradient_buckets(self.names, wanted)
         # One flat buffer per (layout): re-used across steps unless a previous step's gradient views are still
         # referenced by the caller (`.grad` kept with zero_grad(set_to_none=False), accumulation, retained graphs):
         # then that step's buffer stays theirs and a fresh one is taken.

@@ -169,6 +169,36 @@ def test_plan_tensor_table_matches_module_tree():
     assert b"dtype" in L.qt_last_error()
 
 
+def test_gradient_buckets_are_the_surveyed_sizes():
+    """The flat gradient buffer of the all-trainable QuadtreeCNN (Quadtree_from scratch variant): 25,986,028 elements =
+    103.9 MB f32 per step (base_cnn.fc is never used and has no gradient) in the four phase buckets backward
+    finishes them in -- head 59.2 MB, layer4 33.6 MB, layers 3 + 2 10.5 MB, layer1 + stem 0.6 MB (only that one is exposed)."""
+    P = pkg()
+    eng = pkg("engine")
+    L = pkg("_lib").lib()
+    eng._bind_api(L)
+    model = P.QuadtreeCNN(12)
+    desc = eng.PlanDesc(1, 8, 12, 0, 0, 47, 0.5, 1e-5, 0.1, 0, 0)
+    h = ctypes.c_void_p()
+    assert L.qt_plan_create(ctypes.byref(desc), ctypes.byref(h)) == 0
+    names = [L.qt_plan_tensor_name(h, i).decode() for i in range(L.qt_plan_num_tensors(h))]
+    L.qt_plan_destroy(h)
+    index = {n: i for i, n in enumerate(names)}
+    seen, wanted = set(), []
+    for n, p in model.named_parameters():
+        pn = model._plan_name(n)
+        if pn.startswith("base_cnn.fc.") or pn in seen:
+            continue
+        seen.add(pn)
+        wanted.append((index[pn], tuple(p.shape)))
+    offs, sizes, ends, total = eng.PlanEngine.gradient_buckets(names, wanted)
+    assert sum(sizes.values()) == 25986028
+    assert 0 <= total - 25986028 <= 4 * len(wanted)          # (views padded to 16 bytes)
+    mb = [4 * (ends[b] - (ends[b - 1] if b else 0)) / 1e6 for b in range(4)]
+    assert [round(x, 1) for x in mb] == [59.2, 33.6, 10.5, 0.6], mb
+    assert len(set(offs.values())) == len(wanted) and all(o % 4 == 0 for o in offs.values())
+
+
 def test_conv_descriptor_validation_needs_no_device():
     """qt_conv2d_igemm refuses an inconsistent destination mapping (merged stride-2 data gradient, qtcnn.h) with a
     message and before any HIP call: runs on the CPU box, the pointers are never dereferenced."""
