@@ -61,4 +61,4 @@ for Cin, Cout, H, k in ((64, 128, 56, 3), (128, 256, 28, 3), (256, 512, 14, 3), 
         res[on] = timed(fn)
     lib.qt_set_wgrad_s2(-1)
     gf = 2.0 * B * Ho * Ho * Cin * Cout * k * k / 1e9
-    print(f"{Cin:4d}->{Cout:4d} {H}x{H} k{k}: parity-plane kernel {res[1]:7.1f} us ({gf / res[1] * 1e3 / 1e3:6.1f} TFLOP/s)   generic {res[0]:7.1f} us")
+    print(f"{Cin:4d}->{Cout:4d} {H}x{H} k{k}: parity-plane kernel {res[1]:7.1f} us ({gf / res[1] * 1e3:6.0f} TFLOP/s)   generic {res[0]:7.1f} us")
