@@ -57,8 +57,11 @@ struct WS2Args {
 
 __device__ __forceinline__ QT_LDS_AS s16x4* lds_tr_ptr(unsigned lds_byte) { return (QT_LDS_AS s16x4*)(size_t)lds_byte; }
 
-// NPL planes staged (4: conv1; 1: the downsample, plane (0,0) only), NTAP taps accumulated (9 / 1)
-template <int NPL, int NTAP>
+// NPL planes staged (4: conv1; 1: the downsample, plane (0,0) only), NTAP taps accumulated (9 / 1).
+// NB tile buffers (2 or 3: NB - 1 tiles of look-ahead -- the kernel is bound by the latency of its LDS-DMA, a tile's MFMAs
+// last 0.5 us); NU = LDS-DMA instructions EVERY wave issues per tile (its share of the plane units padded with transfers
+// through a zero-record resource into a spare KiB, + one dY unit), so that the counted wait below is an immediate.
+template <int NPL, int NTAP, int NB, int NU>
 __global__ __launch_bounds__(512) void conv_wgrad_s2_kernel(WS2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (lds_addr_of(smem) != 0) return;  // no static LDS in this kernel; addresses below are absolute
@@ -115,17 +118,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_s2_kernel(WS2Args a) {
     img1 = fdiv(g, a.div_pp);
     rem = g - img1 * (unsigned)a.PP;
   };
-  auto dma_tile = [&](int k) {   // tile k -> buffer k & 1
+  const unsigned spare = a.tab + 2u * (unsigned)tabn * 4u;   // a KiB behind the tables: where the padding transfers go
+  auto dma_tile = [&](int k, unsigned bufbase) {   // tile k -> the buffer at LDS byte `bufbase`: exactly NU instructions per wave
     const int q0 = p0 + k * T;
-    const unsigned bufbase = (unsigned)(k & 1) * a.bufb;
-    for (int u = wave; u < xunits; u += 8) {
-      const int pl = NPL == 1 ? 0 : u / xu, uu = NPL == 1 ? u : u - pl * xu;
+#pragma unroll
+    for (int j = 0; j < NU - 1; ++j) {
+      const int u = wave + 8 * j;
+      const bool live = u < xunits;   // (uniform)
+      const int uc = live ? u : 0;
+      const int pl = NPL == 1 ? 0 : uc / xu, uu = NPL == 1 ? uc : uc - pl * xu;
       unsigned img1, rem;
       split_pos(q0 - a.HL + 8 * uu, img1, rem);
       const unsigned plane_off = (unsigned)((pl >> 1) * a.x_rs + (pl & 1) * a.x_ps) * 2u;
       const unsigned base = sgpr((img1 - 1u) * a.x_is2 + (unsigned)c0 * 2u + plane_off);
       const unsigned tv = *reinterpret_cast<const unsigned*>(smem + tab_x + sgpr(rem) * 4u);
-      blds16(rx, tv + base + lane_c, 0u, sgpr(bufbase + (unsigned)pl * a.xrb + (unsigned)uu * 1024u));
+      i32x4 r_ = rx;
+      r_.z = (int)sgpr(live ? a.x_bytes : 0u);   // zero records: no memory traffic, zeros into the spare KiB
+      blds16(r_, tv + base + lane_c, 0u, sgpr(live ? bufbase + (unsigned)pl * a.xrb + (unsigned)uu * 1024u : spare));
     }
     {   // dY: T / 8 = 8 units, one per wave
       unsigned img1, rem;
@@ -162,13 +171,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_s2_kernel(WS2Args a) {
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // tables visible, then tile 0 into buffer 0
+  // tables visible, then tiles 0 .. NB-2 into buffers 0 .. NB-2 (tiles past the range read rows nobody multiplies)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  dma_tile(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < NB - 1; ++t) dma_tile(t, (unsigned)t * a.bufb);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU * (NB - 2)) : "memory");   // tile 0 has landed
 
+  unsigned wbuf = (unsigned)(NB - 1) * a.bufb;   // buffer the next DMA fills: (k + NB - 1) % NB
+  int rbuf = 0;                                  // buffer of tile k: k % NB
   for (int k = 0; k < ntiles; ++k) {
-    if (k + 1 < ntiles) dma_tile(k + 1);   // lands behind this tile's MFMAs
+    dma_tile(k + NB - 1, wbuf);   // lands behind the MFMAs of NB - 1 tiles
+    wbuf = wbuf + a.bufb == (unsigned)NB * a.bufb ? 0u : wbuf + a.bufb;
     // positions of the tile at or behind pend belong to the next range (or lie past the tensor: zeros): a range is a whole
     // number of tiles except the last one, whose tail is past the tensor
     uint4 fa[4], fb[3];
@@ -186,8 +199,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_s2_kernel(WS2Args a) {
                                                             __builtin_bit_cast(bf16x8, fb[t % 3]), acc[i][t], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
-    {  // fragment bases -> the other buffer
-      const unsigned delta = (k & 1) ? 0u - a.bufb : a.bufb;
+    {  // fragment bases -> the next buffer
+      rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
+      const unsigned delta = rbuf == 0 ? 0u - (unsigned)(NB - 1) * a.bufb : a.bufb;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         a_base[i] += delta;
@@ -199,9 +213,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_s2_kernel(WS2Args a) {
         asm volatile("" : "+v"(b_base[t]));
       }
     }
-    // the next tile has landed (this wave's share; the barrier makes it everybody's) and nobody reads this buffer again
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // tile k + 1 has landed -- vmcnt retires in issue order: at most the NU (NB - 2) instructions of the tiles behind it are
+    // outstanding -- (this wave's share; the barrier makes it everybody's) and nobody reads this tile's buffer again
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU * (NB - 2)) : "memory");
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the look-ahead tiles past the range: landed before the LDS changes hands)
+  __syncthreads();
 
   // ---- group 1 hands o-blocks 0,1 to group 0 and takes o-blocks 2,3 from it ----
   {
@@ -265,6 +282,16 @@ bool s2_enabled() {
   return g_wgrad_s2 != 0;
 }
 
+// QTCNN_S2_BUFFERS (default 3): tile buffers of the stride-2 weight-gradient kernel where the LDS holds them (2: round-4 first form)
+int s2_buffers() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("QTCNN_S2_BUFFERS");
+    v = e ? atoi(e) : 3;
+  }
+  return v;
+}
+
 void split_ranges(int total, int tiles, int* pps_out, int* nsplit_out) {
   int nsplit = 256 / tiles;
   if (nsplit < 1) nsplit = 1;
@@ -291,7 +318,9 @@ bool qt_wgrad_s2_eligible(const qt_conv_desc* d) {
   if ((long long)d->batch * (d->out_h + 1) * (d->out_w + 1) >= (1ll << 30)) return false;
   const int PW = d->out_w + 1, HL = (PW + 1 + 7) / 8 * 8;
   const unsigned npl = k3 ? 4u : 1u;
-  const unsigned lds = 2u * ((npl * (unsigned)(T + HL) + (unsigned)T) * 128u) + 2u * (unsigned)((d->out_h + 1) * PW + 8) * 4u;
+  const unsigned lds = 2u * ((npl * (unsigned)(T + HL) + (unsigned)T) * 128u) + 2u * (unsigned)((d->out_h + 1) * PW + 8) * 4u + 1024u;
+  const int nu = qt_cdiv((int)npl * ((T + HL) / 8), 8) + 1;   // (the instantiated DMA counts per wave and tile: see the launcher)
+  if (k3 ? (nu != 6 && nu != 7) : (nu != 2 && nu != 3)) return false;
   return lds <= 160u * 1024u && HL <= (d->out_h + 1) * PW;
 }
 
@@ -336,28 +365,45 @@ int qt_wgrad_s2_launch(const qt_conv_desc* d, const void* dy, const void* x, flo
   }
   a.xrb = (unsigned)(T + a.HL) * 128u;
   a.bufb = (unsigned)npl * a.xrb + (unsigned)T * 128u;
-  a.tab = 2u * a.bufb;
+  const unsigned tab_bytes = 2u * (unsigned)(a.PP + 8) * 4u + 1024u;   // offset tables + the spare KiB of the padding transfers
+  const int nb = (3u * a.bufb + tab_bytes <= 160u * 1024u && s2_buffers() >= 3) ? 3 : 2;
+  a.tab = (unsigned)nb * a.bufb;
+  const int nu = qt_cdiv(npl * ((T + a.HL) / 8), 8) + 1;   // plane units per wave (rounded up) + its dY unit
   for (int t = 0; t < 9; ++t) {
     const int kh = k3 ? t / 3 : 1, kw = k3 ? t % 3 : 1;
     a.tap_plane[t] = k3 ? ((kh != 1) * 2 + (kw != 1)) : 0;
     a.tap_shift[t] = -((kh == 0) * a.PW + (kw == 0));
   }
-  const unsigned lds = a.tab + 2u * (unsigned)(a.PP + 8) * 4u;
+  const unsigned lds = a.tab + tab_bytes;
   // (the exchange at the end lives in the buffers: 4 x 2 NTAP x 64 lanes x 16 B)
   if ((size_t)2 * a.bufb < (size_t)4 * 2 * ntap * 64 * 16) {
     qt_set_error("qt_conv2d_wgrad_oihw: map too small for the stride-2 kernel");
     return QT_ERR_UNSUPPORTED;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static std::atomic<unsigned long long> set9{0}, set1{0};  // per device
-  if (k3) {
-    auto kern = conv_wgrad_s2_kernel<4, 9>;
-    if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024, set9)) return rc;   // (once per device: the largest any shape takes)
-    hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(512), lds, s, a);
-  } else {
-    auto kern = conv_wgrad_s2_kernel<1, 1>;
-    if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024, set1)) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(512), lds, s, a);
+  // instantiations: (planes, taps, buffers, DMA instructions per wave and tile); nu = 6 / 7 for HL = 16 / 32 with four planes,
+  // 2 / 3 (one plane: 10 / 12 units over 8 waves) -- anything else takes the generic kernel
+#define QT_S2_LAUNCH(NPL_, NTAP_, NB_, NU_)                                                                     \
+  {                                                                                                             \
+    auto kern = conv_wgrad_s2_kernel<NPL_, NTAP_, NB_, NU_>;                                                    \
+    static std::atomic<unsigned long long> set_{0};                                                             \
+    if (int rc = qt_raise_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024, set_)) return rc;          \
+    hipLaunchKernelGGL(kern, dim3(a.tiles * a.nsplit), dim3(512), lds, s, a);                                   \
+    launched = true;                                                                                            \
+  }
+  bool launched = false;
+  if (k3 && nb == 3 && nu == 6) QT_S2_LAUNCH(4, 9, 3, 6)
+  else if (k3 && nb == 3 && nu == 7) QT_S2_LAUNCH(4, 9, 3, 7)
+  else if (k3 && nu == 6) QT_S2_LAUNCH(4, 9, 2, 6)
+  else if (k3 && nu == 7) QT_S2_LAUNCH(4, 9, 2, 7)
+  else if (!k3 && nb == 3 && nu == 3) QT_S2_LAUNCH(1, 1, 3, 3)
+  else if (!k3 && nb == 3 && nu == 2) QT_S2_LAUNCH(1, 1, 3, 2)
+  else if (!k3 && nu == 3) QT_S2_LAUNCH(1, 1, 2, 3)
+  else if (!k3 && nu == 2) QT_S2_LAUNCH(1, 1, 2, 2)
+#undef QT_S2_LAUNCH
+  if (!launched) {
+    qt_set_error("qt_conv2d_wgrad_oihw: stride-2 kernel: no instantiation for this map width");
+    return QT_ERR_UNSUPPORTED;
   }
   QT_CHECK_LAUNCH();
   return qt_wgrad_partial_sum_launch(a.part, grad_oihw, filt, real_split, a.KC, k3 ? 1 : 2, s);
