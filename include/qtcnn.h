@@ -546,13 +546,14 @@ int qt_conv3d_first_stats_rows(int batch, int frames, int h, int w);
 int qt_conv3d_c32_stats_rows(int batch, int frames, int h, int w);
 int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const void* w_packed, void* y, const float* scale,
                       const float* shift, int relu, float* stats, int batch, int frames, int h, int w, void* stream);
-/* ... and its data gradient: dx [T][B][H][W][64] (channels 0..31 = d(loss)/d(input), 32..63 zero) from dy
+/* ... and its data gradient: dx [T][B][H][W][dx_channels] (channels 0..31 = d(loss)/d(input); dx_channels = 64: channels
+ * 32..63 written as zeros, the rows a 64-channel-padded conv3d_block1 reads; 32: no padding, round 4) from dy
  * [T][B][H][W][64] and qt_pack_conv3d_block's data-gradient filter [64][27][64] ([input channel][tap][output channel]): the
  * same slab walk over dy with the flipped filter, as two launches over dy's channel halves joined through an f32 scratch
  * (qt_conv3d_c32_dgrad_scratch_bytes; 0 = shape not covered, take qt_conv2d_igemm in QT_CONV_DGRAD mode). */
 size_t qt_conv3d_c32_dgrad_scratch_bytes(int batch, int frames, int h, int w);
-int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, void* scratch, size_t scratch_bytes,
-                        int batch, int frames, int h, int w, void* stream);
+int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, int dx_channels, void* scratch,
+                        size_t scratch_bytes, int batch, int frames, int h, int w, void* stream);
 /* ... and its weight gradient: dweight [64][32][3][3][3] f32 in nn.Conv3d's layout (every element written) from x (channels
  * 0..31 of x_channels-wide rows) and dy [T][B][H][W][64]; the contraction runs over positions with both operands read
  * through transposing LDS reads; per-workgroup partial filters in `workspace` (qt_conv3d_c32_wgrad_workspace_bytes; 0 = shape

@@ -34,13 +34,14 @@ struct S3Args {
   float* stats;           // [gridDim.x][2][64] or NULL
   float* scratch;         // data gradient: f32 [T][B][H][W][32] partial sums between its two passes
   int relu, B, T, H, W, xc, items;
+  int yc;                 // OUT == 2: channels per row of y (64: channels 32..63 written as zeros; 32: none)
   int coff;               // first of the 32 channels of x (and of the filter's K rows) this launch reads
 };
 
 // NB = 16-channel output blocks (4: the forward's 64 channels; 2: the data gradient's 32 input channels, waves (block, quarter
 // of the pixel blocks)).  FLIP: tap (kt, kh, kw) multiplies filter tap 26 - index (the data gradient is the same walk over dy
 // with the flipped filter [I][27][O]).  OUT: 0 = bf16 rows of 64 (NB * 16 channels written); 1 = f32 partial sums to
-// scratch; 2 = scratch + accumulator -> bf16 rows of 64, channels 32..63 zero.  The data gradient contracts over 64 channels =
+// scratch; 2 = scratch + accumulator -> bf16 rows of yc = 64 (channels 32..63 zero) or 32 channels.  The data gradient contracts over 64 channels =
 // two launches of 32 (coff 0 / 32: an LDS ring of 64-channel slabs would need 233 KB), joined through the f32 scratch.
 template <bool AFF, bool STATS, int NB = 4, bool FLIP = false, int OUT = 0>
 __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
@@ -91,19 +92,40 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
   };
 
   const int slabs_per_img = H / S3_R, nmb = S3_R * nbw;
+  // OUT == 2: the first pass's partial sums of a frame's pixel blocks (W <= 128: at most two rounds of two blocks per wave) are
+  // requested a frame ahead.  (Loaded where they are added they cost a memory latency per pixel block with nothing to hide it:
+  // 968 us for this pass against 330 us for the first one at 32 clips x 8 frames of 112 x 112.)
+  float4 qc[4], qn[4];
+  auto load_partials = [&](int b, int t, int h0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int m = half + (k >> 1) * 2 * PARTS + (k & 1) * PARTS;
+      if (m < nmb) {
+        const int rr = m / nbw, cc = m - rr * nbw;
+        const size_t pos = (((size_t)t * p.B + b) * H + h0 + rr) * W + cc * 16 + li;
+        qn[k] = *reinterpret_cast<const float4*>(p.scratch + pos * 32 + nb * 16 + lg * 4);
+      }
+    }
+  };
   __syncthreads();   // the zero fill (halo columns) is complete before any DMA lands
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = item / slabs_per_img, h0 = (item - b * slabs_per_img) * S3_R;
     // (every wave passed the barrier after the previous item's last frame: the ring is free)
+    if (OUT == 2) load_partials(b, 0, h0);
     dma_frame(b, 0, h0);
     if (T > 1) dma_frame(b, 1, h0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < T; ++t) {
+      if (OUT == 2) {   // (in front of the DMA in issue order: the frame's closing vmcnt(0) then waits for loads a frame old)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qc[k] = qn[k];
+        if (t + 1 < T) load_partials(b, t + 1, h0);
+      }
       if (t + 2 < T) dma_frame(b, t + 2, h0);   // into the slot of frame t - 2, which every wave finished before the last barrier
 
       const int kt_lo = t == 0 ? 1 : 0, kt_hi = t + 1 < T ? 2 : 1;
-      for (int mb = half; mb < nmb; mb += 2 * PARTS) {   // two pixel blocks (mb, mb + PARTS) interleaved
+      auto round = [&](const int it, const int mb) {   // two pixel blocks (mb, mb + PARTS) interleaved
         const int mb1 = mb + PARTS;
         const bool two = mb1 < nmb;
         const int r0 = mb / nbw, c0 = mb - r0 * nbw;
@@ -154,15 +176,23 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
             continue;
           }
           if (OUT == 2) {
-            const float4 q = *reinterpret_cast<const float4*>(p.scratch + pos * 32 + nb * 16 + lg * 4);
+            const float4 q = qc[it * 2 + u];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
           }
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          *reinterpret_cast<bf16x4*>(p.y + pos * 64 + nb * 16 + lg * 4) = o;
-          if (OUT == 2) *reinterpret_cast<uint2*>(p.y + pos * 64 + 32 + nb * 16 + lg * 4) = make_uint2(0u, 0u);
+          const int yc = OUT == 2 ? p.yc : 64;
+          *reinterpret_cast<bf16x4*>(p.y + pos * yc + nb * 16 + lg * 4) = o;
+          if (OUT == 2 && yc > 32) *reinterpret_cast<uint2*>(p.y + pos * 64 + 32 + nb * 16 + lg * 4) = make_uint2(0u, 0u);
         }
+      };
+      if constexpr (OUT == 2) {   // (unrolled: the prefetched partial sums are registers)
+        static_assert(NB == 2, "the joining pass: two rounds per wave and frame at W <= 128");
+        if (half < nmb) round(0, half);
+        if (half + 2 * PARTS < nmb) round(1, half + 2 * PARTS);
+      } else {
+        for (int mb = half; mb < nmb; mb += 2 * PARTS) round(0, mb);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of frame t + 2 has landed
       __syncthreads();                                     // ... everyone's has, and everyone is done with output frame t
@@ -401,7 +431,7 @@ extern "C" int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const
   S3Args a;
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)y; a.scale = scale; a.shift = shift; a.stats = stats;
   a.relu = relu; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = x_channels; a.items = batch * (h / S3_R);
-  a.scratch = nullptr; a.coff = 0;
+  a.scratch = nullptr; a.coff = 0; a.yc = 64;
   int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
   if (lds < 2 * 2 * 64 * 4) lds = 2 * 2 * 64 * 4;
   const dim3 grid(s3_grid(a.items)), blk(512);
@@ -424,16 +454,17 @@ extern "C" int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const
   return QT_OK;
 }
 
-// Data gradient of the same layer: dx [T][B][H][W][64] (channels 0..31 = d(loss)/d(input), 32..63 zero) from
+// Data gradient of the same layer: dx [T][B][H][W][dx_channels] (channels 0..31 = d(loss)/d(input); dx_channels = 64: 32..63 zero) from
 // dy [T][B][H][W][64] and qt_pack_conv3d_block's data-gradient filter [64][27][64] ([input channel][tap][output channel]).
 // Two launches of the slab kernel over dy's channels 0..31 / 32..63 joined through `scratch` (f32 [positions][32]).
 extern "C" size_t qt_conv3d_c32_dgrad_scratch_bytes(int batch, int frames, int h, int w) {
   return s3_shape_ok(batch, frames, h, w) ? (size_t)frames * batch * h * w * 32 * sizeof(float) : 0;
 }
 
-extern "C" int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, void* scratch,
+extern "C" int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgrad_packed, void* dx, int dx_channels, void* scratch,
                                    size_t scratch_bytes, int batch, int frames, int h, int w, void* stream) {
   QT_CHECK_ARG(dy && w_dgrad_packed && dx && batch > 0 && frames > 0 && h > 0 && w > 0, "qt_conv3d_c32_dgrad: bad argument");
+  QT_CHECK_ARG(dx_channels == 32 || dx_channels == 64, "qt_conv3d_c32_dgrad: dx rows of %d channels (32 or 64)", dx_channels);
   const size_t need = qt_conv3d_c32_dgrad_scratch_bytes(batch, frames, h, w);
   if (dtype != QT_BF16 || need == 0 || ((uintptr_t)dy % 16) != 0 || ((uintptr_t)w_dgrad_packed % 16) != 0 || ((uintptr_t)dx % 16) != 0) {
     qt_set_error("qt_conv3d_c32_dgrad: bf16, even H, W %% 16 == 0, W <= 128, 16-byte aligned operands only (use qt_conv2d_igemm "
@@ -445,7 +476,7 @@ extern "C" int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgra
   S3Args a;
   a.x = (const bf16_t*)dy; a.w = (const bf16_t*)w_dgrad_packed; a.y = (bf16_t*)dx; a.scale = nullptr; a.shift = nullptr;
   a.stats = nullptr; a.scratch = (float*)scratch;
-  a.relu = 0; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = 64; a.items = batch * (h / S3_R);
+  a.relu = 0; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = 64; a.yc = dx_channels; a.items = batch * (h / S3_R);
   const int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
   const dim3 grid(s3_grid(a.items)), blk(512);
   hipStream_t s = static_cast<hipStream_t>(stream);

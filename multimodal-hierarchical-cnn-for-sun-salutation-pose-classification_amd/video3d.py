@@ -195,13 +195,13 @@ class _Ops:
             ev[1].record()
             self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_FWD)))
 
-    def conv3d_c32_dgrad(self, dt, dy, wd, dx, scr, nscr, B, T, H, W, flops=0.0, nbytes=0.0):
+    def conv3d_c32_dgrad(self, dt, dy, wd, dx, dxc, scr, nscr, B, T, H, W, flops=0.0, nbytes=0.0):
         ev = None
         if self.timed is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        self.check(self.L.qt_conv3d_c32_dgrad(_lib.qt_dtype(dt), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(scr), _c.c_size_t(nscr), B, T, H, W,
-                                              _lib.stream_ptr()), "qt_conv3d_c32_dgrad")
+        self.check(self.L.qt_conv3d_c32_dgrad(_lib.qt_dtype(dt), _ptr(dy), _ptr(wd), _ptr(dx), dxc, _ptr(scr), _c.c_size_t(nscr), B, T,
+                                              H, W, _lib.stream_ptr()), "qt_conv3d_c32_dgrad")
         if ev is not None:
             ev[1].record()
             self.timed.append((ev[0], ev[1], float(flops), float(nbytes), int(_lib.QT_CONV_DGRAD)))
@@ -277,6 +277,9 @@ WGRAD_SIDE = os.environ.get("QTCNN_WGRAD_SIDE_STREAM", "1") != "0"
 PACK_CACHE = os.environ.get("QTCNN_PACK_CACHE", "1") != "0"
 # QTCNN_CONV3D_SLAB (default 1): conv3d_block2's forward on the slab-resident kernel (csrc/conv3d_slab.hip); 0: 27-tap implicit GEMM
 SLAB_C32 = os.environ.get("QTCNN_CONV3D_SLAB", "1") != "0"
+# QTCNN_POOLED32 (default 1): conv3d_block1's pooled map (and its argmax / raw-value companions, and the gradient block 2 sends
+# back) in 32-channel rows where block 2 runs on the slab kernels, which read 32 channels; 0: rows padded to 64 channels (round 3)
+POOLED32 = os.environ.get("QTCNN_POOLED32", "1") != "0"
 _side_streams = {}
 
 
@@ -329,6 +332,7 @@ class _ConvBlock:
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.cin_p = 128 if first else _cpad(self.cin)
         self.cout_p = _cpad(self.cout)
+        self.narrow_out = False   # set by the model: the next block is the 32 -> 64 one (reads 32 channels on the slab kernels)
         self._buf_key = None
 
     # -- operand packing: ONE launch per forward (weights may have changed: fused optimizers do not bump _version) --
@@ -375,6 +379,17 @@ class _ConvBlock:
         but the first: three launches per block and step)"""
         return v if v.shape[0] == self.cout and v.is_contiguous() else v[:self.cout].clone()
 
+    def _pooled_width(self, dt, B, T, H, W):
+        """channels per row of this block's pooled map [T][B][H][W][.]: 32 (no padding) when the next block's forward, data
+        gradient and weight gradient all run on the slab kernels at that size, else the padded width every other kernel reads"""
+        if not (POOLED32 and self.narrow_out and SLAB_C32 and dt == torch.bfloat16 and self.cout == 32):
+            return self.cout_p
+        L = ops().L
+        L.qt_conv3d_c32_dgrad_scratch_bytes.restype = _c.c_size_t
+        ok = (L.qt_conv3d_c32_stats_rows(B, T, H, W) > 0 and int(L.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W)) > 0
+              and self._slab_wgrad_bytes(B, T, H, W) > 0)
+        return 32 if ok else self.cout_p
+
     @staticmethod
     def _slab_wgrad_bytes(B, T, H, W):
         L = ops().L
@@ -416,10 +431,11 @@ class _ConvBlock:
                 return out, (T, H // 2, W // 2), None
             o.conv3d_first(dt, clip, self.wf, y, None, B, T, H, W, fl, nb)
         To, Ho, Wo = T // self.pool_t, H // 2, W // 2
-        out = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=dt, device=dev)
-        arg = torch.empty(To * B * Ho * Wo, self.cout_p, dtype=torch.uint8, device=dev) if keep else None
+        cp = self._pooled_width(dt, B, To, Ho, Wo)
+        out = torch.empty(To * B * Ho * Wo, cp, dtype=dt, device=dev)
+        arg = torch.empty(To * B * Ho * Wo, cp, dtype=torch.uint8, device=dev) if keep else None
         ymax = torch.empty_like(out) if keep else None
-        o.pool_bn(dt, y, stats, out, arg, ymax, T, B, H, W, self.cout_p, self.pool_t, cy=32)
+        o.pool_bn(dt, y, stats, out, arg, ymax, T, B, H, W, cp, self.pool_t, cy=32)
         saved = (clip, y, None, arg, stats, (T, B, H, W), training, out, ymax) if keep else None
         return out, (To, Ho, Wo), saved
 
@@ -448,8 +464,11 @@ class _ConvBlock:
             tk = dict(flops=fl, nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
 
             def conv(**kw):
-                o.conv3d_c32(dt, x, self.cin_p, self.wf, y, B, T, H, W, **kw, **tk)
+                o.conv3d_c32(dt, x, x.shape[1], self.wf, y, B, T, H, W, **kw, **tk)
         else:
+            if x.shape[1] != self.cin_p:
+                raise QtError(f"conv block: input rows of {x.shape[1]} channels, the implicit GEMM reads {self.cin_p}")
+
             def conv(**kw):
                 o.igemm(d, _ptr(x), _ptr(self.wf), _ptr(y), **kw, **tk)
         if training:
@@ -518,7 +537,8 @@ class _ConvBlock:
         if raw:
             o.L.qt_conv3d_first_wgrad_workspace_bytes.restype = _c.c_size_t
             raw_ws = int(o.L.qt_conv3d_first_wgrad_workspace_bytes(B, T, H, W))
-            dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, self.cout_p,
+            # (the pooled side's row width: 32 where block 2 runs on the slab kernels, else padded -- _pooled_width)
+            dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, pooled.shape[1],
                                                    self.pool_t, dev, training, cy=32, cd=32 if raw_ws else self.cout_p)
             if not raw_ws:   # (a width the raw weight-gradient kernel does not take: the packed rows after all)
                 x = o.pack_clip(dt, x, B, T, H, W)
@@ -537,10 +557,11 @@ class _ConvBlock:
         # under batch statistics cb = sum g / M and sum xhat = 0: the gradient of a bias in front of a train-mode
         # BatchNorm is zero (the reference's autograd returns rounding noise there); under running statistics
         # cb = cc = 0 and it is gamma invstd sum g = gamma invstd dbeta.
+        nv = dbeta.shape[0]   # (cout_p, or cout where the pooled side has no padding channels)
         if training:
-            db = torch.zeros(self.cout_p, dtype=torch.float32, device=dev)
+            db = torch.zeros(nv, dtype=torch.float32, device=dev)
         else:
-            db = self.gamma_p.detach().float() * stats[1] * dbeta
+            db = self.gamma_p.detach().float()[:nv] * stats[1][:nv] * dbeta
         slab = (SLAB_C32 and dt == torch.bfloat16 and self.cin == 32 and self.cout == 64 and self.cin_p == 64 and self.cout_p == 64
                 and dy.data_ptr() % 16 == 0)
 
@@ -560,10 +581,12 @@ class _ConvBlock:
                 # conv3d_block2: weight gradient on the slab-resident kernel (csrc/conv3d_slab.hip)
                 nws = self._slab_wgrad_bytes(B, T, H, W)
                 ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-                o.check(o.L.qt_conv3d_c32_wgrad(_lib.qt_dtype(dt), _ptr(x), self.cin_p, _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(nws), B,
+                o.check(o.L.qt_conv3d_c32_wgrad(_lib.qt_dtype(dt), _ptr(x), x.shape[1], _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(nws), B,
                                                 T, H, W, _lib.stream_ptr()), "qt_conv3d_c32_wgrad")
                 return dW
             else:
+                if x.shape[1] != self.cin_p:
+                    raise QtError(f"conv block: input rows of {x.shape[1]} channels, the tile weight gradient reads {self.cin_p}")
                 # one launch per frame tap over the contiguous range of frames the tap connects (the contraction runs over
                 # pixels: f32 sums, nothing accumulates through an activation map); with a workspace the bf16 build takes the
                 # tile-resident kernel and its fixed-order partial sums: deterministic, no float atomics
@@ -592,16 +615,18 @@ class _ConvBlock:
             dW = weight_gradient()
         dx = None
         if not self.first:   # data gradient: one 27-tap launch; conv3d_block2's on the slab-resident kernel (two passes)
-            dx = torch.empty(rows, self.cin_p, dtype=dt, device=dev)
+            dx = torch.empty(rows, x.shape[1], dtype=dt, device=dev)   # (rows as wide as the input's: the previous block's pooled map)
             nscr = 0
             if slab:
                 o.L.qt_conv3d_c32_dgrad_scratch_bytes.restype = _c.c_size_t
                 nscr = int(o.L.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
             if nscr:
                 scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
-                o.conv3d_c32_dgrad(dt, dy, self.wd, dx, scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
+                o.conv3d_c32_dgrad(dt, dy, self.wd, dx, dx.shape[1], scr, nscr, B, T, H, W, flops=2.0 * rows * 27 * self.cin * self.cout,
                                    nbytes=esz * (rows * (self.cin + self.cout_p) + 27.0 * self.cin * self.cout_p))
             else:
+                if dx.shape[1] != self.cin_p:
+                    raise QtError(f"conv block: input rows of {dx.shape[1]} channels, the implicit GEMM writes {self.cin_p}")
                 dd = self._desc(dt, _lib.QT_CONV_DGRAD, T, B, H, W)
                 o.igemm(dd, _ptr(dy), _ptr(self.wd), _ptr(dx), flops=2.0 * rows * 27 * self.cin * self.cout,
                         nbytes=esz * (rows * (self.cin_p + self.cout_p) + 27.0 * self.cin_p * self.cout_p))
@@ -712,7 +737,10 @@ class _ClipModel(nn.Module):
         """the conv blocks' executors (packed filter buffers) live as long as their modules do"""
         key = tuple((id(c), id(b), p, f) for c, b, p, f in specs)
         if self.__dict__.get("_blocks_key") != key:
-            self.__dict__["_blocks"] = [_ConvBlock(c, b, p, f) for c, b, p, f in specs]
+            blocks = [_ConvBlock(c, b, p, f) for c, b, p, f in specs]
+            for prev, nxt in zip(blocks, blocks[1:]):   # conv3d_block1 -> conv3d_block2 (32 -> 64): see _pooled_width
+                prev.narrow_out = prev.first and bool(prev.pool_t) and nxt.cin == 32 and nxt.cout == 64
+            self.__dict__["_blocks"] = blocks
             self.__dict__["_blocks_key"] = key
         return self.__dict__["_blocks"]
 

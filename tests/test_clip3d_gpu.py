@@ -372,12 +372,16 @@ def test_second_conv3d_with_frame_slabs_in_lds(cfg):
     nscr = int(lib.qt_conv3d_c32_dgrad_scratch_bytes(B, T, H, W))
     assert nscr == T * B * H * W * 32 * 4
     scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
-    dx = torch.full((T, B, H, W, 64), float("nan"), dtype=dt, device=dev)
-    L.check(lib.qt_conv3d_c32_dgrad(L.qt_dtype(dt), L.ptr(dyt.to(dev)), L.ptr(wdp), L.ptr(dx), L.ptr(scr), ctypes.c_size_t(nscr), B, T,
-                                    H, W, L.stream_ptr()), "qt_conv3d_c32_dgrad")
-    torch.cuda.synchronize()
-    assert rel_err(dx[..., :32].float().cpu(), xr.grad.permute(2, 0, 3, 4, 1)) <= 1e-2
-    assert (dx[..., 32:] == 0).all()
+    dyd = dyt.to(dev)
+    for dxc in (64, 32):   # rows padded to 64 channels (32..63 written as zeros), and 32-channel rows (round 4)
+        dx = torch.full((T, B, H, W, dxc), float("nan"), dtype=dt, device=dev)
+        L.check(lib.qt_conv3d_c32_dgrad(L.qt_dtype(dt), L.ptr(dyd), L.ptr(wdp), L.ptr(dx), dxc, L.ptr(scr), ctypes.c_size_t(nscr), B, T,
+                                        H, W, L.stream_ptr()), "qt_conv3d_c32_dgrad")
+        torch.cuda.synchronize()
+        assert rel_err(dx[..., :32].float().cpu(), xr.grad.permute(2, 0, 3, 4, 1)) <= 1e-2
+        assert (dx[..., 32:] == 0).all()
+    assert lib.qt_conv3d_c32_dgrad(L.qt_dtype(dt), L.ptr(dyd), L.ptr(wdp), L.ptr(dx), 48, L.ptr(scr), ctypes.c_size_t(nscr), B, T, H, W,
+                                   L.stream_ptr()) == -1
     # the weight gradient: contraction over positions, nn.Conv3d's layout, deterministic
     wr = w.clone().requires_grad_(True)
     F.conv3d(x, wr, None, 1, 1).backward(dyt.float().permute(1, 4, 0, 2, 3))
@@ -385,7 +389,6 @@ def test_second_conv3d_with_frame_slabs_in_lds(cfg):
     nws = int(lib.qt_conv3d_c32_wgrad_workspace_bytes(B, T, H, W))
     assert nws > 0
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    dyd = dyt.to(dev)
     outs = []
     for _ in range(2):
         dwt = torch.full((64, 32, 3, 3, 3), float("nan"), device=dev)
@@ -552,6 +555,37 @@ def test_quadtree3d_config4_size_matches_oracle():
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mm.parameters())
         del mm
         torch.cuda.empty_cache()
+
+
+def test_block1_pooled_map_in_32_channel_rows(monkeypatch):
+    """Round 4: where conv3d_block2 runs on the slab kernels, conv3d_block1's pooled map, its argmax / raw-value companions and
+    the gradient coming back are 32-channel rows (video3d._ConvBlock._pooled_width) instead of rows padded to 64: the same
+    forward bits, and the same gradients up to the order of the BatchNorm-backward partial sums."""
+    dev = _dev()
+    v3d = pkg("video3d")
+    B, T, HW = 2, 4, 64
+    x, f, y = (t.to(dev) for t in _inputs(B, T, HW, 5))
+    res = []
+    for narrow in (True, False):
+        monkeypatch.setattr(v3d, "POOLED32", narrow)
+        m = _build("quadtree_3d_fusion", T, torch.bfloat16).to(dev).train()
+        widths = []
+        orig = v3d._Ops.pool_bn
+
+        def spy(self, dt, y_, stats, out, *a, **k):
+            widths.append(out.shape[1])
+            return orig(self, dt, y_, stats, out, *a, **k)
+        monkeypatch.setattr(v3d._Ops, "pool_bn", spy)
+        out = m(x, f)
+        F.cross_entropy(out, y).backward()
+        monkeypatch.setattr(v3d._Ops, "pool_bn", orig)
+        assert widths[0] == (32 if narrow else 64), widths
+        res.append((out.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n, g32 in res[0][1].items():
+        if _is_conv_bias_before_bn(n):
+            continue
+        assert rel_err(g32.cpu(), res[1][1][n].cpu()) <= 2e-3, n
 
 
 def test_dropout_train_mode_and_eval_backward_and_errors():
