@@ -575,6 +575,18 @@ int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const void* w_packed
 size_t qt_conv3d_first_wgrad_workspace_bytes(int batch, int frames, int h, int w);
 int qt_conv3d_first_wgrad(int dtype, const float* clips, const void* dy, float* dweight, void* workspace,
                           size_t workspace_bytes, int batch, int frames, int h, int w, void* stream);
+/* Round 4: the same weight gradient with d(loss)/dy formed on the way in -- the backward of MaxPool3d((1,2,2)) + ReLU +
+ * BatchNorm3d of conv3d_block1 (/root/reference/3dcnn/models.py:108-112) inside the weight-gradient kernel: y = the raw conv
+ * output [T][B][H][W][32], dout / argmax [T][B][H/2][W/2][pooled_channels] (pooled_channels 32 or 64) = the gradient of the
+ * pooled map and qt_pool3d_bn_relu_max's argmax (pool_t = 1), mean / invstd / scale / shift = qt_bn_finalize's vectors,
+ * coef = qt_bn_bwd_finalize's [3][pooled_channels].  Replaces qt_pool3d_bn_bwd_apply (dy_channels = 32) +
+ * qt_conv3d_first_wgrad: dy (0.8 GB at 32 clips x 8 frames of 224 x 224) is neither written nor read.  The ReLU mask is
+ * recomputed from y (relu(y scale + shift) > 0) instead of read from the pooled map.  Workspace and shapes as
+ * qt_conv3d_first_wgrad; QT_ERR_UNSUPPORTED otherwise. */
+int qt_conv3d_first_wgrad_fused(int dtype, const float* clips, const void* y, const void* dout, const unsigned char* argmax,
+                                int pooled_channels, const float* mean, const float* invstd, const float* scale,
+                                const float* shift, const float* coef, float* dweight, void* workspace, size_t workspace_bytes,
+                                int batch, int frames, int h, int w, void* stream);
 int qt_conv3d_first_fwd(int dtype, const float* clips, const void* w_packed, void* y, const float* scale, const float* shift,
                         int relu, float* stats, int batch, int frames, int h, int w, void* stream);
 /* nn.AdaptiveAvgPool3d((1,1,1)) + flatten(1) into columns [col0, col0+C) of an f32 [B][ld] matrix, and its backward */

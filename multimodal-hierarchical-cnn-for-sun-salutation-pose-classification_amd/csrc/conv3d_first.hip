@@ -17,6 +17,7 @@
 // Bound: the 0.8 GB output write (HBM); 10 MFMAs per 16 pixels are 50 us of matrix pipe for the whole clip batch.
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "qt_common.h"
 
@@ -258,11 +259,28 @@ constexpr int C3W_PART = 32 * 9 * 16;
 
 struct C3WArgs {
   const float* x;         // [B][T][3][H][W]
-  const bf16_t* dy;       // [T][B][H][W][32]
+  const bf16_t* dy;       // [T][B][H][W][32]                     (FUSED: the raw conv output y, same layout)
   float* part;            // [gridDim.x][32][9][16]
   int B, T, H, W, items;
+  // FUSED: d(loss)/dy is formed on the way in from the pooled side (MaxPool3d((1,2,2)) + ReLU + BatchNorm3d backward)
+  const bf16_t* dout;          // [T][B][H/2][W/2][cp]: gradient of the pooled map
+  const unsigned char* arg;    // same shape: window position of the maximum
+  const float *mean, *invstd, *scale, *shift, *coef;   // [32] each; coef [3][cp] = qt_bn_bwd_finalize's (a, b, c)
+  int cp;
 };
 
+// FUSED (round 4): the kernel reads the raw conv output y where it read dy and forms
+//   dy = a (g - b - xhat c),   g = dout at the window's argmax where relu(bn(y)) > 0, else 0
+// in registers (what qt_pool3d_bn_bwd_apply wrote to memory and this kernel read back: 2 x 0.8 GB at 32 clips x 8 frames of
+// 224 x 224).  A lane owns 8 channels of two positions of a chunk -- the 16 bytes LDS-DMA dropped at lane * 16 and
+// 1024 + lane * 16 -- so the chunk's LDS image is the same and the contraction below does not change.  The loads of a chunk
+// (y 2 x 16 B, dout 2 x 16 B, argmax 2 x 8 B per lane) are issued two chunks ahead into registers.
+struct C3WChunk {
+  uint4 y0, y1, d0, d1;
+  uint2 a0, a1;
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void conv3d_first_wgrad_kernel(C3WArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -320,14 +338,43 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_wgrad_kernel(C3WArgs p) {
   const int slabs_per_img = H / C3_R, nck = W >> 5;
   int is_item = blockIdx.x, is_t = 0, is_c = 0;   // next chunk to issue
   int n_issued = 0, n_used = 0;
+  // FUSED: per-lane constants of the lane's 8 channels: dy = ka g + kb - y kc  (= a (g - b - (y - mean) invstd c))
+  float ka[8], kb[8], kc[8], ksc[8], ksh[8];
+  const unsigned me = (unsigned)((wave & 1) * 2 + ((lane >> 2) & 1));   // the position's place in its 2 x 2 window (h0 % 4 == 0)
+  if (FUSED) {
+    const int cg = (lane & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = p.coef[cg + j], bb = p.coef[p.cp + cg + j], cc = p.coef[2 * p.cp + cg + j];
+      const float mu = p.mean[cg + j], is = p.invstd[cg + j];
+      ka[j] = a;
+      kc[j] = a * is * cc;
+      kb[j] = a * (mu * is * cc - bb);
+      ksc[j] = p.scale[cg + j];
+      ksh[j] = p.shift[cg + j];
+    }
+  }
+  C3WChunk r0, r1, rn;   // FUSED: chunks n_used, n_used + 1 and the one being requested
+  r0 = r1 = rn = C3WChunk{};
   auto issue = [&]() {
     if (is_item >= p.items) return;
     const int b = is_item / slabs_per_img, h0 = (is_item - b * slabs_per_img) * C3_R;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(
         p.dy + ((((size_t)is_t * p.B + b) * H + h0 + wave) * W + is_c * 32) * 32);
-    const unsigned dst = ring + (unsigned)(n_issued % C3W_NCH) * 2048u;
-    glds16(src + lane * 16, dst);
-    glds16(src + 1024 + lane * 16, dst + 1024);
+    if (FUSED) {
+      rn.y0 = *reinterpret_cast<const uint4*>(src + lane * 16);
+      rn.y1 = *reinterpret_cast<const uint4*>(src + 1024 + lane * 16);
+      const size_t cell = (((size_t)is_t * p.B + b) * (H >> 1) + ((h0 + wave) >> 1)) * (W >> 1) + is_c * 16 + (lane >> 3);
+      const size_t e0 = cell * p.cp + (lane & 3) * 8, e1 = e0 + (size_t)8 * p.cp;
+      rn.d0 = *reinterpret_cast<const uint4*>(p.dout + e0);
+      rn.d1 = *reinterpret_cast<const uint4*>(p.dout + e1);
+      rn.a0 = *reinterpret_cast<const uint2*>(p.arg + e0);
+      rn.a1 = *reinterpret_cast<const uint2*>(p.arg + e1);
+    } else {
+      const unsigned dst = ring + (unsigned)(n_issued % C3W_NCH) * 2048u;
+      glds16(src + lane * 16, dst);
+      glds16(src + 1024 + lane * 16, dst + 1024);
+    }
     ++n_issued;
     if (++is_c == nck) {
       is_c = 0;
@@ -337,8 +384,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_wgrad_kernel(C3WArgs p) {
       }
     }
   };
+  static_assert(C3W_D == 2, "two chunks ahead: the register sets r0, r1 of the fused form");
+  issue();
+  r0 = rn;
+  issue();
+  r1 = rn;
+  // eight channels of one position: bf16 y, dout (16 B each), eight argmax bytes -> eight bf16 dy
+  auto form_dy = [&](const uint4& yv, const uint4& dv, const uint2& av) -> uint4 {
+    const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+    unsigned o[4];
 #pragma unroll
-  for (int d = 0; d < C3W_D; ++d) issue();
+    for (int q = 0; q < 4; ++q) {
+      float r[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = 2 * q + u;
+        const float yf = __builtin_bit_cast(float, u ? (yw[q] & 0xffff0000u) : (yw[q] << 16));
+        const float df = __builtin_bit_cast(float, u ? (dw[q] & 0xffff0000u) : (dw[q] << 16));
+        const unsigned a = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xffu;
+        const float g = (a == me && yf * ksc[j] + ksh[j] > 0.f) ? df : 0.f;
+        r[u] = ka[j] * g + kb[j] - yf * kc[j];
+      }
+      o[q] = pack_bf16x2(r[0], r[1]);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
 
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = item / slabs_per_img, h0 = (item - b * slabs_per_img) * C3_R;
@@ -361,10 +431,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_wgrad_kernel(C3WArgs p) {
       }
       for (int c = 0; c < nck; ++c) {
         issue();
-        const int ahead = n_issued - n_used - 1;   // chunks issued after the one about to be read
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FUSED) {   // (ordinary loads: the compiler counts them)
+          unsigned char* slot = smem + (ring - smem_base) + (unsigned)(n_used % C3W_NCH) * 2048u;
+          *reinterpret_cast<uint4*>(slot + lane * 16) = form_dy(r0.y0, r0.d0, r0.a0);
+          *reinterpret_cast<uint4*>(slot + 1024 + lane * 16) = form_dy(r0.y1, r0.d1, r0.a1);
+          r0 = r1;
+          r1 = rn;
+        } else {
+          const int ahead = n_issued - n_used - 1;   // chunks issued after the one about to be read
+          if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned da = ring + (unsigned)(n_used % C3W_NCH) * 2048u + lrow * 64 + pp * 8;
         ++n_used;
         uint4 fa[2];
@@ -451,6 +529,22 @@ bool c3_enabled() {
   return on;
 }
 
+template <bool FUSED>
+int c3_wgrad_launch(const C3WArgs& a, float* dweight, void* stream) {
+  const int grid = c3_grid(a.items);
+  int lds = C3_SLABS * (C3_R + 2) * (a.W + 4) * 8 + 4 * C3W_NCH * 2048;
+  if (lds < 4 * C3W_PART * 4) lds = 4 * C3W_PART * 4;   // the four waves' filters at the end
+  static std::atomic<unsigned long long> done{0};
+  int rc = qt_raise_lds_limit((const void*)conv3d_first_wgrad_kernel<FUSED>, lds, done);
+  if (rc != QT_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(conv3d_first_wgrad_kernel<FUSED>, dim3(grid), dim3(256), lds, s, a);
+  QT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(c3_wgrad_sum_kernel, dim3((32 * 81 + 31) / 32), dim3(256), 0, s, (const float*)a.part, dweight, grid);
+  QT_CHECK_LAUNCH();
+  return QT_OK;
+}
+
 bool c3_shape_ok(int dtype, const void* clips, int batch, int frames, int h, int w) {
   return dtype == QT_BF16 && c3_enabled() && batch > 0 && frames > 0 && h >= C3_R && h % C3_R == 0 && w >= 16 && w % 16 == 0 &&
          w <= 256 && ((uintptr_t)clips % 16) == 0;
@@ -475,20 +569,42 @@ extern "C" int qt_conv3d_first_wgrad(int dtype, const float* clips, const void* 
   QT_CHECK_ARG(workspace && workspace_bytes >= need, "qt_conv3d_first_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
                need);
   C3WArgs a;
+  memset(&a, 0, sizeof(a));
   a.x = clips; a.dy = (const bf16_t*)dy; a.part = (float*)workspace;
   a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
-  const int grid = c3_grid(a.items);
-  int lds = C3_SLABS * (C3_R + 2) * (w + 4) * 8 + 4 * C3W_NCH * 2048;
-  if (lds < 4 * C3W_PART * 4) lds = 4 * C3W_PART * 4;   // the four waves' filters at the end
-  static std::atomic<unsigned long long> done{0};
-  int rc = qt_raise_lds_limit((const void*)conv3d_first_wgrad_kernel, lds, done);
-  if (rc != QT_OK) return rc;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(conv3d_first_wgrad_kernel, dim3(grid), dim3(256), lds, s, a);
-  QT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(c3_wgrad_sum_kernel, dim3((32 * 81 + 31) / 32), dim3(256), 0, s, (const float*)workspace, dweight, grid);
-  QT_CHECK_LAUNCH();
-  return QT_OK;
+  return c3_wgrad_launch<false>(a, dweight, stream);
+}
+
+// The same weight gradient with d(loss)/dy formed on the way in (round 4): y = the raw conv output [T][B][H][W][32] of
+// qt_conv3d_first_fwd (statistics form), dout / argmax [T][B][H/2][W/2][pooled_channels] = the gradient of conv3d_block1's
+// pooled map and qt_pool3d_bn_relu_max's argmax (pool_t = 1), mean / invstd / scale / shift = qt_bn_finalize's vectors of the
+// block's BatchNorm3d, coef = qt_bn_bwd_finalize's [3][pooled_channels].  Same result as qt_pool3d_bn_bwd_apply (dy_channels
+// = 32) followed by qt_conv3d_first_wgrad, up to the rounding of the folded dy expression; dy never reaches memory.
+extern "C" int qt_conv3d_first_wgrad_fused(int dtype, const float* clips, const void* y, const void* dout,
+                                           const unsigned char* argmax, int pooled_channels, const float* mean, const float* invstd,
+                                           const float* scale, const float* shift, const float* coef, float* dweight, void* workspace,
+                                           size_t workspace_bytes, int batch, int frames, int h, int w, void* stream) {
+  QT_CHECK_ARG(clips && y && dout && argmax && mean && invstd && scale && shift && coef && dweight && batch > 0 && frames > 0 &&
+                   h > 0 && w > 0,
+               "qt_conv3d_first_wgrad_fused: bad argument");
+  QT_CHECK_ARG(pooled_channels == 32 || pooled_channels == 64, "qt_conv3d_first_wgrad_fused: pooled rows of %d channels (32 or 64)",
+               pooled_channels);
+  const size_t need = qt_conv3d_first_wgrad_workspace_bytes(batch, frames, h, w);
+  if (dtype != QT_BF16 || need == 0 || ((uintptr_t)clips % 16) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)dout % 16) != 0 ||
+      ((uintptr_t)argmax % 8) != 0) {
+    qt_set_error("qt_conv3d_first_wgrad_fused: bf16, H %% 4 == 0, W %% 32 == 0, W <= 256, 16-byte aligned operands only "
+                 "(use qt_pool3d_bn_bwd_apply + qt_conv3d_first_wgrad)");
+    return QT_ERR_UNSUPPORTED;
+  }
+  QT_CHECK_ARG(workspace && workspace_bytes >= need, "qt_conv3d_first_wgrad_fused: workspace of %zu bytes, %zu needed",
+               workspace_bytes, need);
+  C3WArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = clips; a.dy = (const bf16_t*)y; a.part = (float*)workspace;
+  a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
+  a.dout = (const bf16_t*)dout; a.arg = argmax; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.coef = coef;
+  a.cp = pooled_channels;
+  return c3_wgrad_launch<true>(a, dweight, stream);
 }
 
 // Eval forward of conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv bias folded

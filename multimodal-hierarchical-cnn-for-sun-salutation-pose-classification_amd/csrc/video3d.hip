@@ -399,6 +399,71 @@ __global__ void pack_conv3d_block_kernel(const float* __restrict__ W, T* __restr
   }
 }
 
+// The same operands (FIRST == 0) through an LDS tile (round 4): the element-per-thread form above gathers W at a stride of 27
+// floats and scatters wd at a stride of 27 * Op elements -- 118 us for conv3d_final_features' 7.1 M weights (0.5 TB/s), in
+// line in every train forward.  A workgroup owns 32 output x 16 input channels x 27 taps: W arrives as 32 contiguous runs of
+// 432 floats, wf leaves as runs of 16 input channels per (o, tap), wd as runs of 32 output channels per (c, tap); the odd row
+// pitch keeps both read patterns of the tile off the same bank.  The last workgroup writes the per-channel vectors.
+constexpr int PK3_TO = 32, PK3_TI = 16, PK3_PITCH = PK3_TI * 27 + 1;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3d_tile_kernel(const float* __restrict__ W, T* __restrict__ wf, T* __restrict__ wd, int O,
+                                                               int I, int Op, int Ip, const float* const* vec_in,
+                                                               float* __restrict__ vec_out) {
+  __shared__ float tile[PK3_TO * PK3_PITCH];
+  const int tiles_i = Ip / PK3_TI, ntiles = (Op / PK3_TO) * tiles_i;
+  if ((int)blockIdx.x >= ntiles) {
+    for (int i = threadIdx.x; i < 5 * Op; i += 256) {
+      const int v = i / Op, c = i - v * Op;
+      const float* src = vec_in[v];
+      vec_out[i] = (c < O && src) ? src[c] : ((v == 1 || v == 4) ? 1.f : 0.f);
+    }
+    return;
+  }
+  const int o0 = ((int)blockIdx.x / tiles_i) * PK3_TO, c0 = ((int)blockIdx.x % tiles_i) * PK3_TI;
+  // 16 bytes per load and per store: with an element per thread the kernel is bound by its instruction count (35 per element)
+  constexpr int RUN4 = PK3_TI * 27 / 4, NLOAD = PK3_TO * RUN4, ROUND = 7;   // I % 16 == 0: a tile's runs are whole or padding
+  const bool cols = c0 < I;
+  for (int e0 = threadIdx.x; e0 < NLOAD; e0 += 256 * ROUND) {
+    float4 v[ROUND];
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) {
+      const int e = e0 + k * 256;
+      const int o = e / RUN4, q = e - o * RUN4;
+      v[k] = (e < NLOAD && cols && o0 + o < O) ? *reinterpret_cast<const float4*>(W + ((long long)(o0 + o) * I + c0) * 27 + q * 4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) {
+      const int e = e0 + k * 256;
+      if (e < NLOAD) {
+        const int o = e / RUN4, q = e - o * RUN4;
+        float* t = tile + o * PK3_PITCH + q * 4;
+        t[0] = v[k].x; t[1] = v[k].y; t[2] = v[k].z; t[3] = v[k].w;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < PK3_TO * 27 * (PK3_TI / 8); e += 256) {   // (o, tap, eight input channels)
+    const int h = e % (PK3_TI / 8), ot = e / (PK3_TI / 8);
+    const int tap = ot % 27, o = ot / 27;
+    const float* t = tile + o * PK3_PITCH + h * 8 * 27 + tap;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = t[j * 27];
+    QtVec8<T>::store(wf + ((long long)(o0 + o) * 27 + tap) * Ip + c0 + h * 8, v);
+  }
+  if (wd)
+    for (int e = threadIdx.x; e < PK3_TI * 27 * (PK3_TO / 8); e += 256) {   // (c, tap, eight output channels)
+      const int oq = e % (PK3_TO / 8), ct = e / (PK3_TO / 8);
+      const int tap = ct % 27, c = ct / 27;
+      const float* t = tile + oq * 8 * PK3_PITCH + c * 27 + tap;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = t[j * PK3_PITCH];
+      QtVec8<T>::store(wd + ((long long)(c0 + c) * 27 + tap) * Op + o0 + oq * 8, v);
+    }
+}
+
 // weight gradient back to nn.Conv3d's layout: dw [27][Op][Ip]-like pieces -> dW [O][I][27]
 //   FIRST == 0: dw = three [Op][9][Ip] f32 blocks (one per frame tap, as qt_conv2d_wgrad writes them);
 //   FIRST == 1: dw = [Op][128] (K index tap * I + c).
@@ -430,6 +495,21 @@ extern "C" int qt_pack_conv3d_block(int dtype, const float* w, void* w_fwd, void
   const long long total = (first ? (long long)O_pad * 128 : (long long)O_pad * 27 * I_pad) + 5ll * O_pad;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  static const bool tiled = [] {
+    const char* e = getenv("QTCNN_PACK3D_TILED");
+    return !(e && e[0] == '0');
+  }();
+  if (!first && tiled && O_pad % 64 == 0 && I_pad % 64 == 0 && I % PK3_TI == 0 && ((uintptr_t)w % 16) == 0) {
+    const int blocks = (O_pad / PK3_TO) * (I_pad / PK3_TI) + 1;
+    if (dtype == QT_F32)
+      hipLaunchKernelGGL(pack_conv3d_tile_kernel<float>, dim3(blocks), dim3(256), 0, s, w, static_cast<float*>(w_fwd),
+                         static_cast<float*>(w_dgrad), O, I, O_pad, I_pad, vec_in_dev, vec_out);
+    else
+      hipLaunchKernelGGL(pack_conv3d_tile_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, static_cast<bf16_t*>(w_fwd),
+                         static_cast<bf16_t*>(w_dgrad), O, I, O_pad, I_pad, vec_in_dev, vec_out);
+    QT_CHECK_LAUNCH();
+    return QT_OK;
+  }
   if (dtype == QT_F32)
     hipLaunchKernelGGL(pack_conv3d_block_kernel<float>, dim3(grid), dim3(256), 0, s, w, static_cast<float*>(w_fwd),
                        static_cast<float*>(w_dgrad), O, I, O_pad, I_pad, first, vec_in_dev, vec_out);

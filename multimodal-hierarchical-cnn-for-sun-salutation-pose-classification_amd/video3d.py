@@ -216,9 +216,11 @@ class _Ops:
         self.check(self.L.qt_pool3d_bn_relu_max(_lib.qt_dtype(dt), _ptr(y), _ptr(stats[2]), _ptr(stats[3]), _ptr(out), _ptr(arg),
                                                 _ptr(ymax), T, B, H, W, C, cy or C, pt, _lib.stream_ptr()), "qt_pool3d_bn_relu_max")
 
-    def pool_bn_backward(self, dt, dout, arg, pooled, ymax, y, stats, gamma, T, B, H, W, C, pt, dev, batch_stats, cy=None, cd=None):
+    def pool_bn_backward(self, dt, dout, arg, pooled, ymax, y, stats, gamma, T, B, H, W, C, pt, dev, batch_stats, cy=None, cd=None,
+                         apply=True):
         """d/d(pooled) -> (dy, dgamma, dbeta): the BatchNorm sums from the pooled side (every cell sends its gradient to one
-        position), then max-pool backward + ReLU mask + BatchNorm backward in one pass; no full-size gradient map in between"""
+        position), then max-pool backward + ReLU mask + BatchNorm backward in one pass; no full-size gradient map in between.
+        apply = False: no dy, the coefficients [3][C] instead (the consumer forms dy itself: qt_conv3d_first_wgrad_fused)"""
         cells = (T // pt) * B * (H // 2) * (W // 2)
         Mrows = T * B * H * W
         rows = self.L.qt_bn_bwd_partial_rows(_c.c_longlong(cells), C)
@@ -231,6 +233,8 @@ class _Ops:
         self.check(self.L.qt_bn_bwd_finalize(_ptr(part), rows, C, _c.c_longlong(Mrows if batch_stats else 0), _ptr(gamma),
                                              _ptr(stats[1]), _ptr(dgb[0]), _ptr(dgb[1]), 0, _ptr(coef), _lib.stream_ptr()),
                    "qt_bn_bwd_finalize")
+        if not apply:
+            return coef, dgb[0], dgb[1]
         cy, cd = cy or C, cd or cy or C
         dy = torch.empty(Mrows, cd, dtype=dt, device=dev)
         self.check(self.L.qt_pool3d_bn_bwd_apply(q, _ptr(dout), _ptr(arg), _ptr(pooled), _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
@@ -277,6 +281,9 @@ WGRAD_SIDE = os.environ.get("QTCNN_WGRAD_SIDE_STREAM", "1") != "0"
 PACK_CACHE = os.environ.get("QTCNN_PACK_CACHE", "1") != "0"
 # QTCNN_CONV3D_SLAB (default 1): conv3d_block2's forward on the slab-resident kernel (csrc/conv3d_slab.hip); 0: 27-tap implicit GEMM
 SLAB_C32 = os.environ.get("QTCNN_CONV3D_SLAB", "1") != "0"
+# QTCNN_FIRST_WGRAD_FUSED (default 1): conv3d_block1's backward forms d(loss)/dy inside the weight-gradient kernel
+# (qt_conv3d_first_wgrad_fused) instead of writing it with qt_pool3d_bn_bwd_apply and reading it back
+FIRST_WGRAD_FUSED = os.environ.get("QTCNN_FIRST_WGRAD_FUSED", "1") != "0"
 # QTCNN_POOLED32 (default 1): conv3d_block1's pooled map (and its argmax / raw-value companions, and the gradient block 2 sends
 # back) in 32-channel rows where block 2 runs on the slab kernels, which read 32 channels; 0: rows padded to 64 channels (round 3)
 POOLED32 = os.environ.get("QTCNN_POOLED32", "1") != "0"
@@ -533,13 +540,16 @@ class _ConvBlock:
         esz = 2 if dt == torch.bfloat16 else 4
         rows = T * B * H * W
         raw = self.first and x.dtype == torch.float32 and x.dim() == 5   # saved by _forward_raw: the clip itself, y 32 wide
-        raw_ws = 0
+        raw_ws, coef = 0, None
         if raw:
             o.L.qt_conv3d_first_wgrad_workspace_bytes.restype = _c.c_size_t
             raw_ws = int(o.L.qt_conv3d_first_wgrad_workspace_bytes(B, T, H, W))
             # (the pooled side's row width: 32 where block 2 runs on the slab kernels, else padded -- _pooled_width)
+            fused_dy = bool(FIRST_WGRAD_FUSED and raw_ws and self.pool_t == 1 and dt == torch.bfloat16 and dout.data_ptr() % 16 == 0)
             dy, dgamma, dbeta = o.pool_bn_backward(dt, dout, arg, pooled, ymax, y, stats, self.gamma_p, T, B, H, W, pooled.shape[1],
-                                                   self.pool_t, dev, training, cy=32, cd=32 if raw_ws else self.cout_p)
+                                                   self.pool_t, dev, training, cy=32, cd=32 if raw_ws else self.cout_p,
+                                                   apply=not fused_dy)
+            coef = dy if fused_dy else None   # (apply = False returns the coefficients in dy's place)
             if not raw_ws:   # (a width the raw weight-gradient kernel does not take: the packed rows after all)
                 x = o.pack_clip(dt, x, B, T, H, W)
         elif ymax is not None:
@@ -570,6 +580,12 @@ class _ConvBlock:
             dW = torch.empty_like(self.conv.weight)
             if raw_ws:
                 ws = torch.empty(raw_ws, dtype=torch.uint8, device=dev)
+                if coef is not None:   # dy = the pool / ReLU / BatchNorm3d backward of dout, formed inside the kernel
+                    o.check(o.L.qt_conv3d_first_wgrad_fused(_lib.qt_dtype(dt), _ptr(x), _ptr(y), _ptr(dout), _ptr(arg), dout.shape[1],
+                                                            _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(coef),
+                                                            _ptr(dW), _ptr(ws), _c.c_size_t(raw_ws), B, T, H, W, _lib.stream_ptr()),
+                            "qt_conv3d_first_wgrad_fused")
+                    return dW
                 o.check(o.L.qt_conv3d_first_wgrad(_lib.qt_dtype(dt), _ptr(x), _ptr(dy), _ptr(dW), _ptr(ws), _c.c_size_t(raw_ws), B, T,
                                                   H, W, _lib.stream_ptr()), "qt_conv3d_first_wgrad")
                 return dW
@@ -607,7 +623,7 @@ class _ConvBlock:
         # plan's arrangement, csrc/plan.hip).  x and dy were allocated on the compute stream: recorded on the side stream so
         # that the caching allocator does not hand their memory out again while it still reads them.
         if wside is not None:
-            for t_ in (x, dy):
+            for t_ in ((x, y, dout, arg, dy) + tuple(stats) if raw and coef is not None else (x, dy)):
                 t_.record_stream(wside.side)
             with wside.fork():
                 dW = weight_gradient()

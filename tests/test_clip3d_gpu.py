@@ -313,6 +313,36 @@ def test_first_conv3d_from_the_f32_clip(cfg):
             outs.append(dw.cpu())
         assert rel_err(outs[0], wr.grad) <= 2e-4        # products of bf16 values are exact in f32: only the summation order differs
         assert torch.equal(outs[0], outs[1])
+        # round 4: the same weight gradient with dy formed inside the kernel (MaxPool3d((1,2,2)) + ReLU + BatchNorm3d backward of
+        # the pooled gradient) against qt_pool3d_bn_bwd_apply + qt_conv3d_first_wgrad; pooled rows of 32 and of 64 channels
+        mean = (torch.randn(32, generator=g) * 0.1).to(dev)
+        invstd = (torch.rand(32, generator=g) + 0.5).to(dev)
+        for cp in (32, 64):
+            pooled = torch.empty(T, B, H // 2, W // 2, cp, dtype=dt, device=dev)
+            arg = torch.empty(T, B, H // 2, W // 2, cp, dtype=torch.uint8, device=dev)
+            L.check(lib.qt_pool3d_bn_relu_max(L.qt_dtype(dt), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(pooled), L.ptr(arg), None, T, B, H,
+                                              W, cp, 32, 1, L.stream_ptr()), "qt_pool3d_bn_relu_max")
+            dout = torch.randn(T, B, H // 2, W // 2, cp, generator=g).to(dt).to(dev)
+            coef = torch.stack([torch.rand(cp, generator=g) + 0.5, torch.randn(cp, generator=g) * 0.05,
+                                torch.randn(cp, generator=g) * 0.05]).to(dev)
+            dy = torch.empty(T, B, H, W, 32, dtype=dt, device=dev)
+            L.check(lib.qt_pool3d_bn_bwd_apply(L.qt_dtype(dt), L.ptr(dout), L.ptr(arg), L.ptr(pooled), L.ptr(y), L.ptr(mean),
+                                               L.ptr(invstd), L.ptr(coef), L.ptr(dy), T, B, H, W, cp, 32, 32, 1, L.stream_ptr()),
+                    "qt_pool3d_bn_bwd_apply")
+            dw_ref = torch.full((32, 3, 3, 3, 3), float("nan"), device=dev)
+            L.check(lib.qt_conv3d_first_wgrad(L.qt_dtype(dt), L.ptr(cd), L.ptr(dy), L.ptr(dw_ref), L.ptr(ws), ctypes.c_size_t(nws), B, T,
+                                              H, W, L.stream_ptr()), "qt_conv3d_first_wgrad")
+            dw_f = torch.full((32, 3, 3, 3, 3), float("nan"), device=dev)
+            L.check(lib.qt_conv3d_first_wgrad_fused(L.qt_dtype(dt), L.ptr(cd), L.ptr(y), L.ptr(dout), L.ptr(arg), cp, L.ptr(mean),
+                                                    L.ptr(invstd), L.ptr(sc), L.ptr(sh), L.ptr(coef), L.ptr(dw_f), L.ptr(ws),
+                                                    ctypes.c_size_t(nws), B, T, H, W, L.stream_ptr()), "qt_conv3d_first_wgrad_fused")
+            torch.cuda.synchronize()
+            assert torch.isfinite(dw_f).all()
+            # (dy = ka g + kb - y kc in the fused form against a (g - b - (y - mean) invstd c): single bf16 roundings differ)
+            assert rel_err(dw_f.cpu(), dw_ref.cpu()) <= 2e-3, (cp, rel_err(dw_f.cpu(), dw_ref.cpu()))
+        assert lib.qt_conv3d_first_wgrad_fused(L.qt_dtype(dt), L.ptr(cd), L.ptr(y), L.ptr(dout), L.ptr(arg), 48, L.ptr(mean),
+                                               L.ptr(invstd), L.ptr(sc), L.ptr(sh), L.ptr(coef), L.ptr(dw_f), L.ptr(ws),
+                                               ctypes.c_size_t(nws), B, T, H, W, L.stream_ptr()) == -1
     # not covered: f32, a width that is not a multiple of 16, a height that is not a multiple of 4
     assert lib.qt_conv3d_first_fwd(L.QT_F32, L.ptr(cd), L.ptr(wp), L.ptr(y), None, None, 0, None, B, T, H, W, L.stream_ptr()) == -3
     assert lib.qt_conv3d_first_stats_rows(B, T, H, W + 8) == 0 and lib.qt_conv3d_first_stats_rows(B, T, H + 2, W) == 0
@@ -566,8 +596,10 @@ def test_block1_pooled_map_in_32_channel_rows(monkeypatch):
     B, T, HW = 2, 4, 64
     x, f, y = (t.to(dev) for t in _inputs(B, T, HW, 5))
     res = []
-    for narrow in (True, False):
+    for narrow, fused in ((True, True), (False, True), (True, False), (False, False)):
+        # (fused: conv3d_block1's dy formed inside its weight-gradient kernel, qt_conv3d_first_wgrad_fused)
         monkeypatch.setattr(v3d, "POOLED32", narrow)
+        monkeypatch.setattr(v3d, "FIRST_WGRAD_FUSED", fused)
         m = _build("quadtree_3d_fusion", T, torch.bfloat16).to(dev).train()
         widths = []
         orig = v3d._Ops.pool_bn
@@ -581,11 +613,12 @@ def test_block1_pooled_map_in_32_channel_rows(monkeypatch):
         monkeypatch.setattr(v3d._Ops, "pool_bn", orig)
         assert widths[0] == (32 if narrow else 64), widths
         res.append((out.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
-    assert torch.equal(res[0][0], res[1][0])
-    for n, g32 in res[0][1].items():
-        if _is_conv_bias_before_bn(n):
-            continue
-        assert rel_err(g32.cpu(), res[1][1][n].cpu()) <= 2e-3, n
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for n, g32 in res[0][1].items():
+            if _is_conv_bias_before_bn(n):
+                continue
+            assert rel_err(g32.cpu(), other[1][n].cpu()) <= 2e-3, n
 
 
 def test_dropout_train_mode_and_eval_backward_and_errors():
