@@ -526,6 +526,9 @@ int qt_pool3d_bn_relu_max(int dtype, const void* y, const float* scale, const fl
 /* ... and the backward of the three in one pass: dy = a (g - b - xhat c) with g = dout at the window's argmax where
  * pooled > 0, zero elsewhere (coef = qt_bn_bwd_finalize's [3][C]); replaces qt_pool3d_max_bwd + qt_bn_bwd_apply and the
  * full-size gradient map between them.  dy rows are dy_channels wide (>= y_channels; zero beyond y_channels). */
+/* tests: the smallest launch (in 16-byte channel groups) for which qt_pool3d_bn_bwd_apply takes its resident-grid form (bf16, no
+ * padding channels: C = y_channels = dy_channels); 0 restores the default (2^20) */
+void qt_set_pool3d_apply_light_min(long long groups);
 int qt_pool3d_bn_bwd_apply(int dtype, const void* dout, const unsigned char* argmax, const void* pooled, const void* y,
                            const float* mean, const float* invstd, const float* coef, void* dy, int frames, int batch, int h,
                            int w, int C, int y_channels, int dy_channels, int pool_t, void* stream);

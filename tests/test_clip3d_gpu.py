@@ -165,6 +165,15 @@ def test_fused_bn_relu_maxpool3d_equals_separate_kernels(dt, pt, T, H):
     torch.cuda.synchronize()
     assert torch.equal(dy0, dy2)
 
+    if dt == torch.bfloat16:   # the resident-grid form the large maps take (round 4): the same arithmetic, bit for bit
+        lib.qt_set_pool3d_apply_light_min(ctypes.c_longlong(1))
+        dy5 = torch.full_like(yd, 7.0)
+        L.check(lib.qt_pool3d_bn_bwd_apply(q, L.ptr(dd), L.ptr(arg1), L.ptr(out1), L.ptr(yd), L.ptr(mu), L.ptr(isd), L.ptr(coef1),
+                                           L.ptr(dy5), T, B, H, W, C, C, C, pt, st), "fused apply, resident grid")
+        lib.qt_set_pool3d_apply_light_min(ctypes.c_longlong(0))
+        torch.cuda.synchronize()
+        assert torch.equal(dy1, dy5)
+
     # y rows narrower than the pooled rows (the first layer's 32 channels feeding 64-channel K rows): same values in the
     # first channels, zeros in the padding of pooled / argmax / y_at_max / dy
     Cy = C // 2
