@@ -565,11 +565,12 @@ size_t qt_conv3d_c32_wgrad_workspace_bytes(int batch, int frames, int h, int w);
 int qt_conv3d_c32_wgrad(int dtype, const void* x, int x_channels, const void* dy, float* dweight, void* workspace,
                         size_t workspace_bytes, int batch, int frames, int h, int w, void* stream);
 /* Eval forward of the whole conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv
- * bias folded into shift) + ReLU + MaxPool3d((1,2,2)) in registers; pooled [T][B][H/2][W/2][64] with channels 32..63 zero (the
- * K rows block 2 reads); the conv map never reaches memory.  Same values as qt_conv3d_first_fwd(scale, shift, relu) followed by
- * qt_pool3d_max.  Shapes as qt_conv3d_first_fwd. */
-int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const void* w_packed, void* pooled, const float* scale,
-                             const float* shift, int batch, int frames, int h, int w, void* stream);
+ * bias folded into shift) + ReLU + MaxPool3d((1,2,2)) in registers; pooled [T][B][H/2][W/2][pooled_channels]: 64 with channels
+ * 32..63 zero (the K rows the implicit GEMM reads) or 32 (round 4: what the slab kernels of block 2 read); the conv map never
+ * reaches memory.  Same values as qt_conv3d_first_fwd(scale, shift, relu) followed by qt_pool3d_max.  Shapes as
+ * qt_conv3d_first_fwd. */
+int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const void* w_packed, void* pooled, int pooled_channels,
+                             const float* scale, const float* shift, int batch, int frames, int h, int w, void* stream);
 /* ... and its weight gradient from the f32 clip and dy [T][B][H][W][32] (32-channel rows, what qt_pool3d_bn_bwd_apply
  * writes with dy_channels = 32): dweight [32][3][3][3][3] f32 in nn.Conv3d's own layout, every element written; partial
  * filters per workgroup in `workspace` (qt_conv3d_first_wgrad_workspace_bytes, 0 = shape not covered: W % 32, else as

@@ -34,6 +34,7 @@ struct C3Args {
   const float* shift;
   float* stats;           // [gridDim.x][2][64] or NULL (channels 32..63 written as zero)
   int relu, B, T, H, W, items;
+  int pc;                 // POOL: channels per pooled row (64: channels 32..63 written as zeros; 32: none)
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -145,8 +146,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(C3Args p) {
         const int pr = wave & 1;   // row pair of the slab; blocks (wave >> 1), (wave >> 1) + 2, ...
         // the addresses above are for slab row `wave`: move them to row 2 * pr
         const int back = (wave - 2 * pr) * rowb;
-        bf16_t* orow = p.y + ((((size_t)t * p.B + b) * (H >> 1) + (h0 >> 1) + pr) * (W >> 1) + (li >> 1)) * 64 +
+        const int pc = p.pc;
+        bf16_t* orow = p.y + ((((size_t)t * p.B + b) * (H >> 1) + (h0 >> 1) + pr) * (W >> 1) + (li >> 1)) * pc +
                        ((li & 1) ? 32 : 0) + lg * 8;
+        const bool writes = pc > 32 || !(li & 1);   // (32-channel rows have no zero half for the odd lanes to write)
         for (int blk = wave >> 1; blk < nblk; blk += 2) {
           f32x4 acc[2][2];
 #pragma unroll
@@ -176,8 +179,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(C3Args p) {
             const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xb1, 0xf, 0xf, false));
             v[j] = (li & 1) ? 0.f : fmaxf(m, o);   // odd lanes write the zero half of their left neighbour's pooled row
           }
-          *reinterpret_cast<uint4*>(orow + (size_t)blk * 8 * 64) =
-              make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          if (writes)
+            *reinterpret_cast<uint4*>(orow + (size_t)blk * 8 * pc) =
+                make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         }
         continue;
       }
@@ -608,11 +612,14 @@ extern "C" int qt_conv3d_first_wgrad_fused(int dtype, const float* clips, const 
 }
 
 // Eval forward of conv3d_block1 in one launch: Conv3d + folded BatchNorm3d (scale / shift of 32 channels, the conv bias folded
-// into shift) + ReLU + MaxPool3d((1,2,2)); pooled [T][B][H/2][W/2][64], channels 32..63 zero.  Shapes as qt_conv3d_first_fwd.
-extern "C" int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const void* w_packed, void* pooled, const float* scale,
-                                        const float* shift, int batch, int frames, int h, int w, void* stream) {
+// into shift) + ReLU + MaxPool3d((1,2,2)); pooled [T][B][H/2][W/2][pooled_channels] (64: channels 32..63 zero).  Shapes as
+// qt_conv3d_first_fwd.
+extern "C" int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const void* w_packed, void* pooled, int pooled_channels,
+                                        const float* scale, const float* shift, int batch, int frames, int h, int w, void* stream) {
   QT_CHECK_ARG(clips && w_packed && pooled && scale && shift && batch > 0 && frames > 0 && h > 0 && w > 0,
                "qt_conv3d_first_fwd_pool: bad argument");
+  QT_CHECK_ARG(pooled_channels == 32 || pooled_channels == 64, "qt_conv3d_first_fwd_pool: pooled rows of %d channels (32 or 64)",
+               pooled_channels);
   if (!c3_shape_ok(dtype, clips, batch, frames, h, w)) {
     qt_set_error("qt_conv3d_first_fwd_pool: bf16, H %% 4 == 0, W %% 16 == 0, W <= 256 and a 16-byte aligned clip only "
                  "(use qt_conv3d_first_fwd / qt_pack_clip27 + qt_conv2d_igemm, then qt_pool3d_max)");
@@ -620,7 +627,7 @@ extern "C" int qt_conv3d_first_fwd_pool(int dtype, const float* clips, const voi
   }
   C3Args a;
   a.x = clips; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)pooled; a.scale = scale; a.shift = shift; a.stats = nullptr;
-  a.relu = 1; a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
+  a.relu = 1; a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R); a.pc = pooled_channels;
   const int lds = C3_SLABS * (C3_R + 2) * (w + 4) * 8;
   static std::atomic<unsigned long long> done{0};
   if (int rc = qt_raise_lds_limit((const void*)conv3d_first_kernel<true, false, true>, lds, done)) return rc;
@@ -649,7 +656,7 @@ extern "C" int qt_conv3d_first_fwd(int dtype, const float* clips, const void* w_
   }
   C3Args a;
   a.x = clips; a.w = (const bf16_t*)w_packed; a.y = (bf16_t*)y; a.scale = scale; a.shift = shift; a.stats = stats;
-  a.relu = relu; a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R);
+  a.relu = relu; a.B = batch; a.T = frames; a.H = h; a.W = w; a.items = batch * (h / C3_R); a.pc = 64;
   const int lds = C3_SLABS * (C3_R + 2) * (w + 4) * 8;
   const dim3 grid(c3_grid(a.items)), blk(256);
   hipStream_t s = static_cast<hipStream_t>(stream);

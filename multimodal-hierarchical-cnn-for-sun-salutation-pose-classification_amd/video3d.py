@@ -175,8 +175,8 @@ class _Ops:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         if pooled is not None:   # y is the pooled map; pooled = the folded BatchNorm3d's (.., .., scale, shift)
-            self.check(self.L.qt_conv3d_first_fwd_pool(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), _ptr(pooled[2]), _ptr(pooled[3]),
-                                                       B, T, H, W, _lib.stream_ptr()), "qt_conv3d_first_fwd_pool")
+            self.check(self.L.qt_conv3d_first_fwd_pool(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), y.shape[1], _ptr(pooled[2]),
+                                                       _ptr(pooled[3]), B, T, H, W, _lib.stream_ptr()), "qt_conv3d_first_fwd_pool")
         else:
             self.check(self.L.qt_conv3d_first_fwd(_lib.qt_dtype(dt), _ptr(clip), _ptr(wf), _ptr(y), None, None, 0, _ptr(part), B, T, H, W,
                                                   _lib.stream_ptr()), "qt_conv3d_first_fwd")
@@ -433,7 +433,7 @@ class _ConvBlock:
             stats[3].addcmul_(stats[2], self.bias_p)
             stats[0].sub_(self.bias_p)
             if not keep and self.pool_t == 1:   # eval without backward: the whole block in one launch, y never exists
-                out = torch.empty(T * B * (H // 2) * (W // 2), self.cout_p, dtype=dt, device=dev)
+                out = torch.empty(T * B * (H // 2) * (W // 2), self._pooled_width(dt, B, T, H // 2, W // 2), dtype=dt, device=dev)
                 o.conv3d_first(dt, clip, self.wf, out, None, B, T, H, W, fl, 4.0 * rows * 3 + 2.0 * out.numel(), pooled=stats)
                 return out, (T, H // 2, W // 2), None
             o.conv3d_first(dt, clip, self.wf, y, None, B, T, H, W, fl, nb)

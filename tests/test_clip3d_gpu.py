@@ -295,13 +295,14 @@ def test_first_conv3d_from_the_f32_clip(cfg):
     assert torch.equal(y, y2)
     assert rel_err(y3.float().cpu(), torch.relu(ref_tb * sc.cpu() + sh.cpu())) <= 1e-2
     # the whole eval block in one launch: conv + folded BatchNorm3d + ReLU + MaxPool3d((1,2,2)) = the affine form, pooled
-    pooled = torch.full((T, B, H // 2, W // 2, 64), float("nan"), dtype=dt, device=dev)
-    L.check(lib.qt_conv3d_first_fwd_pool(L.qt_dtype(dt), L.ptr(cd), L.ptr(wp), L.ptr(pooled), L.ptr(sc), L.ptr(sh), B, T, H, W,
-                                         L.stream_ptr()), "qt_conv3d_first_fwd_pool")
     want = torch.empty(T, B, H // 2, W // 2, 32, dtype=dt, device=dev)
     L.check(lib.qt_pool3d_max(L.qt_dtype(dt), L.ptr(y3), L.ptr(want), None, T, B, H, W, 32, 1, L.stream_ptr()), "pool")
-    torch.cuda.synchronize()
-    assert torch.equal(pooled[..., :32], want) and (pooled[..., 32:] == 0).all()
+    for pc in (64, 32):   # rows padded to 64 channels (zeros), and 32-channel rows (round 4)
+        pooled = torch.full((T, B, H // 2, W // 2, pc), float("nan"), dtype=dt, device=dev)
+        L.check(lib.qt_conv3d_first_fwd_pool(L.qt_dtype(dt), L.ptr(cd), L.ptr(wp), L.ptr(pooled), pc, L.ptr(sc), L.ptr(sh), B, T, H, W,
+                                             L.stream_ptr()), "qt_conv3d_first_fwd_pool")
+        torch.cuda.synchronize()
+        assert torch.equal(pooled[..., :32], want) and (pooled[..., 32:] == 0).all()
     # weight gradient from the clip and a 32-channel-row gradient map, in nn.Conv3d's layout; deterministic
     lib.qt_conv3d_first_wgrad_workspace_bytes.restype = ctypes.c_size_t
     nws = int(lib.qt_conv3d_first_wgrad_workspace_bytes(B, T, H, W))
