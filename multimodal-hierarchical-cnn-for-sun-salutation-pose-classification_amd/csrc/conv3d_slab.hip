@@ -14,7 +14,12 @@
 //     (108 VGPRs) stay in registers for the whole walk, so the K loop is one LDS read + one MFMA per tap, two pixel blocks
 //     interleaved; frames outside the clip are skipped (no MFMA work on padding frames);
 //   * epilogue: bias-free accumulator + BatchNorm3d partial sums (train) or scale / shift / ReLU (eval), 8-byte stores.
-// Bound: LDS reads (one 1 KB fragment read per MFMA, 4 SIMDs share 128 B/clk: at most 50 % of the matrix pipe).
+// Bound (round 3's reading): LDS reads (one 1 KB fragment read per MFMA, 4 SIMDs share 128 B/clk: at most 50 % of the matrix pipe).
+// Round 4 measured it: with two channel blocks per wave (CPW = 2: half the fragment reads per MFMA) and the reads issued a
+// group ahead of their MFMAs the forward goes 534 -> 464 us, no further; counters of that form (eval forward, 32 clips x 8
+// frames of 112 x 112): matrix pipes busy 40 % of the CU-busy cycles, LDS active 40 % (half of it the 2-way conflict of a
+// 64-byte pixel pitch under ds_read_b128), 2.7 VALU + 1.5 SALU instructions per MFMA.  Neither pipe is the bound: four waves
+// per CU issue-limited by the per-block address / epilogue arithmetic around 27 CPW MFMAs, and one barrier per frame.
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -43,34 +48,45 @@ struct S3Args {
 // with the flipped filter [I][27][O]).  OUT: 0 = bf16 rows of 64 (NB * 16 channels written); 1 = f32 partial sums to
 // scratch; 2 = scratch + accumulator -> bf16 rows of yc = 64 (channels 32..63 zero) or 32 channels.  The data gradient contracts over 64 channels =
 // two launches of 32 (coff 0 / 32: an LDS ring of 64-channel slabs would need 233 KB), joined through the f32 scratch.
-template <bool AFF, bool STATS, int NB = 4, bool FLIP = false, int OUT = 0>
-__global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
+// CPW (round 4) = 16-channel blocks per WAVE.  1: eight waves, every B fragment (16 pixels x 32 channels of a tap, 1 KB) feeds one
+// MFMA -- the LDS read path (128 B / clk per CU) then holds the matrix pipe at 50 %.  2: four waves of 512 registers each keep the
+// filter fragments of two channel blocks (216 VGPRs), a fragment read feeds two MFMAs: half the LDS traffic per flop.
+template <bool AFF, bool STATS, int NB = 4, bool FLIP = false, int OUT = 0, int CPW = 1>
+__global__ __launch_bounds__(512 / CPW) void conv3d_c32_kernel(S3Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  constexpr int PARTS = 8 / NB;              // waves that share a channel block split the pixel blocks
-  const int nb = wave % NB, half = wave / NB;
+  constexpr int NW = 8 / CPW;                // waves
+  constexpr int NG = NB / CPW;               // groups of CPW channel blocks
+  constexpr int PARTS = NW / NG;             // waves that share a channel group split the pixel blocks
+  static_assert(NB % CPW == 0 && NW % NG == 0, "channel blocks per wave");
+  const int ng = wave % NG, half = wave / NG;
   const int W = p.W, H = p.H, T = p.T;
   const int rowb = (W + 2) * 64, slab = (S3_R + 2) * rowb;
   const unsigned smem_base = lds_addr_of(smem);
 
-  for (int i = tid * 16; i < S3_RING * slab; i += 512 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+  for (int i = tid * 16; i < S3_RING * slab; i += NW * 64 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
 
-  // filter fragments (A operand): row li = output channel 16 nb + li, k-group lg = input channels 8 lg .. 8 lg + 7 of the tap
-  uint4 wf[27];
+  // filter fragments (A operand): row li = output channel 16 (ng CPW + cb) + li, k-group lg = input channels 8 lg .. 8 lg + 7 of the tap
+  uint4 wf[CPW][27];
 #pragma unroll
-  for (int tap = 0; tap < 27; ++tap)
-    wf[tap] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(nb * 16 + li) * 27 + (FLIP ? 26 - tap : tap)) * 64 + p.coff + lg * 8);
+  for (int cb = 0; cb < CPW; ++cb)
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+      wf[cb][tap] = *reinterpret_cast<const uint4*>(p.w + ((size_t)((ng * CPW + cb) * 16 + li) * 27 + (FLIP ? 26 - tap : tap)) * 64 +
+                                                    p.coff + lg * 8);
 
-  float sc[4], sh[4], s1[4], s2[4];
+  float sc[CPW][4], sh[CPW][4], s1[CPW][4], s2[CPW][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ch = nb * 16 + lg * 4 + r;
-    sc[r] = AFF ? p.scale[ch] : 1.f;
-    sh[r] = AFF ? p.shift[ch] : 0.f;
-    s1[r] = s2[r] = 0.f;
-  }
+  for (int cb = 0; cb < CPW; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = (ng * CPW + cb) * 16 + lg * 4 + r;
+      sc[cb][r] = AFF ? p.scale[ch] : 1.f;
+      sh[cb][r] = AFF ? p.shift[ch] : 0.f;
+      s1[cb][r] = s2[cb][r] = 0.f;
+    }
 
   const int nbw = W >> 4;                    // blocks of 16 pixels per row
   const int ndma = (S3_R + 2) * nbw;         // 1 KB DMA instructions per frame slab
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
   // frame f of (clip b, rows h0 - 1 .. h0 + S3_R) -> ring slot f % 4; instruction j = (slab row, block of 16 pixels)
   auto dma_frame = [&](int b, int f, int h0) {
     const unsigned dst0 = smem_base + (unsigned)(f % S3_RING) * slab + 64;   // pixel 0 of a slab row is the left halo
-    for (int j = wave; j < ndma; j += 8) {
+    for (int j = wave; j < ndma; j += NW) {
       const int r = j / nbw, blk = j - r * nbw;
       const int hh = h0 - 1 + r;
       const unsigned char* src =
@@ -93,9 +109,8 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
 
   const int slabs_per_img = H / S3_R, nmb = S3_R * nbw;
   // OUT == 2: the first pass's partial sums of a frame's pixel blocks (W <= 128: at most two rounds of two blocks per wave) are
-  // requested a frame ahead.  (Loaded where they are added they cost a memory latency per pixel block with nothing to hide it:
-  // 968 us for this pass against 330 us for the first one at 32 clips x 8 frames of 112 x 112.)
-  float4 qc[4], qn[4];
+  // requested a frame ahead (loaded where they are added they cost a memory latency per pixel block with nothing to hide it)
+  float4 qc[4][CPW], qn[4][CPW];
   auto load_partials = [&](int b, int t, int h0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -103,7 +118,9 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
       if (m < nmb) {
         const int rr = m / nbw, cc = m - rr * nbw;
         const size_t pos = (((size_t)t * p.B + b) * H + h0 + rr) * W + cc * 16 + li;
-        qn[k] = *reinterpret_cast<const float4*>(p.scratch + pos * 32 + nb * 16 + lg * 4);
+#pragma unroll
+        for (int cb = 0; cb < CPW; ++cb)
+          qn[k][cb] = *reinterpret_cast<const float4*>(p.scratch + pos * 32 + (ng * CPW + cb) * 16 + lg * 4);
       }
     }
   };
@@ -119,7 +136,9 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
     for (int t = 0; t < T; ++t) {
       if (OUT == 2) {   // (in front of the DMA in issue order: the frame's closing vmcnt(0) then waits for loads a frame old)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) qc[k] = qn[k];
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int cb = 0; cb < CPW; ++cb) qc[k][cb] = qn[k][cb];
         if (t + 1 < T) load_partials(b, t + 1, h0);
       }
       if (t + 2 < T) dma_frame(b, t + 2, h0);   // into the slot of frame t - 2, which every wave finished before the last barrier
@@ -132,59 +151,82 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
         const int r1 = two ? mb1 / nbw : r0, c1 = two ? mb1 - r1 * nbw : c0;
         const unsigned char* a0 = smem + r0 * rowb + (c0 * 16 + li) * 64 + lg * 16;
         const unsigned char* a1 = smem + r1 * rowb + (c1 * 16 + li) * 64 + lg * 16;
-        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc0[CPW], acc1[CPW];
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt) {   // (unrolled: the filter fragments are registers; frames outside the clip: a uniform skip)
-          if (kt < kt_lo || kt > kt_hi) continue;
-          const int so = ((t + kt + S3_RING - 1) % S3_RING) * slab;
+        for (int cb = 0; cb < CPW; ++cb) acc0[cb] = acc1[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Nine groups (frame tap kt, row tap kh) of 6 fragment reads + 6 CPW MFMAs, software-pipelined by hand (round 4): the
+        // reads of group g + 1 are issued BEFORE the MFMAs of group g.  Written tap by tap the compiler waits for every read in
+        // front of its MFMA (the ISA was `ds_read_b128, s_waitcnt lgkmcnt(0), v_mfma` 54 times per round: one LDS latency per
+        // 16-cycle MFMA), and grouping the reads in the source alone does not survive its scheduler.  Frames outside the clip:
+        // a uniform skip of the group's reads and MFMAs.
+        uint4 xs[2][2][3];
+        auto live = [&](int g) { return g / 3 >= kt_lo && g / 3 <= kt_hi; };
+        auto read_group = [&](int g, uint4 (&x)[2][3]) {
+          const int kt = g / 3, kh = g - kt * 3;
+          const int off = ((t + kt + S3_RING - 1) % S3_RING) * slab + kh * rowb;
 #pragma unroll
-          for (int kh = 0; kh < 3; ++kh)
+          for (int kw = 0; kw < 3; ++kw) {
+            x[0][kw] = *reinterpret_cast<const uint4*>(a0 + off + kw * 64);
+            x[1][kw] = *reinterpret_cast<const uint4*>(a1 + off + kw * 64);
+          }
+        };
+        if (live(0)) read_group(0, xs[0]);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              const int off = so + kh * rowb + kw * 64;
-              const uint4 x0 = *reinterpret_cast<const uint4*>(a0 + off);
-              const uint4 x1 = *reinterpret_cast<const uint4*>(a1 + off);
-              const uint4 wk = wf[(kt * 3 + kh) * 3 + kw];
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk), __builtin_bit_cast(bf16x8, x0), acc0, 0,
-                                                             0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk), __builtin_bit_cast(bf16x8, x1), acc1, 0,
-                                                             0, 0);
-            }
+        for (int g = 0; g < 9; ++g) {
+          if (g + 1 < 9 && live(g + 1)) read_group(g + 1, xs[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (live(g)) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int cb = 0; cb < CPW; ++cb) {
+                const uint4 wk = wf[cb][g * 3 + kw];
+                acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk),
+                                                                   __builtin_bit_cast(bf16x8, xs[g & 1][0][kw]), acc0[cb], 0, 0, 0);
+                acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk),
+                                                                   __builtin_bit_cast(bf16x8, xs[g & 1][1][kw]), acc1[cb], 0, 0, 0);
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (u == 1 && !two) break;
-          const f32x4 acc = u ? acc1 : acc0;
           const int rr = u ? r1 : r0, cc = u ? c1 : c0;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = acc[r];
-            if (STATS) {
-              s1[r] += a;
-              s2[r] += a * a;
-            }
-            v[r] = a;
-            if (AFF) {
-              v[r] = a * sc[r] + sh[r];
-              if (p.relu) v[r] = fmaxf(v[r], 0.f);
-            }
-          }
           const size_t pos = (((size_t)t * p.B + b) * H + h0 + rr) * W + cc * 16 + li;
-          if (OUT == 1) {
-            *reinterpret_cast<float4*>(p.scratch + pos * 32 + nb * 16 + lg * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            continue;
-          }
-          if (OUT == 2) {
-            const float4 q = qc[it * 2 + u];
-            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-          }
-          bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          const int yc = OUT == 2 ? p.yc : 64;
-          *reinterpret_cast<bf16x4*>(p.y + pos * yc + nb * 16 + lg * 4) = o;
-          if (OUT == 2 && yc > 32) *reinterpret_cast<uint2*>(p.y + pos * 64 + 32 + nb * 16 + lg * 4) = make_uint2(0u, 0u);
+          for (int cb = 0; cb < CPW; ++cb) {
+            const f32x4 acc = u ? acc1[cb] : acc0[cb];
+            const int chb = (ng * CPW + cb) * 16 + lg * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = acc[r];
+              if (STATS) {
+                s1[cb][r] += a;
+                s2[cb][r] += a * a;
+              }
+              v[r] = a;
+              if (AFF) {
+                v[r] = a * sc[cb][r] + sh[cb][r];
+                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+              }
+            }
+            if (OUT == 1) {
+              *reinterpret_cast<float4*>(p.scratch + pos * 32 + chb) = make_float4(v[0], v[1], v[2], v[3]);
+              continue;
+            }
+            if (OUT == 2) {
+              const float4 q = qc[it * 2 + u][cb];
+              v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            const int yc = OUT == 2 ? p.yc : 64;
+            *reinterpret_cast<bf16x4*>(p.y + pos * yc + chb) = o;
+            if (OUT == 2 && yc > 32) *reinterpret_cast<uint2*>(p.y + pos * 64 + 32 + chb) = make_uint2(0u, 0u);
+          }
         }
       };
       if constexpr (OUT == 2) {   // (unrolled: the prefetched partial sums are registers)
@@ -194,23 +236,28 @@ __global__ __launch_bounds__(512) void conv3d_c32_kernel(S3Args p) {
       } else {
         for (int mb = half; mb < nmb; mb += 2 * PARTS) round(0, mb);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of frame t + 2 has landed
+      // this wave's share of frame t + 2 has landed.  (A counted wait that leaves the frame's stores outstanding -- the DMA is
+      // issued in front of them and the counter retires in order -- measured the same: 5.39 / 5.39 against 5.38 / 5.40 ms per
+      // Quadtree3DCNN step; the store acknowledgements are not what a frame waits for.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                     // ... everyone's has, and everyone is done with output frame t
     }
   }
 
   if (STATS) {
-    static_assert(!STATS || NB == 4, "statistics: the forward form");
+    static_assert(!STATS || (NB == 4 && PARTS == 2), "statistics: the forward form");
     // 16 lanes of a row hold 16 pixels of the same 4 channels; the two waves of a channel block through LDS, fixed order
     float* red = reinterpret_cast<float*>(smem);   // [2 halves][2][64]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float a1 = qt_row16_sum(s1[r]), a2 = qt_row16_sum(s2[r]);
-      if (li == 0) {
-        red[(half * 2 + 0) * 64 + nb * 16 + lg * 4 + r] = a1;
-        red[(half * 2 + 1) * 64 + nb * 16 + lg * 4 + r] = a2;
+    for (int cb = 0; cb < CPW; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a1 = qt_row16_sum(s1[cb][r]), a2 = qt_row16_sum(s2[cb][r]);
+        if (li == 0) {
+          red[(half * 2 + 0) * 64 + (ng * CPW + cb) * 16 + lg * 4 + r] = a1;
+          red[(half * 2 + 1) * 64 + (ng * CPW + cb) * 16 + lg * 4 + r] = a2;
+        }
       }
-    }
     __syncthreads();
     if (tid < 128) {
       const int which = tid >> 6, ch = tid & 63;
@@ -406,6 +453,15 @@ bool s3_enabled() {
   return on;
 }
 
+// QTCNN_S3_CPW (default 2): 16-channel blocks per wave of the forward / data-gradient slab kernel (1: the eight-wave form of round 3)
+int s3_cpw() {
+  static const int v = [] {
+    const char* e = getenv("QTCNN_S3_CPW");
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
+  return v;
+}
+
 bool s3_shape_ok(int batch, int frames, int h, int w) {
   return s3_enabled() && batch > 0 && frames > 0 && h >= S3_R && h % S3_R == 0 && w >= 16 && w % 16 == 0 && w <= 128;
 }
@@ -434,21 +490,25 @@ extern "C" int qt_conv3d_c32_fwd(int dtype, const void* x, int x_channels, const
   a.scratch = nullptr; a.coff = 0; a.yc = 64;
   int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
   if (lds < 2 * 2 * 64 * 4) lds = 2 * 2 * 64 * 4;
-  const dim3 grid(s3_grid(a.items)), blk(512);
+  const dim3 grid(s3_grid(a.items));
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = QT_OK;
-  if (scale) {
-    static std::atomic<unsigned long long> done{0};
-    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<true, false>, lds, done)) != QT_OK) return rc;
-    hipLaunchKernelGGL((conv3d_c32_kernel<true, false>), grid, blk, lds, s, a);
-  } else if (stats) {
-    static std::atomic<unsigned long long> done{0};
-    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, true>, lds, done)) != QT_OK) return rc;
-    hipLaunchKernelGGL((conv3d_c32_kernel<false, true>), grid, blk, lds, s, a);
+#define QT_S3_LAUNCH(...)                                                                                    \
+  do {                                                                                                       \
+    static std::atomic<unsigned long long> done{0};                                                          \
+    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<__VA_ARGS__>, lds, done)) != QT_OK) return rc; \
+    hipLaunchKernelGGL((conv3d_c32_kernel<__VA_ARGS__>), grid, blk, lds, s, a);                              \
+  } while (0)
+  if (s3_cpw() == 2) {
+    const dim3 blk(256);
+    if (scale) QT_S3_LAUNCH(true, false, 4, false, 0, 2);
+    else if (stats) QT_S3_LAUNCH(false, true, 4, false, 0, 2);
+    else QT_S3_LAUNCH(false, false, 4, false, 0, 2);
   } else {
-    static std::atomic<unsigned long long> done{0};
-    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, false>, lds, done)) != QT_OK) return rc;
-    hipLaunchKernelGGL((conv3d_c32_kernel<false, false>), grid, blk, lds, s, a);
+    const dim3 blk(512);
+    if (scale) QT_S3_LAUNCH(true, false);
+    else if (stats) QT_S3_LAUNCH(false, true);
+    else QT_S3_LAUNCH(false, false);
   }
   QT_CHECK_LAUNCH();
   return QT_OK;
@@ -478,23 +538,27 @@ extern "C" int qt_conv3d_c32_dgrad(int dtype, const void* dy, const void* w_dgra
   a.stats = nullptr; a.scratch = (float*)scratch;
   a.relu = 0; a.B = batch; a.T = frames; a.H = h; a.W = w; a.xc = 64; a.yc = dx_channels; a.items = batch * (h / S3_R);
   const int lds = S3_RING * (S3_R + 2) * (w + 2) * 64;
-  const dim3 grid(s3_grid(a.items)), blk(512);
+  const dim3 grid(s3_grid(a.items));
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = QT_OK;
-  {
-    static std::atomic<unsigned long long> done{0};
-    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, false, 2, true, 1>, lds, done)) != QT_OK) return rc;
+  if (s3_cpw() == 2) {
+    const dim3 blk(256);
     a.coff = 0;
-    hipLaunchKernelGGL((conv3d_c32_kernel<false, false, 2, true, 1>), grid, blk, lds, s, a);
+    QT_S3_LAUNCH(false, false, 2, true, 1, 2);
     QT_CHECK_LAUNCH();
-  }
-  {
-    static std::atomic<unsigned long long> done{0};
-    if ((rc = qt_raise_lds_limit((const void*)conv3d_c32_kernel<false, false, 2, true, 2>, lds, done)) != QT_OK) return rc;
     a.coff = 32;
-    hipLaunchKernelGGL((conv3d_c32_kernel<false, false, 2, true, 2>), grid, blk, lds, s, a);
+    QT_S3_LAUNCH(false, false, 2, true, 2, 2);
+    QT_CHECK_LAUNCH();
+  } else {
+    const dim3 blk(512);
+    a.coff = 0;
+    QT_S3_LAUNCH(false, false, 2, true, 1);
+    QT_CHECK_LAUNCH();
+    a.coff = 32;
+    QT_S3_LAUNCH(false, false, 2, true, 2);
     QT_CHECK_LAUNCH();
   }
+#undef QT_S3_LAUNCH
   return QT_OK;
 }
 
