@@ -4,12 +4,13 @@ scripts/collect_profiles.sh's command: 2 warm-up + 3 timed)."""
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
 steps = 5
 for d in sys.argv[1:]:
-    f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)   # (the latest run in the directory)
     agg = collections.defaultdict(lambda: [0, 0])
     for r in csv.DictReader(open(f)):
         n = re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", r["Kernel_Name"])

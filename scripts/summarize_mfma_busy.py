@@ -23,7 +23,7 @@ import bench  # noqa: E402
 out = {"kind": "mfma_busy", "model": "quadtree", "kernel_sources_sha1": bench.kernel_sources_sha1(), "counter": "SQ_VALU_MFMA_BUSY_CYCLES (rocprofv3 --pmc, one pass, --kernel-trace only)", "batch": 256, "dtype": "bf16",
        "simds": 1024, "clock_ghz_for_utilisation": 2.4, "busy_cycles_per_mfma_16x16x32": 16}
 for mode in ("train", "eval"):
-    f = glob.glob(os.path.join(root, "gpurun_out", name, mode, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(root, "gpurun_out", name, mode, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # (the latest run: gpurun merges every call into the same directory)
     busy = collections.defaultdict(float)
     launches = collections.Counter()
     for r in csv.DictReader(open(f)):

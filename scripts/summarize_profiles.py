@@ -24,6 +24,11 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", name)
 
 
+def newest(paths):
+    """gpurun merges every call's outputs into the same local directory: take the file of the LATEST run, never glob()[0]"""
+    return max(paths, key=os.path.getmtime)
+
+
 def family(kernel):
     if model != "quadtree":   # other models: the kernel's own name without template / call arguments
         m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kernel)          # mangled: length-prefixed name behind the anonymous namespace
@@ -44,7 +49,7 @@ def family(kernel):
 
 
 def pmc(sub, counter):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    f = [newest(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")))]
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] == counter:
@@ -54,7 +59,7 @@ def pmc(sub, counter):
     return agg
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
 rows = list(csv.DictReader(open(stats)))
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 stem = tag if model == "quadtree" else f"{tag}_{model}"
